@@ -1,0 +1,246 @@
+/*
+ * rthip.h -- C ABI of the MI355X (gfx950) rendering backend.
+ *
+ * The library behind this header replaces ONE path of patricklbell/raytracer:
+ * LBVH build -> TLAS/BLAS traversal -> ray/triangle intersection -> shading ->
+ * framebuffer.  Every entry point below names the reference interface it stands
+ * in for (paths relative to the reference's repository root).
+ *
+ * Conventions
+ *   - plain C, POD arguments only; no HIP or torch types in any signature
+ *     (streams travel as `void*` holding a hipStream_t, NULL = default stream);
+ *   - every function returns 0 on success and a non-zero RTHIP_E_* code on
+ *     failure; rthip_last_error() then returns a human readable message;
+ *   - "host" pointers are ordinary CPU memory, "device" pointers (`d_` prefix)
+ *     are HBM addresses valid on the context's GPU;
+ *   - arrays of meshes / instances / materials are passed in the order in which
+ *     the reference iterates its world lists (`first -> next`), i.e. element 0
+ *     is the item that was added LAST (src/raytracer/raytracer_core.c:21,37,53
+ *     push to the front).  TLAS ids are 1-based indices into that order,
+ *     exactly like `id = idx + 1` in src/lbvh/lbvh.c:116.
+ *   - one context drives one GPU.  Multi-GPU jobs run one process (one context)
+ *     per GPU and shard with rthip_shard.
+ */
+#ifndef RTHIP_H
+#define RTHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTHIP_ABI_VERSION 1
+
+enum {
+    RTHIP_OK = 0,
+    RTHIP_E_INVALID = 1,  /* bad argument / call order                      */
+    RTHIP_E_HIP = 2,      /* a HIP runtime call failed                      */
+    RTHIP_E_NOMEM = 3,    /* device or host allocation failed               */
+    RTHIP_E_LIMIT = 4     /* input exceeds a documented limit               */
+};
+
+/* RT_MaterialType, src/raytracer/raytracer_core.h:65-72 (same numeric values) */
+enum {
+    RTHIP_MAT_LAMBERTIAN = 0,
+    RTHIP_MAT_DIELECTRIC = 1,
+    RTHIP_MAT_METAL = 2,
+    RTHIP_MAT_NORMAL = 3,
+    RTHIP_MAT_LIGHT = 4
+};
+
+/* RT_InstanceType, src/raytracer/raytracer_core.h:31-35 (same numeric values) */
+enum { RTHIP_INST_SPHERE = 0, RTHIP_INST_MESH = 1 };
+
+/* RT_Material, src/raytracer/raytracer_core.h:74-84 */
+typedef struct rthip_material {
+    uint32_t type;
+    float albedo[3];
+    float emissive[3];
+    float roughness;
+    float ior;
+    uint32_t billboard;
+} rthip_material;
+
+/* RT_Instance (+ RT_SphereInstance / RT_MeshInstance),
+ * src/raytracer/raytracer_core.h:17-45.  `material` is the index of the
+ * material in the array given to rthip_tlas_build, -1 for the reference's zero
+ * handle (src/raytracer/cpu/raytracer_cpu.c:264-266).  `blas_id` is the value
+ * the reference stores in RT_Mesh.blas_id (raytracer_cpu.c:112). */
+typedef struct rthip_instance {
+    uint32_t type;
+    int32_t material;
+    uint32_t blas_id;
+    float sphere_center[3];
+    float sphere_radius;
+    float translation[3];
+    float rotation[4]; /* quaternion x,y,z,w */
+    float scale[3];
+} rthip_instance;
+
+/* RT_CastSettings, src/raytracer/raytracer_core.h:163-178 */
+typedef struct rthip_cast_settings {
+    float eye[3];
+    float up[3];
+    float forward[3];
+    float right[3];
+    float viewport[3];
+    uint32_t samples; /* per axis: samples*samples paths per pixel */
+    float ior;
+    uint32_t defocus;
+    float defocus_disk[2];
+    uint32_t orthographic;
+} rthip_cast_settings;
+
+/* One LBVH node in depth-first pre-order.  The left child of an inner node is
+ * the next record; `skip` is the index of the first record after the node's
+ * subtree (== node count for the last subtree).  `id` is 0 for inner nodes and
+ * the 1-based primitive id for leaves: the same value as LBVH_Node.id,
+ * src/lbvh/lbvh.h:4-9.  Serialising records in array order reproduces the
+ * reference's dump (src/lbvh/extra/dump.c:1-13) up to its null-child bytes. */
+typedef struct rthip_node {
+    float aabb_min[3];
+    uint32_t skip;
+    float aabb_max[3];
+    uint32_t id;
+} rthip_node;
+
+/* How one context's share of a frame is chosen when several GPUs render it.
+ * mode 0: everything.  mode 1 (tiles): pixels are cut into 64x64 tiles numbered
+ * row-major; this context renders tiles with (tile % world) == rank and leaves
+ * other pixels at 0, so the shares sum to the frame.  mode 2 (samples): this
+ * context renders sample indices s with (s % world) == rank of every pixel and
+ * writes the plain sum of their radiance (no 1/spp factor). */
+typedef struct rthip_shard {
+    uint32_t mode;
+    uint32_t rank;
+    uint32_t world;
+} rthip_shard;
+
+/* Counters of the most recent cast / trace call and timings of the most recent
+ * build, read back on demand. */
+typedef struct rthip_stats {
+    uint64_t rays;          /* TLAS closest-hit queries (primary + bounces)   */
+    uint64_t nodes_tested;  /* BVH nodes whose box was tested (both levels)   */
+    uint64_t tris_tested;   /* triangles handed to the triangle test          */
+    uint64_t inst_entered;  /* TLAS leaves entered                            */
+    float last_cast_ms;     /* device time of the last cast / trace kernel(s) */
+    float last_build_ms;    /* device time of the last LBVH build             */
+} rthip_stats;
+
+typedef struct rthip_ctx rthip_ctx;
+
+/* ---- life cycle ------------------------------------------------------- */
+
+/* rt_make_tracer, src/raytracer/cpu/raytracer_cpu.c:14-25 (allocation part).
+ * Fails (RTHIP_E_HIP) when no gfx950 device `device_id` is usable: there is no
+ * CPU fallback. */
+int rthip_create(rthip_ctx** out_ctx, int device_id);
+/* rt_tracer_cleanup, raytracer_cpu.c:38-43 */
+void rthip_destroy(rthip_ctx* ctx);
+/* No counterpart (the reference hooks return void and assert). */
+const char* rthip_last_error(const rthip_ctx* ctx);
+int rthip_abi_version(void);
+
+/* RT_TracerSettings as copied by rt_make_tracer, raytracer_cpu.c:20-21
+ * (winding order is never copied there, so it does not exist here). */
+int rthip_set_tracer(rthip_ctx* ctx, uint32_t max_bounces, int sky);
+
+/* ---- acceleration structures ------------------------------------------ */
+
+/* rt_tracer_build_blas -> rt_cpu_build_blas, raytracer_cpu.c:26-31,101-116.
+ * begin discards any previous BLAS set (arena_clear, :29); add_mesh copies one
+ * mesh to HBM (the caller's memory is not retained); commit builds one LBVH
+ * per mesh (rt_cpu_blas_node_from_mesh, :57-99 + lbvh_make, src/lbvh/lbvh.c:92).
+ * `verts` is the reference's interleaved vertex buffer (16 bytes per present
+ * attribute, src/geo/geo.c:2-15); nrm_off < 0 means "no normal attribute";
+ * idx == NULL or index_count == 0 means auto-index (raytracer_cpu.c:59). */
+int rthip_blas_begin(rthip_ctx* ctx, uint32_t n_meshes);
+int rthip_blas_add_mesh(rthip_ctx* ctx, uint32_t blas_id, const void* verts, uint32_t vertex_count,
+                        uint32_t stride_bytes, uint32_t pos_off, int32_t nrm_off, const uint32_t* idx,
+                        uint32_t index_count);
+int rthip_blas_commit(rthip_ctx* ctx);
+
+/* rt_tracer_build_tlas -> rt_cpu_build_tlas, raytracer_cpu.c:32-37,149-174:
+ * world AABB per instance (:131-147, :583-606) then lbvh_make over them. */
+int rthip_tlas_build(rthip_ctx* ctx, const rthip_instance* instances, uint32_t n_instances,
+                     const rthip_material* materials, uint32_t n_materials);
+
+/* ---- rendering --------------------------------------------------------- */
+
+/* rt_tracer_cast -> rt_cpu_raygen, raytracer_cpu.c:45-49,179-242.  out_rgb is
+ * host memory, width*height*3 floats, row-major, y down, fully overwritten.
+ * `seed` replaces the reference's global srand() state (src/demos/demos_inc.c:97):
+ * random numbers come from a counter-based generator keyed by (seed, pixel,
+ * sample, draw index), so the image does not depend on scheduling or GPU count. */
+int rthip_cast(rthip_ctx* ctx, const rthip_cast_settings* cast, uint64_t seed, float* out_rgb, int width, int height);
+
+/* Same work with the framebuffer in HBM and no host synchronisation: the call
+ * only enqueues on `stream`.  With shard->mode != 0 the buffer holds this
+ * context's share as described at rthip_shard.  shard == NULL means mode 0. */
+int rthip_cast_device(rthip_ctx* ctx, const rthip_cast_settings* cast, uint64_t seed, float* d_out_rgb, int width,
+                      int height, const rthip_shard* shard, void* stream);
+
+/* ---- parity and measurement taps -------------------------------------- */
+
+/* lbvh_make, src/lbvh/lbvh.c:92-125, on caller-supplied boxes (n x {min[3],max[3]}).
+ * Any output pointer may be NULL.  out_codes[i] is the Morton code of box i
+ * (lbvh_c_to_morton_code, lbvh.c:74-90, release-mode centroid bounds :97-100);
+ * out_codes_sorted / out_ids_sorted are the sorted NodeIndex array (lbvh.c:5-8,120;
+ * ids 1-based; equal codes keep ascending id); out_nodes receives 2n-1 pre-order
+ * records.  out_ms = device time of the build kernels. */
+int rthip_lbvh_build(rthip_ctx* ctx, const float* aabb6, uint64_t n, uint64_t* out_codes,
+                     uint64_t* out_codes_sorted, uint32_t* out_ids_sorted, rthip_node* out_nodes,
+                     float* out_ms);
+
+/* The same build with the boxes already in HBM and the tree left in HBM: what the
+ * build benchmark times.  d_nodes must hold 2n-1 records.  Enqueues on `stream`
+ * and returns without synchronising. */
+int rthip_lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, rthip_node* d_nodes, void* stream);
+
+/* rt_cpu_blas_node_from_mesh, raytracer_cpu.c:57-99, for one mesh whose vertex
+ * positions (SoA: d_px, d_py, d_pz) and indices are already in HBM: triangle
+ * boxes + lbvh_make.  d_indices == NULL means auto-index.  d_nodes must hold
+ * 2*n_tris-1 records. */
+int rthip_mesh_build_device(rthip_ctx* ctx, const float* d_px, const float* d_py, const float* d_pz,
+                            uint32_t vertex_count, const uint32_t* d_indices, uint64_t n_tris,
+                            rthip_node* d_nodes, void* stream);
+
+/* One closest-hit query per pixel with the pixel-centre ray that rt_cpu_raygen
+ * generates for samples == 1 (raytracer_cpu.c:195-231, no defocus jitter):
+ * lbvh_query_ray on the TLAS with rt_cpu_tlas_hit (raytracer_cpu.c:402-407).
+ * out_instance_id = 1-based TLAS leaf id (0 = miss), out_tri_idx = index-buffer
+ * offset of the triangle ((id-1)*3, raytracer_cpu.c:467,479; 0 for spheres and
+ * misses), out_t = interval.max after the query (-1.0f on a miss). */
+int rthip_primary_hits(rthip_ctx* ctx, const rthip_cast_settings* cast, uint32_t* out_instance_id,
+                       uint32_t* out_tri_idx, float* out_t, int width, int height);
+
+/* rt_cpu_intersect, raytracer_cpu.c:402-457, for n caller-supplied rays (host
+ * arrays of 3 floats each; directions are used as given).  Outputs as for
+ * rthip_primary_hits; out_uv (2 floats per ray, may be NULL) receives the
+ * barycentrics stored by geo_intersect_tri (src/geo/geo.c:106-107); out_normal
+ * (3 floats per ray, may be NULL) the shading normal of raytracer_cpu.c:421-453. */
+int rthip_trace_rays(rthip_ctx* ctx, const float* origins, const float* directions, uint64_t n,
+                     uint32_t* out_instance_id, uint32_t* out_tri_idx, float* out_t, float* out_uv,
+                     float* out_normal);
+
+/* The same query with rays and results in HBM (SoA not required: o and d are n x 3
+ * floats); enqueues on `stream` without synchronising.  d_hits is n x 4 uint32:
+ * {instance id, tri_idx, t bits, 0}. */
+int rthip_trace_rays_device(rthip_ctx* ctx, const float* d_origins, const float* d_directions, uint64_t n,
+                            uint32_t* d_hits, void* stream);
+
+/* Reads (and clears) the traversal counters; blocks until the context's work is done. */
+int rthip_get_stats(rthip_ctx* ctx, rthip_stats* out);
+/* Turns traversal counting on or off (off by default: counting costs atomics). */
+int rthip_set_counting(rthip_ctx* ctx, int enabled);
+
+/* TLAS / BLAS tree read-back for dumps in the reference's format
+ * (src/lbvh/extra/dump.c): which = -1 for the TLAS, otherwise a blas_id.
+ * *out_count receives the node count; out_nodes (may be NULL) must hold that many. */
+int rthip_get_tree(rthip_ctx* ctx, int which, rthip_node* out_nodes, uint64_t* out_count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTHIP_H */

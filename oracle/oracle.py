@@ -1,0 +1,387 @@
+"""TEST INFRASTRUCTURE -- ctypes access to the CPU oracle (oracle/librt_oracle.so) and, when it
+has been built in a container that holds the reference, to the unmodified reference
+(oracle/_ref/*.so).  Imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg only; nothing under raytracer_amd/ may import this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+
+from raytracer_amd import abi
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_SO = os.path.join(HERE, "librt_oracle.so")
+REF_DIR = os.path.join(HERE, "_ref")
+_P = C.c_void_p
+
+RNG_GLIBC, RNG_COUNTER = 0, 1
+
+
+class MeshDesc(C.Structure):
+    _fields_ = [("verts", _P), ("vertex_count", C.c_uint32), ("stride_bytes", C.c_uint32), ("pos_off", C.c_uint32),
+                ("nrm_off", C.c_int32), ("indices", _P), ("index_count", C.c_uint32)]
+
+
+class RefMeshDesc(C.Structure):
+    _fields_ = [("verts", _P), ("vertex_count", C.c_uint32), ("indices", _P), ("index_count", C.c_uint32),
+                ("attrs", C.c_uint32)]
+
+
+COUNTERS = np.dtype([("rays", "<u8"), ("nodes_tested", "<u8"), ("tris_tested", "<u8"), ("inst_entered", "<u8")])
+
+
+def build_oracle() -> None:
+    subprocess.check_call(["make", "-s", "-C", HERE, "oracle"])
+
+
+_oracle = None
+
+
+def lib() -> C.CDLL:
+    global _oracle
+    if _oracle is None:
+        if not os.path.exists(ORACLE_SO):
+            build_oracle()
+        L = C.CDLL(ORACLE_SO)
+        L.ora_morton.restype = C.c_uint64
+        L.ora_morton.argtypes = [_P, _P, _P]
+        L.ora_lbvh_build.restype = C.c_int
+        L.ora_lbvh_build.argtypes = [_P, C.c_uint64, _P, _P, _P, _P]
+        L.ora_lbvh_dump.restype = C.c_uint64
+        L.ora_lbvh_dump.argtypes = [_P, C.c_uint64, _P, C.c_uint64]
+        L.ora_slab.restype = C.c_int
+        L.ora_slab.argtypes = [_P, _P, _P]
+        L.ora_intersect_tri.restype = C.c_int
+        L.ora_intersect_tri.argtypes = [_P] * 6
+        L.ora_intersect_sphere.restype = C.c_int
+        L.ora_intersect_sphere.argtypes = [_P, _P, C.c_float, _P]
+        L.ora_transform_aabb.restype = None
+        L.ora_transform_aabb.argtypes = [_P] * 5
+        L.ora_tri_aabbs.restype = None
+        L.ora_tri_aabbs.argtypes = [C.POINTER(MeshDesc), _P]
+        L.ora_cast_settings.restype = None
+        L.ora_cast_settings.argtypes = [C.c_int, C.c_int, C.c_uint32, _P, _P, C.c_float, C.c_int, C.c_float, _P]
+        L.ora_a_to_b_quat.restype = None
+        L.ora_a_to_b_quat.argtypes = [_P, _P, _P]
+        L.ora_srand.restype = None
+        L.ora_srand.argtypes = [C.c_uint32]
+        L.ora_rand.restype = C.c_int
+        L.ora_counter_rand.restype = C.c_uint32
+        L.ora_counter_rand.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]
+        L.ora_poly_sin.restype = C.c_float
+        L.ora_poly_sin.argtypes = [C.c_float]
+        L.ora_poly_cos.restype = C.c_float
+        L.ora_poly_cos.argtypes = [C.c_float]
+        L.ora_scene_create.restype = _P
+        L.ora_scene_create.argtypes = [C.c_uint32, C.c_int, _P, C.c_uint32, _P, C.c_uint32, _P, C.c_uint32]
+        L.ora_scene_destroy.restype = None
+        L.ora_scene_destroy.argtypes = [_P]
+        L.ora_scene_get_tree.restype = C.c_int
+        L.ora_scene_get_tree.argtypes = [_P, C.c_int, _P, _P]
+        L.ora_scene_trace.restype = None
+        L.ora_scene_trace.argtypes = [_P, _P, _P, C.c_uint64, _P, _P, _P, _P, _P, _P, C.c_int]
+        L.ora_primary_rays.restype = None
+        L.ora_primary_rays.argtypes = [_P, C.c_int, C.c_int, _P, _P]
+        L.ora_scene_cast.restype = None
+        L.ora_scene_cast.argtypes = [_P, _P, C.c_uint64, C.c_int, _P, C.c_int, C.c_int, _P, C.c_int, _P]
+        _oracle = L
+    return _oracle
+
+
+# ---- LBVH ------------------------------------------------------------------------
+
+
+def lbvh_build(aabbs: np.ndarray):
+    """ora_lbvh_build -> (codes, codes_sorted, ids_sorted, nodes)."""
+    aabbs = np.ascontiguousarray(aabbs, dtype=np.float32).reshape(-1, 6)
+    n = aabbs.shape[0]
+    codes = np.zeros(n, dtype=np.uint64)
+    cs = np.zeros(n, dtype=np.uint64)
+    ids = np.zeros(n, dtype=np.uint32)
+    nodes = np.zeros(2 * n - 1, dtype=abi.NODE)
+    rc = lib().ora_lbvh_build(abi.ptr(aabbs), n, abi.ptr(codes), abi.ptr(cs), abi.ptr(ids), abi.ptr(nodes))
+    assert rc == 0
+    return codes, cs, ids, nodes
+
+
+def dump_bytes(nodes: np.ndarray) -> bytes:
+    """Pre-order records -> the byte stream of the reference's lbvh_dump_tree (src/lbvh/extra/dump.c)."""
+    nodes = np.ascontiguousarray(nodes, dtype=abi.NODE)
+    need = lib().ora_lbvh_dump(abi.ptr(nodes), nodes.size, None, 0)
+    buf = np.zeros(need, dtype=np.uint8)
+    got = lib().ora_lbvh_dump(abi.ptr(nodes), nodes.size, abi.ptr(buf), need)
+    assert got == need
+    return buf.tobytes()
+
+
+def parse_dump(data: bytes) -> np.ndarray:
+    """The reference's dump byte stream -> pre-order abi.NODE records (skip links rebuilt)."""
+    ids, boxes, skips = [], [], []
+    # explicit stack of [node index, children still to read]; a record is: 1, id, min, max, left, right | 0
+    pos = 0
+    open_nodes = []
+    while True:
+        present = data[pos]
+        pos += 1
+        if present:
+            ids.append(int.from_bytes(data[pos:pos + 8], "little"))
+            boxes.append(np.frombuffer(data, dtype="<f4", count=6, offset=pos + 8))
+            skips.append(0)
+            pos += 32
+            open_nodes.append([len(ids) - 1, 2])
+            continue
+        # a null child: the innermost open node has one child fewer to read
+        open_nodes[-1][1] -= 1
+        while open_nodes and open_nodes[-1][1] == 0:
+            idx, _ = open_nodes.pop()
+            skips[idx] = len(ids)
+            if open_nodes:
+                open_nodes[-1][1] -= 1
+        if not open_nodes:
+            break
+    assert pos == len(data), "trailing bytes in dump"
+    out = np.zeros(len(ids), dtype=abi.NODE)
+    b = np.array(boxes, dtype=np.float32).reshape(-1, 6)
+    out["id"] = np.array(ids, dtype=np.uint64).astype(np.uint32)
+    out["aabb_min"] = b[:, 0:3]
+    out["aabb_max"] = b[:, 3:6]
+    out["skip"] = np.array(skips, dtype=np.uint32)
+    return out
+
+
+# ---- scenes ------------------------------------------------------------------------
+
+
+def _mesh_descs(meshes: list):
+    arr = (MeshDesc * max(len(meshes), 1))()
+    for k, m in enumerate(meshes):
+        arr[k].verts = abi.ptr(m["verts"])
+        arr[k].vertex_count = m["vertex_count"]
+        arr[k].stride_bytes = m["stride"]
+        arr[k].pos_off = m["pos_off"]
+        arr[k].nrm_off = m["nrm_off"]
+        arr[k].indices = abi.ptr(m["indices"]) if m["indices"] is not None else None
+        arr[k].index_count = 0 if m["indices"] is None else m["indices"].size
+    return arr
+
+
+def tri_aabbs(mesh: dict) -> np.ndarray:
+    arr = _mesh_descs([mesh])
+    n = (mesh["indices"].size if mesh["indices"] is not None else mesh["vertex_count"]) // 3
+    out = np.zeros((n, 6), dtype=np.float32)
+    lib().ora_tri_aabbs(arr, abi.ptr(out))
+    return out
+
+
+class Scene:
+    """A world handed to the oracle (same flat arrays as the C ABI takes)."""
+
+    def __init__(self, flat, max_bounces: int, sky: bool):
+        self.flat = flat
+        descs = _mesh_descs(flat.meshes)
+        self.h = lib().ora_scene_create(max_bounces, 1 if sky else 0, descs, len(flat.meshes),
+                                        abi.ptr(flat.instances), flat.instances.size, abi.ptr(flat.materials),
+                                        flat.materials.size)
+
+    def close(self):
+        if self.h:
+            lib().ora_scene_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def tree(self, which: int) -> np.ndarray:
+        cnt = C.c_uint64(0)
+        assert lib().ora_scene_get_tree(self.h, which, None, C.addressof(cnt)) == 0
+        nodes = np.zeros(cnt.value, dtype=abi.NODE)
+        lib().ora_scene_get_tree(self.h, which, abi.ptr(nodes), C.addressof(cnt))
+        return nodes
+
+    def trace(self, o, d, threads=1, want_normal=True):
+        o = np.ascontiguousarray(o, dtype=np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(d, dtype=np.float32).reshape(-1, 3)
+        n = o.shape[0]
+        inst = np.zeros(n, dtype=np.uint32)
+        tri = np.zeros(n, dtype=np.uint32)
+        t = np.zeros(n, dtype=np.float32)
+        uv = np.zeros((n, 2), dtype=np.float32)
+        nrm = np.zeros((n, 3), dtype=np.float32) if want_normal else None
+        cnt = np.zeros(1, dtype=COUNTERS)
+        lib().ora_scene_trace(self.h, abi.ptr(o), abi.ptr(d), n, abi.ptr(inst), abi.ptr(tri), abi.ptr(t), abi.ptr(uv),
+                              abi.ptr(nrm), abi.ptr(cnt), threads)
+        return inst, tri, t, uv, nrm, {k: int(cnt[0][k]) for k in COUNTERS.names}
+
+    def cast(self, cast, seed, width, height, rng_mode=RNG_COUNTER, shard=None, threads=1):
+        cast = np.ascontiguousarray(cast, dtype=abi.CAST).reshape(1)
+        out = np.zeros((height, width, 3), dtype=np.float32)
+        cnt = np.zeros(1, dtype=COUNTERS)
+        sh = None
+        if shard is not None:
+            sh = np.zeros(1, dtype=abi.SHARD)
+            sh[0] = shard
+        lib().ora_scene_cast(self.h, abi.ptr(cast), int(seed) & (2**64 - 1), rng_mode, abi.ptr(out), width, height,
+                             abi.ptr(sh), threads, abi.ptr(cnt))
+        return out, {k: int(cnt[0][k]) for k in COUNTERS.names}
+
+
+def primary_rays(cast, width, height):
+    cast = np.ascontiguousarray(cast, dtype=abi.CAST).reshape(1)
+    o = np.zeros((width * height, 3), dtype=np.float32)
+    d = np.zeros((width * height, 3), dtype=np.float32)
+    lib().ora_primary_rays(abi.ptr(cast), width, height, abi.ptr(o), abi.ptr(d))
+    return o, d
+
+
+# ---- the unmodified reference (only where oracle/_ref has been built) ---------------
+
+
+def have_ref(name: str = "core") -> bool:
+    return os.path.exists(os.path.join(REF_DIR, f"libref_{name}.so"))
+
+
+_ref_libs = {}
+
+
+def ref(name: str = "core") -> C.CDLL:
+    if name not in _ref_libs:
+        L = C.CDLL(os.path.join(REF_DIR, f"libref_{name}.so"))
+        if name.startswith("core"):
+            L.ref_morton.restype = C.c_uint64
+            L.ref_morton.argtypes = [_P, _P, _P]
+            L.ref_lbvh_build.restype = C.c_int
+            L.ref_lbvh_build.argtypes = [_P, C.c_uint64, _P, _P, _P, C.c_uint64, _P, _P]
+            L.ref_lbvh_dump_file.argtypes = [_P, C.c_uint64, C.c_char_p]
+            L.ref_slab.argtypes = [_P, _P, _P]
+            L.ref_intersect_tri.argtypes = [_P] * 6
+            L.ref_intersect_sphere.argtypes = [_P, _P, C.c_float, _P]
+            L.ref_transform_aabb.restype = None
+            L.ref_transform_aabb.argtypes = [_P] * 5
+            L.ref_cast_settings.restype = None
+            L.ref_cast_settings.argtypes = [C.c_int, C.c_int, C.c_uint32, _P, _P, C.c_float, C.c_int, C.c_float, _P]
+            L.ref_a_to_b_quat.restype = None
+            L.ref_a_to_b_quat.argtypes = [_P, _P, _P]
+            L.ref_scene_create.restype = _P
+            L.ref_scene_create.argtypes = [C.c_uint32, C.c_int, _P, C.c_uint32, _P, C.c_uint32, _P, C.c_uint32]
+            L.ref_scene_destroy.restype = None
+            L.ref_scene_destroy.argtypes = [_P]
+            L.ref_scene_cast.restype = C.c_double
+            L.ref_scene_cast.argtypes = [_P, _P, C.c_int, _P, C.c_int, C.c_int, C.c_char_p]
+            L.ref_scene_trace.restype = C.c_double
+            L.ref_scene_trace.argtypes = [_P, _P, _P, C.c_uint64, _P, _P, _P, _P, _P]
+            L.ref_scene_dump_tree.argtypes = [_P, C.c_int, _P, C.c_uint64, _P]
+            L.ref_load_obj.argtypes = [C.c_char_p, C.c_uint32, _P, C.c_uint64, _P, _P, C.c_uint64, _P]
+        else:
+            L.ref_demo_run.restype = C.c_int
+            L.ref_demo_run.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, _P, _P, _P, _P,
+                                       C.c_uint64, _P, _P, _P, _P, C.c_uint64, _P, _P]
+        _ref_libs[name] = L
+    return _ref_libs[name]
+
+
+def ref_lbvh_build(aabbs: np.ndarray, flavour="core"):
+    """lbvh_make run by the reference -> (codes, ids_in_tree_order, dump bytes, seconds)."""
+    aabbs = np.ascontiguousarray(aabbs, dtype=np.float32).reshape(-1, 6)
+    n = aabbs.shape[0]
+    codes = np.zeros(n, dtype=np.uint64)
+    ids = np.zeros(n, dtype=np.uint64)
+    cap = 70 * n + 64
+    dump = np.zeros(cap, dtype=np.uint8)
+    ln = C.c_uint64(0)
+    sec = C.c_double(0)
+    rc = ref(flavour).ref_lbvh_build(abi.ptr(aabbs), n, abi.ptr(codes), abi.ptr(ids), abi.ptr(dump), cap,
+                                     C.addressof(ln), C.addressof(sec))
+    assert rc == 0
+    return codes, ids, dump[: ln.value].tobytes(), sec.value
+
+
+class RefScene:
+    """A world built through the reference's own scene API and traced by its own code."""
+
+    def __init__(self, flat, max_bounces: int, sky: bool, flavour="core"):
+        self.L = ref(flavour)
+        self.flat = flat
+        descs = (RefMeshDesc * max(len(flat.meshes), 1))()
+        for k, m in enumerate(flat.meshes):
+            descs[k].verts = abi.ptr(m["verts"])
+            descs[k].vertex_count = m["vertex_count"]
+            descs[k].indices = abi.ptr(m["indices"]) if m["indices"] is not None else None
+            descs[k].index_count = 0 if m["indices"] is None else m["indices"].size
+            descs[k].attrs = m["attrs"]
+        self.h = self.L.ref_scene_create(max_bounces, 1 if sky else 0, descs, len(flat.meshes),
+                                         abi.ptr(flat.instances), flat.instances.size, abi.ptr(flat.materials),
+                                         flat.materials.size)
+
+    def close(self):
+        if self.h:
+            self.L.ref_scene_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def tree_dump(self, which: int) -> bytes:
+        ln = C.c_uint64(0)
+        assert self.L.ref_scene_dump_tree(self.h, which, None, 0, C.addressof(ln)) == 0
+        buf = np.zeros(ln.value, dtype=np.uint8)
+        assert self.L.ref_scene_dump_tree(self.h, which, abi.ptr(buf), ln.value, C.addressof(ln)) == 0
+        return buf.tobytes()
+
+    def trace(self, o, d, want_normal=True):
+        o = np.ascontiguousarray(o, dtype=np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(d, dtype=np.float32).reshape(-1, 3)
+        n = o.shape[0]
+        inst = np.zeros(n, dtype=np.uint32)
+        tri = np.zeros(n, dtype=np.uint32)
+        t = np.zeros(n, dtype=np.float32)
+        uv = np.zeros((n, 2), dtype=np.float32)
+        nrm = np.zeros((n, 3), dtype=np.float32) if want_normal else None
+        sec = self.L.ref_scene_trace(self.h, abi.ptr(o), abi.ptr(d), n, abi.ptr(inst), abi.ptr(tri), abi.ptr(t),
+                                     abi.ptr(uv), abi.ptr(nrm))
+        return inst, tri, t, uv, nrm, sec
+
+    def cast(self, cast, seed, width, height, workdir=None):
+        cast = np.ascontiguousarray(cast, dtype=abi.CAST).reshape(1)
+        out = np.zeros((height, width, 3), dtype=np.float32)
+        wd = workdir.encode() if workdir else None
+        sec = self.L.ref_scene_cast(self.h, abi.ptr(cast), int(seed), abi.ptr(out), width, height, wd)
+        return out, sec
+
+
+def ref_demo(name, width, height, samples, bounces, seed, rays=None, workdir=None):
+    """Runs an unmodified reference demo program.  Returns dict(rgb, cast, tlas_dump, n_instances, hits)."""
+    L = ref(name)
+    rgb = np.zeros((height, width, 3), dtype=np.float32)
+    cast = np.zeros(1, dtype=abi.CAST)
+    cap = 1 << 22
+    dump = np.zeros(cap, dtype=np.uint8)
+    ln = C.c_uint64(0)
+    ninst = C.c_uint32(0)
+    n = 0
+    o = d = inst = tri = t = None
+    if rays is not None:
+        o = np.ascontiguousarray(rays[0], dtype=np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(rays[1], dtype=np.float32).reshape(-1, 3)
+        n = o.shape[0]
+        inst = np.zeros(n, dtype=np.uint32)
+        tri = np.zeros(n, dtype=np.uint32)
+        t = np.zeros(n, dtype=np.float32)
+    tmp = None
+    if workdir is None:
+        tmp = tempfile.TemporaryDirectory()
+        workdir = tmp.name
+    rc = L.ref_demo_run(width, height, samples, bounces, seed, workdir.encode(), abi.ptr(rgb), abi.ptr(cast),
+                        abi.ptr(o), abi.ptr(d), n, abi.ptr(inst), abi.ptr(tri), abi.ptr(t), abi.ptr(dump), cap,
+                        C.addressof(ln), C.addressof(ninst))
+    rays_file = os.path.join(workdir, "out.rays")
+    ray_records = open(rays_file, "rb").read() if os.path.exists(rays_file) else None
+    if tmp is not None:
+        tmp.cleanup()
+    assert rc == 0
+    return dict(rgb=rgb, cast=cast, tlas_dump=dump[: ln.value].tobytes(), n_instances=ninst.value,
+                hits=(inst, tri, t), ray_records=ray_records)

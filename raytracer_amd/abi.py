@@ -1,0 +1,104 @@
+"""ctypes view of include/rthip.h: record layouts and the loader for librthip.so.
+
+The records are numpy structured dtypes whose field offsets equal the C structs
+of include/rthip.h, so arrays of them can be handed to the C ABI as plain
+pointers.  Nothing here computes anything: the library is the product, and
+`load()` raises when it is missing instead of falling back to anything else.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "librthip.so")
+
+# rthip_material (RT_Material, src/raytracer/raytracer_core.h:74-84)
+MATERIAL = np.dtype(
+    [("type", "<u4"), ("albedo", "<f4", 3), ("emissive", "<f4", 3), ("roughness", "<f4"), ("ior", "<f4"),
+     ("billboard", "<u4")],
+    align=False,
+)
+# rthip_instance (RT_Instance, src/raytracer/raytracer_core.h:17-45)
+INSTANCE = np.dtype(
+    [("type", "<u4"), ("material", "<i4"), ("blas_id", "<u4"), ("sphere_center", "<f4", 3), ("sphere_radius", "<f4"),
+     ("translation", "<f4", 3), ("rotation", "<f4", 4), ("scale", "<f4", 3)],
+    align=False,
+)
+# rthip_cast_settings (RT_CastSettings, src/raytracer/raytracer_core.h:163-178)
+CAST = np.dtype(
+    [("eye", "<f4", 3), ("up", "<f4", 3), ("forward", "<f4", 3), ("right", "<f4", 3), ("viewport", "<f4", 3),
+     ("samples", "<u4"), ("ior", "<f4"), ("defocus", "<u4"), ("defocus_disk", "<f4", 2), ("orthographic", "<u4")],
+    align=False,
+)
+# rthip_node
+NODE = np.dtype([("aabb_min", "<f4", 3), ("skip", "<u4"), ("aabb_max", "<f4", 3), ("id", "<u4")], align=False)
+# rthip_shard
+SHARD = np.dtype([("mode", "<u4"), ("rank", "<u4"), ("world", "<u4")], align=False)
+# rthip_stats
+STATS = np.dtype(
+    [("rays", "<u8"), ("nodes_tested", "<u8"), ("tris_tested", "<u8"), ("inst_entered", "<u8"),
+     ("last_cast_ms", "<f4"), ("last_build_ms", "<f4")],
+    align=False,
+)
+assert MATERIAL.itemsize == 40 and INSTANCE.itemsize == 68 and CAST.itemsize == 84
+assert NODE.itemsize == 32 and SHARD.itemsize == 12 and STATS.itemsize == 40
+
+MAT_LAMBERTIAN, MAT_DIELECTRIC, MAT_METAL, MAT_NORMAL, MAT_LIGHT = range(5)
+INST_SPHERE, INST_MESH = 0, 1
+
+# every symbol include/rthip.h declares: (name, restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = [
+    ("rthip_create", C.c_int, [C.POINTER(_P), C.c_int]),
+    ("rthip_destroy", None, [_P]),
+    ("rthip_last_error", C.c_char_p, [_P]),
+    ("rthip_abi_version", C.c_int, []),
+    ("rthip_set_tracer", C.c_int, [_P, C.c_uint32, C.c_int]),
+    ("rthip_blas_begin", C.c_int, [_P, C.c_uint32]),
+    ("rthip_blas_add_mesh", C.c_int,
+     [_P, C.c_uint32, _P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32, _P, C.c_uint32]),
+    ("rthip_blas_commit", C.c_int, [_P]),
+    ("rthip_tlas_build", C.c_int, [_P, _P, C.c_uint32, _P, C.c_uint32]),
+    ("rthip_cast", C.c_int, [_P, _P, C.c_uint64, _P, C.c_int, C.c_int]),
+    ("rthip_cast_device", C.c_int, [_P, _P, C.c_uint64, _P, C.c_int, C.c_int, _P, _P]),
+    ("rthip_lbvh_build", C.c_int, [_P, _P, C.c_uint64, _P, _P, _P, _P, _P]),
+    ("rthip_lbvh_build_device", C.c_int, [_P, _P, C.c_uint64, _P, _P]),
+    ("rthip_mesh_build_device", C.c_int, [_P, _P, _P, _P, C.c_uint32, _P, C.c_uint64, _P, _P]),
+    ("rthip_primary_hits", C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int]),
+    ("rthip_trace_rays", C.c_int, [_P, _P, _P, C.c_uint64, _P, _P, _P, _P, _P]),
+    ("rthip_trace_rays_device", C.c_int, [_P, _P, _P, C.c_uint64, _P, _P]),
+    ("rthip_get_stats", C.c_int, [_P, _P]),
+    ("rthip_set_counting", C.c_int, [_P, C.c_int]),
+    ("rthip_get_tree", C.c_int, [_P, C.c_int, _P, _P]),
+]
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Loads raytracer_amd/librthip.so (built by __graft_entry__.build()); no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback."
+            )
+        lib = C.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def ptr(a) -> int | None:
+    """Address of a numpy array's buffer (None for None)."""
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"], "array must be C-contiguous"
+    return a.ctypes.data

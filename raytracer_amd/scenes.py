@@ -1,0 +1,458 @@
+"""Scene data of the reference's demos and of the benchmark configurations, built
+through the host-side mirror of the reference's scene API (world.py).
+
+All arithmetic that the reference performs in binary32 on the host (quad
+rotations, box centres, camera derivation) is done here in numpy float32 scalars,
+one IEEE operation at a time and in the reference's order, so the instance and
+camera records are bit-identical to the ones the reference's demos build.
+tanf comes from the host libm, as it does for the reference.
+"""
+from __future__ import annotations
+
+import ctypes
+import ctypes.util
+import math
+
+import numpy as np
+
+from . import abi
+from .world import (GEO_N, GEO_P, RT_World, rt_make_world, rt_world_add_instance, rt_world_add_material,
+                    rt_world_add_mesh)
+
+f32 = np.float32
+PI_F32 = f32(3.1415926535897932384626433832795028841971693993751058209749445923078164062)
+EPSILON_F32 = f32(1.1920929e-7)
+
+_libm = ctypes.CDLL(ctypes.util.find_library("m") or "libm.so.6")
+_libm.tanf.restype = ctypes.c_float
+_libm.tanf.argtypes = [ctypes.c_float]
+
+
+def tanf(x) -> np.float32:
+    return f32(_libm.tanf(ctypes.c_float(float(x))))
+
+
+# ---- binary32 vector helpers in the reference's operation order (src/common/common_math.c) ----
+def v3(x, y, z):
+    return (f32(x), f32(y), f32(z))
+
+
+def add3(a, b):
+    return (a[0] + b[0], a[1] + b[1], a[2] + b[2])
+
+
+def sub3(a, b):
+    return (a[0] - b[0], a[1] - b[1], a[2] - b[2])
+
+
+def mul3(a, s):
+    return (a[0] * s, a[1] * s, a[2] * s)
+
+
+def elmul3(a, b):
+    return (a[0] * b[0], a[1] * b[1], a[2] * b[2])
+
+
+def dot3(a, b):
+    return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]
+
+
+def length3(a):
+    return np.sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2])
+
+
+def normalize3(a):
+    l = length3(a)
+    return (a[0] / l, a[1] / l, a[2] / l)
+
+
+def cross3(a, b):  # common_math.c:29
+    return (a[1] * b[2] - a[2] * b[1], -(a[0] * b[2] - a[2] * b[0]), a[0] * b[1] - a[1] * b[0])
+
+
+def min3(a, b):
+    return tuple(x if x < y else y for x, y in zip(a, b))
+
+
+def max3(a, b):
+    return tuple(x if x > y else y for x, y in zip(a, b))
+
+
+def orthogonal3(x):  # common_math.c:37-46
+    a = tuple(abs(c) for c in x)
+    mx = f32(1.0 if (a[0] <= a[1] and a[0] <= a[2]) else 0.0)
+    my = f32(1.0 if (a[1] < a[0] and a[1] <= a[2]) else 0.0)
+    mz = f32(1.0) - mx - my
+    return cross3(x, (mx, my, mz))
+
+
+def make_a_to_b_quat(a, b):  # common_math.c:92-100
+    k = np.sqrt(dot3(a, a) * dot3(b, b))
+    k_cos_theta = dot3(a, b)
+    with np.errstate(all="ignore"):
+        if k_cos_theta / k < f32(-1.0) + EPSILON_F32:
+            o = normalize3(orthogonal3(a))
+            return (o[0], o[1], o[2], f32(0.0))
+    c = cross3(a, b)
+    w = k_cos_theta + k
+    l = np.sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2] + w * w)
+    return (c[0] / l, c[1] / l, c[2] / l, w / l)
+
+
+IDENTITY_QUAT = (f32(0), f32(0), f32(0), f32(1))
+
+
+def degrees_to_rad(v: int) -> np.float32:
+    """DegreesToRad, common_math.h:289: (v * (PI_F32 / 180.f)) with an int v."""
+    return f32(v) * (PI_F32 / f32(180.0))
+
+
+def get_rt_cast_settings(width, height, samples, eye, subject, defocus_angle=0.0, orthographic=False, vfov=0.0):
+    """get_rt_cast_settings, src/demos/demos_inc.c:104-130 -> one abi.CAST record."""
+    eye = v3(*eye)
+    subject = v3(*subject)
+    d = sub3(subject, eye)
+    up = v3(0, 1, 0)
+    forward = normalize3(d)
+    right = cross3(forward, up)
+    aspect = f32(width) / f32(height)
+    vfov = f32(vfov) if f32(vfov) > 0 else degrees_to_rad(45)
+    focus = length3(d)
+    h = tanf(vfov / f32(2.0))
+    plane_h = f32(2) * h * focus
+    defocus_angle = f32(defocus_angle)
+    defocus_radius = focus * tanf(defocus_angle / f32(2.0))
+    c = np.zeros(1, dtype=abi.CAST)
+    c[0]["eye"] = eye
+    c[0]["up"] = up
+    c[0]["forward"] = forward
+    c[0]["right"] = right
+    c[0]["viewport"] = (plane_h * aspect, plane_h, focus)
+    c[0]["samples"] = samples
+    c[0]["ior"] = 1.0
+    c[0]["defocus"] = 1 if defocus_angle > 0 else 0
+    c[0]["defocus_disk"] = (defocus_radius, defocus_radius)
+    c[0]["orthographic"] = 1 if orthographic else 0
+    return c
+
+
+# ---- demo scenes ---------------------------------------------------------------
+
+
+def _set_mesh(m, verts, indices, attrs):
+    m.vertices = np.ascontiguousarray(verts, dtype=np.float32)
+    m.vertices_count = m.vertices.shape[0]
+    if indices is not None:
+        m.indices = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1)
+        m.indices_count = m.indices.size
+    m.attrs = attrs
+
+
+def cornell():
+    """src/demos/cornell/main.c:79-226.  Returns (world, camera(width, height, samples), sky)."""
+    world = rt_make_world()
+    box_v = np.array([[-1, -1, -1, 0], [1, -1, -1, 0], [1, 1, -1, 0], [1, -1, 1, 0], [1, 1, 1, 0], [-1, 1, -1, 0],
+                      [-1, 1, 1, 0], [-1, -1, 1, 0]], dtype=np.float32)
+    box_i = np.array([0, 1, 2, 0, 2, 5, 7, 3, 4, 7, 4, 6, 1, 3, 4, 1, 4, 2, 0, 5, 6, 0, 6, 7, 5, 2, 4, 5, 4, 6, 0, 7,
+                      3, 0, 3, 1], dtype=np.uint32)
+    quad_v = np.array([[-1, 0, -1, 0], [1, 0, -1, 0], [1, 0, 1, 0], [-1, 0, 1, 0]], dtype=np.float32)
+    quad_i = np.array([0, 1, 2, 0, 2, 3], dtype=np.uint32)
+    box = rt_world_add_mesh(world)
+    _set_mesh(box, box_v, box_i, GEO_P)
+    quad = rt_world_add_mesh(world)
+    _set_mesh(quad, quad_v, quad_i, GEO_P)
+
+    def lambertian(albedo):
+        m = rt_world_add_material(world)
+        m.type, m.albedo, m.billboard = abi.MAT_LAMBERTIAN, albedo, True
+        return m
+
+    ext = f32(277.5)
+    white = lambertian(v3(0.73, 0.73, 0.73))
+    red = lambertian(v3(0.65, 0.05, 0.05))
+    green = lambertian(v3(0.12, 0.45, 0.15))
+    light = rt_world_add_material(world)
+    light.type, light.emissive = abi.MAT_LIGHT, v3(16, 16, 16)
+    metal = rt_world_add_material(world)  # created by the demo, used by nothing
+    metal.type, metal.roughness, metal.billboard = abi.MAT_METAL, f32(0.01), True
+
+    def add_quad(mat, c, u, v):  # cornell/main.c:33-48
+        n = cross3(v, u)
+        it = rt_world_add_instance(world)
+        it.type, it.material, it.mesh = abi.INST_MESH, mat, quad
+        it.translation = c
+        it.rotation = make_a_to_b_quat(v3(0, 1, 0), n)
+        it.scale = (length3(u), f32(1), length3(v))
+
+    def add_box(mat, a, b):  # cornell/main.c:50-67
+        mn, mx = min3(a, b), max3(a, b)
+        it = rt_world_add_instance(world)
+        it.type, it.material, it.mesh = abi.INST_MESH, mat, box
+        it.translation = mul3(add3(mn, mx), f32(0.5))
+        it.rotation = IDENTITY_QUAT
+        it.scale = mul3(sub3(mx, mn), f32(0.5))
+
+    z = f32(0)
+    add_quad(white, (z, -ext, z), (ext, z, z), (z, z, ext))  # floor
+    add_quad(white, (z, ext, z), (ext, z, z), (z, z, ext))  # ceiling
+    add_quad(white, (z, z, -ext), (ext, z, z), (z, ext, z))  # back wall
+    add_quad(green, (-ext, z, z), (z, z, ext), (z, ext, z))  # left wall
+    add_quad(red, (ext, z, z), (z, z, ext), (z, ext, z))  # right wall
+    add_quad(light, (z, ext - f32(1), z), (ext / f32(4), z, z), (z, z, ext / f32(4)))  # light
+    flip = v3(-1, 1, -1)
+    e3 = (ext, ext, ext)
+    add_box(white, elmul3(sub3(v3(130, 0, 65), e3), flip), elmul3(sub3(v3(295, 165, 230), e3), flip))
+    add_box(white, elmul3(sub3(v3(265, 0, 295), e3), flip), elmul3(sub3(v3(430, 330, 460), e3), flip))
+
+    def camera(width, height, samples):
+        return get_rt_cast_settings(width, height, samples, (z, z, f32(2.4) * ext), (0, 0, 0), vfov=degrees_to_rad(40))
+
+    return world, camera, False
+
+
+def tri():
+    """src/demos/tri/main.c:4-62 (auto-indexed single triangle, orthographic camera, sky on)."""
+    world = rt_make_world()
+    s = np.sqrt(f32(3.0)) / f32(4.0)
+    verts = np.array([[-0.5, -s, 0, 0], [0.5, -s, 0, 0], [0.0, s, 0, 0]], dtype=np.float32)
+    m = rt_world_add_mesh(world)
+    _set_mesh(m, verts, None, GEO_P)
+    mat = rt_world_add_material(world)
+    mat.type, mat.albedo, mat.billboard = abi.MAT_LAMBERTIAN, v3(0.5, 0.5, 0.5), True
+    it = rt_world_add_instance(world)
+    it.type, it.material, it.mesh = abi.INST_MESH, mat, m
+    it.translation, it.rotation, it.scale = v3(0, 0, 0), IDENTITY_QUAT, v3(1, 1, 1)
+
+    def camera(width, height, samples):
+        return get_rt_cast_settings(width, height, samples, (0, 0, 1), (0, 0, 0), orthographic=True)
+
+    return world, camera, True
+
+
+def spheres(defocus=True):
+    """src/demos/spheres/main.c:40-72 (five spheres, no meshes, defocus camera, sky on)."""
+    world = rt_make_world()
+
+    def add_sphere(center, radius):
+        mat = rt_world_add_material(world)
+        it = rt_world_add_instance(world)
+        it.type, it.material = abi.INST_SPHERE, mat
+        it.sphere_center, it.sphere_radius = v3(*center), f32(radius)
+        return mat
+
+    m = add_sphere((0, 0, 0), 1.0)
+    m.type, m.ior = abi.MAT_DIELECTRIC, f32(1.52)
+    m = add_sphere((0, 0, 0), 0.8)
+    m.type, m.albedo = abi.MAT_LAMBERTIAN, v3(0.8, 0.5, 0.5)
+    m = add_sphere((-1.6, 0, 0), 0.5)
+    m.type, m.roughness = abi.MAT_METAL, f32(0.1)
+    m = add_sphere((1.6, 0, 0), 0.5)
+    m.type, m.roughness = abi.MAT_METAL, f32(0.9)
+    m = add_sphere((0, -101, 0), 100.0)
+    m.type, m.albedo = abi.MAT_LAMBERTIAN, v3(0.5, 0.6, 0.5)
+
+    def camera(width, height, samples):
+        return get_rt_cast_settings(width, height, samples, (0, 0, -2.5), (0, 0, 0),
+                                    defocus_angle=degrees_to_rad(5) if defocus else 0.0)
+
+    return world, camera, True
+
+
+# ---- stand-in for data/bunny.obj (absent from the reference checkout) ----------
+
+
+def _icosphere(subdiv: int):
+    t = (1.0 + math.sqrt(5.0)) / 2.0
+    v = [(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t), (0, -1, -t), (0, 1, -t), (t, 0, -1),
+         (t, 0, 1), (-t, 0, -1), (-t, 0, 1)]
+    f = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6),
+         (7, 1, 8), (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10), (8, 6, 7),
+         (9, 8, 1)]
+    verts = np.array(v, dtype=np.float64)
+    verts /= np.sqrt((verts * verts).sum(axis=1))[:, None]
+    faces = np.array(f, dtype=np.int64)
+    for _ in range(subdiv):
+        a, b, c = faces[:, 0], faces[:, 1], faces[:, 2]
+        edges = np.concatenate([np.stack([a, b], 1), np.stack([b, c], 1), np.stack([c, a], 1)], axis=0)
+        key = np.minimum(edges[:, 0], edges[:, 1]) * (1 << 32) + np.maximum(edges[:, 0], edges[:, 1])
+        uniq, inverse = np.unique(key, return_inverse=True)
+        lo, hi = uniq >> 32, uniq & ((1 << 32) - 1)
+        mid = verts[lo] + verts[hi]
+        mid /= np.sqrt((mid * mid).sum(axis=1))[:, None]
+        base = verts.shape[0]
+        verts = np.concatenate([verts, mid], axis=0)
+        nf = faces.shape[0]
+        ab, bc, ca = base + inverse[:nf], base + inverse[nf:2 * nf], base + inverse[2 * nf:]
+        faces = np.concatenate([np.stack([a, ab, ca], 1), np.stack([b, bc, ab], 1), np.stack([c, ca, bc], 1),
+                                np.stack([ab, bc, ca], 1)], axis=0)
+    return verts, faces
+
+
+def bunny_class_mesh(subdiv: int = 6):
+    """Deterministic 'bunny-class' mesh: an icosphere (subdiv 6 -> 40 962 vertices, 81 920
+    triangles) with a smooth radial displacement, centred at (-0.3, 1.2, 0), radius ~1, with
+    area-weighted vertex normals.  Only +,-,*,/ and sqrt are used, so the float32 result is
+    the same on every machine.  Returns (verts float32 [V, 8] = P,pad,N,pad ; indices uint32)."""
+    p, faces = _icosphere(subdiv)
+    x, y, z = p[:, 0], p[:, 1], p[:, 2]
+    bump = (0.10 * (x * y + y * z * z - x * z) + 0.05 * (4 * x * x * x - 3 * x) * (2 * y * y - 1)
+            + 0.03 * (8 * z * z * z * z - 8 * z * z + 1) * (2 * x * y))
+    p = p * (1.0 + bump)[:, None] + np.array([-0.3, 1.2, 0.0])
+    p32 = p.astype(np.float32)
+    pf = p32.astype(np.float64)
+    e1 = pf[faces[:, 1]] - pf[faces[:, 0]]
+    e2 = pf[faces[:, 2]] - pf[faces[:, 0]]
+    fn = np.stack([e1[:, 1] * e2[:, 2] - e1[:, 2] * e2[:, 1], e1[:, 2] * e2[:, 0] - e1[:, 0] * e2[:, 2],
+                   e1[:, 0] * e2[:, 1] - e1[:, 1] * e2[:, 0]], axis=1)
+    vn = np.zeros_like(pf)
+    for k in range(3):
+        for c in range(3):
+            vn[:, c] += np.bincount(faces[:, k], weights=fn[:, c], minlength=pf.shape[0])
+    vn /= np.sqrt((vn * vn).sum(axis=1))[:, None]
+    verts = np.zeros((p32.shape[0], 8), dtype=np.float32)
+    verts[:, 0:3] = p32
+    verts[:, 4:7] = vn.astype(np.float32)
+    return verts, faces.astype(np.uint32).reshape(-1)
+
+
+def write_obj(path: str, verts: np.ndarray, indices: np.ndarray) -> None:
+    """Writes the `v` / `vn` / `f a//a` flavour that the reference's PN loader reads (src/mesh/mesh.c:162-166)."""
+    with open(path, "w") as f:
+        for r in verts:
+            f.write("v %.9g %.9g %.9g\n" % (r[0], r[1], r[2]))
+        for r in verts:
+            f.write("vn %.9g %.9g %.9g\n" % (r[4], r[5], r[6]))
+        tri = indices.reshape(-1, 3) + 1
+        for a, b, c in tri:
+            f.write("f %d//%d %d//%d %d//%d\n" % (a, a, b, b, c, c))
+
+
+def bunny(verts=None, indices=None):
+    """src/demos/bunny/main.c:39-78 with the stand-in mesh (one PN mesh, one instance, sky on)."""
+    if verts is None:
+        verts, indices = bunny_class_mesh()
+    world = rt_make_world()
+    m = rt_world_add_mesh(world)
+    _set_mesh(m, verts, indices, GEO_P | GEO_N)
+    mat = rt_world_add_material(world)
+    mat.type, mat.albedo, mat.billboard = abi.MAT_LAMBERTIAN, v3(0.73, 0.73, 0.73), True
+    it = rt_world_add_instance(world)
+    it.type, it.material, it.mesh = abi.INST_MESH, mat, m
+    it.translation, it.rotation, it.scale = v3(0, 0, 0), IDENTITY_QUAT, v3(1, 1, 1)
+
+    def camera(width, height, samples):
+        return get_rt_cast_settings(width, height, samples, (-0.3, 1.2, 3.5), (-0.3, 1.2, 0), vfov=degrees_to_rad(45))
+
+    return world, camera, True
+
+
+# ---- counter-based host randomness for the synthetic configurations -------------
+
+
+def _mix64(z: np.ndarray) -> np.ndarray:
+    z = z.astype(np.uint64)
+    with np.errstate(over="ignore"):
+        z ^= z >> np.uint64(30)
+        z *= np.uint64(0xBF58476D1CE4E5B9)
+        z ^= z >> np.uint64(27)
+        z *= np.uint64(0x94D049BB133111EB)
+        z ^= z >> np.uint64(31)
+    return z
+
+
+def hash_unit(seed: int, stream: int, n: int, start: int = 0) -> np.ndarray:
+    """n float64 values in [0,1) from a counter hash (24 random bits each: exact in float32)."""
+    with np.errstate(over="ignore"):
+        idx = np.arange(start, start + n, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+        key = _mix64(np.uint64(seed) * np.uint64(0xD1342543DE82EF95) + np.uint64(stream))
+        bits = _mix64(idx + key) >> np.uint64(40)
+    return bits.astype(np.float64) / float(1 << 24)
+
+
+def instanced_grid(n_side: int = 100, seed: int = 1, verts=None, indices=None):
+    """Configuration 3: the stand-in mesh instanced n_side x n_side times on an XZ grid (spacing
+    2.5), per-instance yaw and uniform scale in [0.5, 1], three materials cycling."""
+    if verts is None:
+        verts, indices = bunny_class_mesh()
+    world = rt_make_world()
+    m = rt_world_add_mesh(world)
+    _set_mesh(m, verts, indices, GEO_P | GEO_N)
+    mats = []
+    for kind in range(3):
+        mat = rt_world_add_material(world)
+        if kind == 0:
+            mat.type, mat.albedo, mat.billboard = abi.MAT_LAMBERTIAN, v3(0.73, 0.73, 0.73), True
+        elif kind == 1:
+            mat.type, mat.albedo, mat.billboard = abi.MAT_LAMBERTIAN, v3(0.65, 0.05, 0.05), True
+        else:
+            mat.type, mat.roughness, mat.billboard = abi.MAT_METAL, f32(0.1), True
+        mats.append(mat)
+    n = n_side * n_side
+    yaw_c = hash_unit(seed, 1, n) * 2.0 - 1.0  # cos-like parameter in [-1,1)
+    scl = 0.5 + 0.5 * hash_unit(seed, 2, n)
+    half = (n_side - 1) * 2.5 / 2.0
+    for k in range(n):
+        gx, gz = k % n_side, k // n_side
+        # yaw quaternion (0, sin(a/2), 0, cos(a/2)) from c = cos(a/2) in [-1,1): s = sqrt(1-c^2)
+        c = f32(yaw_c[k])
+        s = np.sqrt(f32(1.0) - c * c)
+        it = rt_world_add_instance(world)
+        it.type, it.material, it.mesh = abi.INST_MESH, mats[k % 3], m
+        sc = f32(scl[k])
+        it.translation = v3(gx * 2.5 - half + 0.3 * float(sc), -1.2 * float(sc), gz * 2.5 - half)
+        it.rotation = (f32(0), s, f32(0), c)
+        it.scale = (sc, sc, sc)
+
+    def camera(width, height, samples):
+        return get_rt_cast_settings(width, height, samples, (0.0, half * 0.35, half * 1.15), (0, 0, 0),
+                                    vfov=degrees_to_rad(45))
+
+    return world, camera, True
+
+
+def triangle_soup(n_tris: int, seed: int = 1, chunk: int = 1 << 20):
+    """Configuration 4: n_tris small triangles, centroid uniform in [0,1)^3, vertices = centroid
+    + U(-0.001, 0.001)^3, auto-indexed.  Returns float32 [3*n_tris, 4] (P + pad)."""
+    out = np.zeros((3 * n_tris, 4), dtype=np.float32)
+    for start in range(0, n_tris, chunk):
+        n = min(chunk, n_tris - start)
+        cen = np.stack([hash_unit(seed, 10 + a, n, start) for a in range(3)], axis=1)
+        for vtx in range(3):
+            off = np.stack([hash_unit(seed, 20 + 3 * vtx + a, n, start) for a in range(3)], axis=1)
+            out[3 * start + vtx:3 * (start + n):3, 0:3] = (cen + (off * 2.0 - 1.0) * 0.001).astype(np.float32)
+    return out
+
+
+def soup_world(n_tris: int, seed: int = 1):
+    world = rt_make_world()
+    m = rt_world_add_mesh(world)
+    _set_mesh(m, triangle_soup(n_tris, seed), None, GEO_P)
+    mat = rt_world_add_material(world)
+    mat.type, mat.albedo, mat.billboard = abi.MAT_LAMBERTIAN, v3(0.73, 0.73, 0.73), True
+    it = rt_world_add_instance(world)
+    it.type, it.material, it.mesh = abi.INST_MESH, mat, m
+    it.translation, it.rotation, it.scale = v3(0, 0, 0), IDENTITY_QUAT, v3(1, 1, 1)
+
+    def camera(width, height, samples):
+        return get_rt_cast_settings(width, height, samples, (0.5, 0.5, 2.6), (0.5, 0.5, 0.5), vfov=degrees_to_rad(45))
+
+    return world, camera, True
+
+
+def random_rays(n: int, seed: int, lo=(0.0, 0.0, 0.0), hi=(1.0, 1.0, 1.0)):
+    """'Incoherent' rays: origin uniform in the box [lo,hi], direction uniform on the sphere
+    (rejection-free: z uniform, azimuth by a rational parametrisation), float32, unit length."""
+    lo = np.asarray(lo, dtype=np.float64)
+    hi = np.asarray(hi, dtype=np.float64)
+    o = np.stack([hash_unit(seed, 40 + a, n) for a in range(3)], axis=1) * (hi - lo) + lo
+    zc = hash_unit(seed, 50, n) * 2.0 - 1.0
+    # azimuth: point on the unit circle from t in [-1,1) via (1-t^2, 2t)/(1+t^2), quadrant by two sign bits
+    t = hash_unit(seed, 51, n) * 2.0 - 1.0
+    cx, cy = (1 - t * t) / (1 + t * t), (2 * t) / (1 + t * t)
+    flip = hash_unit(seed, 52, n) < 0.5
+    cx = np.where(flip, -cx, cx)
+    r = np.sqrt(np.maximum(0.0, 1.0 - zc * zc))
+    d = np.stack([r * cx, r * cy, zc], axis=1).astype(np.float32)
+    d64 = d.astype(np.float64)
+    d = (d64 / np.sqrt((d64 * d64).sum(axis=1))[:, None]).astype(np.float32)
+    return o.astype(np.float32), d

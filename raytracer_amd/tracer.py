@@ -1,0 +1,180 @@
+"""The five tracer hooks of the reference (src/raytracer/raytracer_core.h:180-184)
+on top of the C ABI of librthip.so, plus thin wrappers of the parity taps.
+
+Everything is computed by the HIP library; a missing library or a failing call
+raises RTHipError -- there is no CPU path behind these functions.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import abi
+from .world import RT_World, flatten_meshes, flatten_world
+
+
+class RTHipError(RuntimeError):
+    pass
+
+
+@dataclass
+class RT_TracerSettings:  # raytracer_core.h:155-159
+    max_bounces: int = 8
+    sky: bool = True
+
+
+class RT_Tracer:
+    """Owner of one rthip_ctx (one GPU)."""
+
+    def __init__(self, device_id: int = 0):
+        self.lib = abi.load()
+        h = C.c_void_p()
+        rc = self.lib.rthip_create(C.byref(h), device_id)
+        if rc != 0 or not h.value:
+            raise RTHipError(f"rthip_create failed with code {rc} (no usable gfx950 device {device_id}?)")
+        self.h = h
+
+    def check(self, rc: int, what: str):
+        if rc != 0:
+            msg = self.lib.rthip_last_error(self.h)
+            raise RTHipError(f"{what}: code {rc}: {msg.decode() if msg else ''}")
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h.value:
+            self.lib.rthip_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def rt_make_tracer(settings: RT_TracerSettings, device_id: int = 0) -> RT_Tracer:
+    """rt_make_tracer, src/raytracer/cpu/raytracer_cpu.c:14-25."""
+    assert settings.max_bounces < 64  # RT_MAX_MAX_BOUNCES, raytracer_core.h:161
+    t = RT_Tracer(device_id)
+    t.check(t.lib.rthip_set_tracer(t.h, int(settings.max_bounces), 1 if settings.sky else 0), "rthip_set_tracer")
+    return t
+
+
+def rt_tracer_build_blas(tracer: RT_Tracer, world: RT_World) -> None:
+    """rt_tracer_build_blas, raytracer_cpu.c:26-31."""
+    meshes = flatten_meshes(world)
+    upload_meshes(tracer, meshes)
+
+
+def upload_meshes(tracer: RT_Tracer, meshes: list) -> None:
+    lib = tracer.lib
+    tracer.check(lib.rthip_blas_begin(tracer.h, len(meshes)), "rthip_blas_begin")
+    for blas_id, m in enumerate(meshes):
+        idx = m["indices"]
+        tracer.check(
+            lib.rthip_blas_add_mesh(
+                tracer.h, blas_id, abi.ptr(m["verts"]), m["vertex_count"], m["stride"], m["pos_off"], m["nrm_off"],
+                abi.ptr(idx) if idx is not None else None, 0 if idx is None else idx.size,
+            ),
+            "rthip_blas_add_mesh",
+        )
+    tracer.check(lib.rthip_blas_commit(tracer.h), "rthip_blas_commit")
+
+
+def rt_tracer_build_tlas(tracer: RT_Tracer, world: RT_World) -> None:
+    """rt_tracer_build_tlas, raytracer_cpu.c:32-37."""
+    flat = flatten_world(world)
+    build_tlas_flat(tracer, flat.instances, flat.materials)
+
+
+def build_tlas_flat(tracer: RT_Tracer, instances: np.ndarray, materials: np.ndarray) -> None:
+    instances = np.ascontiguousarray(instances, dtype=abi.INSTANCE)
+    materials = np.ascontiguousarray(materials, dtype=abi.MATERIAL)
+    tracer.check(
+        tracer.lib.rthip_tlas_build(tracer.h, abi.ptr(instances), instances.size, abi.ptr(materials), materials.size),
+        "rthip_tlas_build",
+    )
+
+
+def rt_tracer_cast(tracer: RT_Tracer, settings: np.ndarray, out_radiance: np.ndarray, width: int, height: int,
+                   seed: int = 0) -> None:
+    """rt_tracer_cast, raytracer_cpu.c:45-49.  out_radiance: float32 [height, width, 3]."""
+    cast = np.ascontiguousarray(settings, dtype=abi.CAST).reshape(1)
+    assert out_radiance.dtype == np.float32 and out_radiance.size == width * height * 3
+    tracer.check(
+        tracer.lib.rthip_cast(tracer.h, abi.ptr(cast), int(seed) & (2**64 - 1), abi.ptr(out_radiance), width, height),
+        "rthip_cast",
+    )
+
+
+def rt_tracer_cleanup(tracer: RT_Tracer) -> None:
+    """rt_tracer_cleanup, raytracer_cpu.c:38-43."""
+    tracer.close()
+
+
+# ---- parity / measurement taps ---------------------------------------------
+
+
+def lbvh_build(tracer: RT_Tracer, aabbs: np.ndarray):
+    """lbvh_make (src/lbvh/lbvh.c:92-125) on the GPU.  Returns (codes, codes_sorted, ids_sorted, nodes, ms)."""
+    aabbs = np.ascontiguousarray(aabbs, dtype=np.float32).reshape(-1, 6)
+    n = aabbs.shape[0]
+    codes = np.zeros(n, dtype=np.uint64)
+    codes_sorted = np.zeros(n, dtype=np.uint64)
+    ids_sorted = np.zeros(n, dtype=np.uint32)
+    nodes = np.zeros(max(2 * n - 1, 0), dtype=abi.NODE)
+    ms = C.c_float(0)
+    tracer.check(
+        tracer.lib.rthip_lbvh_build(tracer.h, abi.ptr(aabbs), n, abi.ptr(codes), abi.ptr(codes_sorted),
+                                    abi.ptr(ids_sorted), abi.ptr(nodes), C.addressof(ms)),
+        "rthip_lbvh_build",
+    )
+    return codes, codes_sorted, ids_sorted, nodes, ms.value
+
+
+def primary_hits(tracer: RT_Tracer, settings: np.ndarray, width: int, height: int):
+    cast = np.ascontiguousarray(settings, dtype=abi.CAST).reshape(1)
+    inst = np.zeros(width * height, dtype=np.uint32)
+    tri = np.zeros(width * height, dtype=np.uint32)
+    t = np.zeros(width * height, dtype=np.float32)
+    tracer.check(
+        tracer.lib.rthip_primary_hits(tracer.h, abi.ptr(cast), abi.ptr(inst), abi.ptr(tri), abi.ptr(t), width, height),
+        "rthip_primary_hits",
+    )
+    return inst, tri, t
+
+
+def trace_rays(tracer: RT_Tracer, origins: np.ndarray, directions: np.ndarray, want_uv=True, want_normal=True):
+    o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
+    d = np.ascontiguousarray(directions, dtype=np.float32).reshape(-1, 3)
+    n = o.shape[0]
+    inst = np.zeros(n, dtype=np.uint32)
+    tri = np.zeros(n, dtype=np.uint32)
+    t = np.zeros(n, dtype=np.float32)
+    uv = np.zeros((n, 2), dtype=np.float32) if want_uv else None
+    nrm = np.zeros((n, 3), dtype=np.float32) if want_normal else None
+    tracer.check(
+        tracer.lib.rthip_trace_rays(tracer.h, abi.ptr(o), abi.ptr(d), n, abi.ptr(inst), abi.ptr(tri), abi.ptr(t),
+                                    abi.ptr(uv), abi.ptr(nrm)),
+        "rthip_trace_rays",
+    )
+    return inst, tri, t, uv, nrm
+
+
+def get_tree(tracer: RT_Tracer, which: int) -> np.ndarray:
+    cnt = C.c_uint64(0)
+    tracer.check(tracer.lib.rthip_get_tree(tracer.h, which, None, C.addressof(cnt)), "rthip_get_tree")
+    nodes = np.zeros(cnt.value, dtype=abi.NODE)
+    tracer.check(tracer.lib.rthip_get_tree(tracer.h, which, abi.ptr(nodes), C.addressof(cnt)), "rthip_get_tree")
+    return nodes
+
+
+def get_stats(tracer: RT_Tracer) -> dict:
+    st = np.zeros(1, dtype=abi.STATS)
+    tracer.check(tracer.lib.rthip_get_stats(tracer.h, abi.ptr(st)), "rthip_get_stats")
+    return {k: st[0][k].item() for k in abi.STATS.names}
+
+
+def set_counting(tracer: RT_Tracer, enabled: bool) -> None:
+    tracer.check(tracer.lib.rthip_set_counting(tracer.h, 1 if enabled else 0), "rthip_set_counting")
