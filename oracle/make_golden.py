@@ -1,0 +1,156 @@
+"""TEST INFRASTRUCTURE -- writes tests/golden/*.npz from the UNMODIFIED reference.
+
+Run once in a container that holds /root/reference (after `make -C oracle ref`):
+    python oracle/make_golden.py
+Every array named `ref_*` in the output is produced by the reference's own code
+(oracle/_ref/libref_*.so); the inputs next to them are synthetic and seeded.  The .npz
+files are data only (loaded with allow_pickle=False).
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path = [p for p in sys.path if os.path.abspath(p or ".") != os.path.dirname(os.path.abspath(__file__))]
+sys.path.insert(0, ROOT)
+
+from oracle import oracle as O  # noqa: E402
+from raytracer_amd import scenes, world  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def sha(a: np.ndarray) -> str:
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def boxes_from(cen, half):
+    cen = np.asarray(cen, dtype=np.float32)
+    half = np.asarray(half, dtype=np.float32)
+    return np.concatenate([cen - half, cen + half], axis=1).astype(np.float32)
+
+
+def aabb_sets():
+    rng = np.random.default_rng(1)
+    sets = {}
+    sets["uniform_1000"] = boxes_from(rng.random((1000, 3)), rng.random((1000, 3)) * 0.01)
+    centres = rng.random((16, 3))
+    pts = centres[rng.integers(0, 16, 2048)] + rng.normal(0, 0.01, (2048, 3))
+    sets["clustered_2048"] = boxes_from(pts, rng.random((2048, 3)) * 0.002)
+    grid = rng.integers(0, 4, (1000, 3)).astype(np.float32)  # many equal centroids
+    sets["duplicates_1000"] = boxes_from(grid, rng.random((1000, 3)) * 0.25)
+    few = rng.integers(0, 3, (24, 3)).astype(np.float32)  # duplicates in a set small enough to be sorted stably
+    sets["duplicates_24"] = boxes_from(few, rng.random((24, 3)) * 0.25)
+    planar = rng.random((300, 3))
+    planar[:, 1] = 0.5
+    sets["planar_300"] = boxes_from(planar, np.stack([rng.random(300) * 0.01, np.zeros(300), rng.random(300) * 0.01], 1))
+    sets["single"] = boxes_from([[0.25, 0.5, 0.75]], [[0.1, 0.2, 0.3]])
+    sets["pair"] = boxes_from([[0.0, 0.0, 0.0], [1.0, 2.0, 3.0]], [[0.5, 0.5, 0.5], [0.25, 0.25, 0.25]])
+    sets["identical_40"] = boxes_from(np.tile([[0.3, 0.3, 0.3]], (40, 1)), np.tile([[0.1, 0.1, 0.1]], (40, 1)))
+    # triangle boxes / instance boxes of the reference's own demo scenes
+    for name, builder in (("cornell", scenes.cornell), ("tri", scenes.tri), ("spheres", scenes.spheres)):
+        w, _, sky = builder()
+        flat = world.flatten_world(w)
+        for k, m in enumerate(flat.meshes):
+            sets[f"{name}_blas{k}"] = O.tri_aabbs(m)
+        sc = O.Scene(flat, 8, sky)
+        tl = sc.tree(-1)
+        leaves = tl[tl["id"] > 0]
+        order = np.argsort(leaves["id"])
+        sets[f"{name}_tlas"] = np.concatenate([leaves["aabb_min"][order], leaves["aabb_max"][order]], axis=1)
+    return sets
+
+
+def write_lbvh():
+    for name, boxes in aabb_sets().items():
+        codes, ids, dump, _ = O.ref_lbvh_build(boxes)
+        np.savez_compressed(os.path.join(OUT, f"lbvh_{name}.npz"), aabbs=boxes, ref_codes=codes,
+                            ref_ids_tree_order=ids.astype(np.uint32), ref_dump=np.frombuffer(dump, dtype=np.uint8))
+        print("lbvh", name, boxes.shape[0], len(dump))
+    # big sets: digests only
+    rng = np.random.default_rng(7)
+    digests = {}
+    for n in (100_000, 1_000_000):
+        boxes = boxes_from(rng.random((n, 3)), rng.random((n, 3)) * 0.001)
+        codes, ids, dump, sec = O.ref_lbvh_build(boxes)
+        digests[f"n{n}_aabbs"] = sha(boxes)
+        digests[f"n{n}_codes"] = sha(codes)
+        digests[f"n{n}_ids"] = sha(ids.astype(np.uint32))
+        digests[f"n{n}_dump"] = hashlib.sha256(dump).hexdigest()
+        digests[f"n{n}_unique_codes"] = str(np.unique(codes).size)
+        print("lbvh big", n, "ref seconds", sec)
+    np.savez_compressed(os.path.join(OUT, "lbvh_big_digests.npz"), **{k: np.array(v) for k, v in digests.items()})
+
+
+def write_demos():
+    for name, builder, defocus_off in (("cornell", scenes.cornell, False), ("tri", scenes.tri, False),
+                                       ("spheres", scenes.spheres, True)):
+        W = H = 64
+        w, cam, sky = builder()
+        cast = cam(W, H, 1)
+        run = O.ref_demo(name, W, H, 1, 8, 1)
+        assert run["cast"].tobytes() == cast.tobytes(), name
+        ray_cast = cast.copy()
+        if defocus_off:
+            ray_cast[0]["defocus"] = 0
+        o, d = O.primary_rays(ray_cast, W, H)
+        hits = O.ref_demo(name, W, H, 1, 8, 1, rays=(o, d))["hits"]
+        out = dict(ref_cast=run["cast"], ref_tlas_dump=np.frombuffer(run["tlas_dump"], dtype=np.uint8),
+                   rays_o=o, rays_d=d, ref_inst=hits[0], ref_tri=hits[1], ref_t=hits[2], ref_rgb_s1_seed1=run["rgb"])
+        run2 = O.ref_demo(name, 32, 32, 2, 8, 3)
+        out["ref_rgb_32_s2_seed3"] = run2["rgb"]
+        if name == "cornell":
+            for seed in (1, 2):
+                out[f"ref_rgb_64_s8_seed{seed}"] = O.ref_demo(name, 64, 64, 8, 8, seed)["rgb"]
+            cast512 = cam(512, 512, 1)
+            o5, d5 = O.primary_rays(cast512, 512, 512)
+            h5 = O.ref_demo(name, 512, 512, 1, 1, 1, rays=(o5, d5))["hits"]
+            out["ref_512_inst_sha"] = np.array(sha(h5[0]))
+            out["ref_512_tri_sha"] = np.array(sha(h5[1]))
+            out["ref_512_t_sha"] = np.array(sha(h5[2]))
+            out["ref_512_hits"] = np.array(int((h5[0] > 0).sum()))
+        # the reference's own ray dump (debug build) pins the camera rays bit for bit
+        if O.have_ref(name + "_debug"):
+            dbg = O.ref_demo(name + "_debug", 16, 16, 1, 1, 1)
+            rec = np.frombuffer(dbg["ray_records"], dtype=np.dtype([("o", "<f4", 3), ("d", "<f4", 3), ("p", "<f4", 3),
+                                                                    ("n", "<f4", 3), ("t", "<f4"), ("m", "<u8")]))
+            out["ref_debug_rays_16_o"] = rec["o"].copy()
+            out["ref_debug_rays_16_d"] = rec["d"].copy()
+        np.savez_compressed(os.path.join(OUT, f"demo_{name}.npz"), **out)
+        print("demo", name, int((hits[0] > 0).sum()), "hits")
+
+
+def write_bunny():
+    verts, indices = scenes.bunny_class_mesh()
+    w, cam, sky = scenes.bunny(verts, indices)
+    flat = world.flatten_world(w)
+    rs = O.RefScene(flat, 2, sky)
+    out = dict(mesh_verts_sha=np.array(sha(verts)), mesh_indices_sha=np.array(sha(indices)))
+    out["ref_blas_dump_sha"] = np.array(hashlib.sha256(rs.tree_dump(0)).hexdigest())
+    W, H = 160, 90
+    cast = cam(W, H, 1)
+    o, d = O.primary_rays(cast, W, H)
+    inst, tri, t, uv, nrm, _ = rs.trace(o, d)
+    out.update(cast_160x90=cast, ref_inst=inst, ref_tri=tri, ref_t=t, ref_uv=uv, ref_normal=nrm)
+    W, H = 1920, 1080
+    cast = cam(W, H, 1)
+    o, d = O.primary_rays(cast, W, H)
+    inst, tri, t, uv, nrm, sec = rs.trace(o, d, want_normal=False)
+    out.update(ref_1080_inst_sha=np.array(sha(inst)), ref_1080_tri_sha=np.array(sha(tri)), ref_1080_t_sha=np.array(sha(t)),
+               ref_1080_hits=np.array(int((inst > 0).sum())), ref_1080_trace_seconds=np.array(sec))
+    img, sec = rs.cast(cam(96, 54, 2), 5, 96, 54)
+    out["ref_rgb_96x54_s2_b2_seed5"] = img
+    np.savez_compressed(os.path.join(OUT, "demo_bunny_class.npz"), **out)
+    print("bunny-class", int(out["ref_1080_hits"]), "hits at 1080p; ref trace seconds", float(out["ref_1080_trace_seconds"]))
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    assert O.have_ref("core"), "build oracle/_ref first: make -C oracle ref"
+    write_lbvh()
+    write_demos()
+    write_bunny()

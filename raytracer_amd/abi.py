@@ -87,6 +87,13 @@ def load() -> C.CDLL:
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  There is no CPU fallback."
             )
+        # One process must hold ONE HIP runtime.  PyTorch ships its own copy (same soname as the
+        # system one); when torch is installed it is loaded first, so that librthip.so binds to the
+        # runtime torch uses and device pointers / streams can be shared between the two.
+        try:
+            import torch  # noqa: F401
+        except Exception:  # torch is plumbing for the Python harnesses only
+            pass
         lib = C.CDLL(LIB_PATH)
         for name, res, args in SYMBOLS:
             fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol

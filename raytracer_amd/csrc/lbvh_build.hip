@@ -1,0 +1,723 @@
+// LBVH construction on gfx950: Morton codes, LDS-staged wave64 radix sort, bottom-up
+// hierarchy emission with in-flight box refit, pre-order layout.
+//
+// The tree produced here is, node for node, the tree that the reference's top-down
+// builder produces (src/lbvh/lbvh.c:15-125): a radix tree over the distinct Morton
+// codes in which every run of equal codes is a subtree split at count/2
+// (lbvh_get_split_idx, lbvh.c:22-24).  How that is reached without recursion:
+//
+//   * every inner node of a binary tree over a sorted leaf sequence owns exactly one
+//     "gap" g (between sorted leaves g and g+1): the place where it splits its range;
+//   * give every gap a priority: the number of leading bits its two codes share when
+//     they differ (lbvh.c:25), or 64 + (depth inside the midpoint-split tree of its
+//     run) when they are equal.  The reference tree is the Cartesian tree of those
+//     priorities: a node covers the widest range around its gap in which every other
+//     gap has a larger priority;
+//   * so each subtree can find its parent locally: of the two gaps that bound its leaf
+//     range, the one with the larger priority (bottom-up walk, one thread per leaf, the
+//     second child to arrive at a node carries on);
+//   * pre-order index of leaf i = i + (number of inner nodes whose range starts at or
+//     before i) and the inner nodes on a left spine sit directly in front of its leaf,
+//     so one prefix sum places every node; skip = index + subtree size.
+//
+// Floating point: compiled with -ffp-contract=off; min/max are the reference's
+// ternaries (common_core.h:113-114) so that ties and signed zeros resolve the same way.
+
+#include "rthip_internal.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kSortItems = 16;                  // keys per thread in the radix kernels
+constexpr int kSortTile = kBlock * kSortItems;  // 4096 keys per workgroup
+constexpr int kScanItems = 8;
+constexpr int kScanTile = kBlock * kScanItems;  // 2048 values per workgroup
+
+struct alignas(16) ChildRec {  // == ChildInfo: what a child leaves at its parent
+    float box[6];
+    uint32_t far_end;  // the end of the child's leaf range that is not the parent's gap
+    uint32_t dl;       // number of left-edges from the child down to its leftmost leaf
+};
+static_assert(sizeof(ChildRec) == 32, "ChildRec must be 32 bytes");
+
+__device__ __forceinline__ float ref_min(float a, float b) { return (a < b) ? a : b; }  // Min(A,B)
+__device__ __forceinline__ float ref_max(float a, float b) { return (a > b) ? a : b; }  // Max(A,B)
+
+// order-preserving map float -> uint32 for atomicMin / atomicMax
+__device__ __forceinline__ uint32_t f2ord(float f) {
+    uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(uint32_t u) {
+    uint32_t b = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    return __uint_as_float(b);
+}
+
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// ---- K1: triangle boxes + per-triangle vertex records ----------------------------
+// rt_cpu_aabb_from_tri and its loops, src/raytracer/cpu/raytracer_cpu.c:54-87.
+__global__ __launch_bounds__(kBlock) void tri_prepare_kernel(const float* __restrict__ px, const float* __restrict__ py,
+                                                             const float* __restrict__ pz, const float* __restrict__ nx,
+                                                             const float* __restrict__ ny, const float* __restrict__ nz,
+                                                             const uint32_t* __restrict__ indices, uint64_t n_tris,
+                                                             float* __restrict__ aabb6, float4* __restrict__ tri_v,
+                                                             float4* __restrict__ tri_n) {
+    uint64_t t = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= n_tris) return;
+    uint32_t i0, i1, i2;
+    if (indices) {
+        i0 = indices[3 * t];
+        i1 = indices[3 * t + 1];
+        i2 = indices[3 * t + 2];
+    } else {
+        i0 = (uint32_t)(3 * t);
+        i1 = i0 + 1;
+        i2 = i0 + 2;
+    }
+    float ax = px[i0], ay = py[i0], az = pz[i0];
+    float bx = px[i1], by = py[i1], bz = pz[i1];
+    float cx = px[i2], cy = py[i2], cz = pz[i2];
+    float* o = aabb6 + 6 * t;
+    o[0] = ref_min(ref_min(ax, bx), cx);
+    o[1] = ref_min(ref_min(ay, by), cy);
+    o[2] = ref_min(ref_min(az, bz), cz);
+    o[3] = ref_max(ref_max(ax, bx), cx);
+    o[4] = ref_max(ref_max(ay, by), cy);
+    o[5] = ref_max(ref_max(az, bz), cz);
+    if (tri_v) {
+        tri_v[3 * t + 0] = make_float4(ax, ay, az, 0.f);
+        tri_v[3 * t + 1] = make_float4(bx, by, bz, 0.f);
+        tri_v[3 * t + 2] = make_float4(cx, cy, cz, 0.f);
+    }
+    if (tri_n && nx) {
+        tri_n[3 * t + 0] = make_float4(nx[i0], ny[i0], nz[i0], 0.f);
+        tri_n[3 * t + 1] = make_float4(nx[i1], ny[i1], nz[i1], 0.f);
+        tri_n[3 * t + 2] = make_float4(nx[i2], ny[i2], nz[i2], 0.f);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void deinterleave_kernel(const uint8_t* __restrict__ src, uint32_t count,
+                                                              uint32_t stride, uint32_t off, float* __restrict__ x,
+                                                              float* __restrict__ y, float* __restrict__ z) {
+    uint32_t v = blockIdx.x * kBlock + threadIdx.x;
+    if (v >= count) return;
+    const float* p = (const float*)(src + (size_t)v * stride + off);
+    x[v] = p[0];
+    y[v] = p[1];
+    z[v] = p[2];
+}
+
+// ---- centroid bounds: first loop of lbvh_make, src/lbvh/lbvh.c:95-105 (release build) ----
+__global__ void bounds_init_kernel(uint32_t* bounds) {
+    int i = threadIdx.x;
+    if (i < 3) bounds[i] = f2ord(3.402823466e+38f);
+    else if (i < 6) bounds[i] = f2ord(-3.402823466e+38f);
+}
+
+__global__ __launch_bounds__(kBlock) void bounds_kernel(const float* __restrict__ aabb6, uint64_t n,
+                                                        uint32_t* __restrict__ bounds) {
+    __shared__ float red[6][kBlock / 64];
+    float mn[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f};
+    float mx[3] = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
+        const float* b = aabb6 + 6 * i;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            float c = (b[k] + b[k + 3]) * 0.5f;  // mul_3f32(add_3f32(min, max), 0.5f), lbvh.c:98
+            mn[k] = ref_min(mn[k], c);
+            mx[k] = ref_max(mx[k], c);
+        }
+    }
+    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        float a = wave_min(mn[k]), b = wave_max(mx[k]);
+        if (lane == 0) {
+            red[k][wave] = a;
+            red[k + 3][wave] = b;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        int k = threadIdx.x;
+        float v = red[k][0];
+        for (int w = 1; w < kBlock / 64; w++) v = (k < 3) ? fminf(v, red[k][w]) : fmaxf(v, red[k][w]);
+        if (k < 3) atomicMin(&bounds[k], f2ord(v));
+        else atomicMax(&bounds[k], f2ord(v));
+    }
+}
+
+// ---- K2: lbvh_c_to_morton_code, lbvh.c:74-90 ----------------------------------------
+__device__ __forceinline__ uint64_t spread21(uint32_t v) {  // bit i of v -> bit 3i
+    uint64_t x = v & 0x1fffffu;
+    x = (x | x << 32) & 0x1f00000000ffffull;
+    x = (x | x << 16) & 0x1f0000ff0000ffull;
+    x = (x | x << 8) & 0x100f00f00f00f00full;
+    x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+    x = (x | x << 2) & 0x1249249249249249ull;
+    return x;
+}
+// norm is binary32 (subtraction then IEEE division); the reference widens it to double
+// and scales by 2^21, which is exact, so the same integer comes out of a binary32
+// scale.  0/0 on a zero-extent axis is NaN, which the reference's x86-64 cast turns
+// into 0.  Only bits 0..20 are used, so norm == 1.0 contributes 0 (no clamp).
+__device__ __forceinline__ uint32_t morton_axis(float c, float mn, float ext) {
+    float norm = (c - mn) / ext;
+    float scaled = norm * 2097152.0f;
+    if (!(scaled == scaled)) return 0u;
+    if (!(scaled < 4294967296.0f) || scaled < 0.f) return 0u;
+    return (uint32_t)scaled;
+}
+
+__global__ __launch_bounds__(kBlock) void morton_kernel(const float* __restrict__ aabb6, uint64_t n,
+                                                        const uint32_t* __restrict__ bounds,
+                                                        uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    float mn[3], ext[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        mn[k] = ord2f(bounds[k]);
+        ext[k] = ord2f(bounds[k + 3]) - mn[k];  // extents = max - min, lbvh.c:106
+    }
+    const float* b = aabb6 + 6 * i;
+    uint64_t code = 0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        float c = (b[k] + b[k + 3]) * 0.5f;  // lbvh.c:114
+        code |= spread21(morton_axis(c, mn[k], ext[k])) << k;
+    }
+    keys[i] = code;
+    vals[i] = (uint32_t)i;
+}
+
+// ---- K3: LSD radix sort, 8 bits per pass, stable ---------------------------------------
+// Replaces radsort(...) at lbvh.c:120.  Equal codes keep ascending primitive index.
+
+__global__ __launch_bounds__(kBlock) void radix_hist_kernel(const uint64_t* __restrict__ keys, uint64_t n, int shift,
+                                                            uint32_t* __restrict__ block_hist, uint32_t tiles) {
+    __shared__ uint32_t hist[256];
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    uint64_t base = (uint64_t)blockIdx.x * kSortTile;
+#pragma unroll
+    for (int j = 0; j < kSortItems; j++) {
+        uint64_t i = base + (uint64_t)j * kBlock + threadIdx.x;
+        if (i < n) atomicAdd(&hist[(uint32_t)(keys[i] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    block_hist[(uint64_t)threadIdx.x * tiles + blockIdx.x] = hist[threadIdx.x];
+}
+
+// Each workgroup ranks its 4096 keys by the current digit (wave-level match-any on
+// ballots, wave-private LDS counters), sorts the tile in LDS and writes every digit
+// bucket to its place in the output with consecutive lanes on consecutive addresses.
+__global__ __launch_bounds__(kBlock) void radix_scatter_kernel(const uint64_t* __restrict__ keys_in,
+                                                               const uint32_t* __restrict__ vals_in,
+                                                               uint64_t* __restrict__ keys_out,
+                                                               uint32_t* __restrict__ vals_out, uint64_t n, int shift,
+                                                               const uint32_t* __restrict__ gbase, uint32_t tiles) {
+    __shared__ uint32_t wave_cnt[kBlock / 64][256];
+    __shared__ uint32_t bin_start[256];
+    __shared__ uint32_t out_base[256];
+    __shared__ uint32_t wave_tot[kBlock / 64];
+    __shared__ uint64_t skeys[kSortTile];
+    __shared__ uint32_t svals[kSortTile];
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const uint64_t base = (uint64_t)blockIdx.x * kSortTile;
+    const uint64_t wbase = base + (uint64_t)wave * (64 * kSortItems);
+
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; w++) wave_cnt[w][tid] = 0;
+
+    uint64_t key[kSortItems];
+#pragma unroll
+    for (int j = 0; j < kSortItems; j++) {
+        uint64_t i = wbase + (uint64_t)j * 64 + lane;
+        key[j] = (i < n) ? keys_in[i] : ~0ull;
+    }
+    __syncthreads();
+
+    uint32_t rank[kSortItems];
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int j = 0; j < kSortItems; j++) {
+        uint32_t d = (uint32_t)(key[j] >> shift) & 255u;
+        uint64_t same = ~0ull;
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            bool bit = (d >> b) & 1u;
+            uint64_t bal = __ballot(bit);
+            same &= bit ? bal : ~bal;
+        }
+        uint32_t below = __popcll(same & lt_mask);
+        uint32_t old = 0;
+        if (below == 0) {  // lowest lane of each digit group updates the wave's counter
+            old = wave_cnt[wave][d];
+            wave_cnt[wave][d] = old + __popcll(same);
+        }
+        old = __shfl(old, __ffsll((long long)same) - 1);
+        rank[j] = old + below;
+    }
+    __syncthreads();
+
+    {   // thread d: offsets of each wave inside digit d, digit totals, exclusive scan of the totals
+        uint32_t run = 0;
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; w++) {
+            uint32_t c = wave_cnt[w][tid];
+            wave_cnt[w][tid] = run;
+            run += c;
+        }
+        uint32_t incl = run;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            uint32_t up = __shfl_up(incl, o);
+            if (lane >= o) incl += up;
+        }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        uint32_t wsum = 0;
+        for (int w = 0; w < wave; w++) wsum += wave_tot[w];
+        uint32_t start = wsum + incl - run;
+        bin_start[tid] = start;
+        out_base[tid] = gbase[(uint64_t)tid * tiles + blockIdx.x] - start;
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int j = 0; j < kSortItems; j++) {
+        uint32_t d = (uint32_t)(key[j] >> shift) & 255u;
+        uint32_t pos = bin_start[d] + wave_cnt[wave][d] + rank[j];
+        uint64_t i = wbase + (uint64_t)j * 64 + lane;
+        skeys[pos] = key[j];
+        svals[pos] = (i < n) ? vals_in[i] : 0u;
+    }
+    __syncthreads();
+
+    uint64_t left = n - base;
+    uint32_t valid = left < (uint64_t)kSortTile ? (uint32_t)left : (uint32_t)kSortTile;
+#pragma unroll
+    for (int j = 0; j < kSortItems; j++) {
+        uint32_t p = (uint32_t)j * kBlock + tid;
+        if (p < valid) {
+            uint64_t k = skeys[p];
+            uint32_t d = (uint32_t)(k >> shift) & 255u;
+            uint32_t dst = out_base[d] + p;
+            keys_out[dst] = k;
+            vals_out[dst] = svals[p];
+        }
+    }
+}
+
+// ---- device-wide prefix sums of uint32 ------------------------------------------------
+template <bool INCLUSIVE>
+__global__ __launch_bounds__(kBlock) void scan_tile_kernel(uint32_t* __restrict__ data, uint64_t n,
+                                                           uint32_t* __restrict__ sums) {
+    __shared__ uint32_t wave_tot[kBlock / 64];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    uint64_t base = (uint64_t)blockIdx.x * kScanTile + (uint64_t)tid * kScanItems;
+    uint32_t v[kScanItems];
+    uint32_t run = 0;
+#pragma unroll
+    for (int j = 0; j < kScanItems; j++) {
+        v[j] = (base + j < n) ? data[base + j] : 0u;
+        run += v[j];
+    }
+    uint32_t incl = run;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t up = __shfl_up(incl, o);
+        if (lane >= o) incl += up;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    uint32_t wsum = 0, total = 0;
+    for (int w = 0; w < kBlock / 64; w++) {
+        if (w < wave) wsum += wave_tot[w];
+        total += wave_tot[w];
+    }
+    uint32_t acc = wsum + incl - run;  // exclusive prefix of this thread's first item
+#pragma unroll
+    for (int j = 0; j < kScanItems; j++) {
+        uint32_t x = v[j];
+        if (INCLUSIVE) acc += x;
+        if (base + j < n) data[base + j] = acc;
+        if (!INCLUSIVE) acc += x;
+    }
+    if (sums && tid == 0) sums[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(kBlock) void scan_add_kernel(uint32_t* __restrict__ data, uint64_t n,
+                                                          const uint32_t* __restrict__ sums) {
+    uint32_t add = sums[blockIdx.x];
+    uint64_t base = (uint64_t)blockIdx.x * kScanTile;
+#pragma unroll
+    for (int j = 0; j < kScanItems; j++) {
+        uint64_t i = base + (uint64_t)j * kBlock + threadIdx.x;
+        if (i < n) data[i] += add;
+    }
+}
+
+// ---- K4: priority of every gap -----------------------------------------------------------
+// lbvh_get_split_idx, lbvh.c:15-42, seen from the gap: differing codes -> shared leading
+// bits; equal codes -> 64 + depth of the gap in the count/2 tree of its run.
+__global__ __launch_bounds__(kBlock) void gap_priority_kernel(const uint64_t* __restrict__ keys, uint64_t n,
+                                                              uint8_t* __restrict__ prio) {
+    uint64_t g = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (g + 1 >= n) return;
+    uint64_t k0 = keys[g], k1 = keys[g + 1];
+    if (k0 != k1) {
+        prio[g] = (uint8_t)__clzll((long long)(k0 ^ k1));
+        return;
+    }
+    // run of equal codes [a, b): a = first index with key == k0, b = first index with key > k0
+    uint64_t lo = 0, hi = g;
+    while (lo < hi) {
+        uint64_t mid = (lo + hi) >> 1;
+        if (keys[mid] < k0) lo = mid + 1;
+        else hi = mid;
+    }
+    uint64_t a = lo;
+    lo = g + 1;
+    hi = n;
+    while (lo < hi) {
+        uint64_t mid = (lo + hi) >> 1;
+        if (keys[mid] > k0) hi = mid;
+        else lo = mid + 1;
+    }
+    uint64_t b = lo;
+    uint64_t s = a, c = b - a;
+    uint32_t depth = 0;
+    for (;;) {
+        uint64_t m = c >> 1;          // count/2, lbvh.c:23
+        uint64_t gap = s + m - 1;     // the gap this node splits at
+        if (g == gap) break;
+        if (g < gap) c = m;
+        else {
+            s += m;
+            c -= m;
+        }
+        depth++;
+    }
+    prio[g] = (uint8_t)(64u + depth);
+}
+
+// ---- K5 + K6: hierarchy emission with box refit ------------------------------------------
+// lbvh_create_subtree, lbvh.c:44-72, bottom-up.  A child publishes its record in its
+// parent's slot and bumps the parent's arrival counter; the second child to arrive
+// reads its sibling's record, merges (merge_rng3_f32(left, right), lbvh.c:58) and walks on.
+//
+// Hand-off between workgroups: the record is written with device-scope (write-through)
+// stores, the wave drains them (s_waitcnt vmcnt(0)) before its counter add, and the
+// sibling is read with device-scope loads only after the add has returned.  FENCE = true
+// replaces that with plain accesses bracketed by __threadfence().
+template <bool FENCE>
+__device__ __forceinline__ void child_store(ChildRec* slot, const float* box, uint32_t far_end, uint32_t dl) {
+    uint64_t w0 = (uint64_t)__float_as_uint(box[0]) | ((uint64_t)__float_as_uint(box[1]) << 32);
+    uint64_t w1 = (uint64_t)__float_as_uint(box[2]) | ((uint64_t)__float_as_uint(box[3]) << 32);
+    uint64_t w2 = (uint64_t)__float_as_uint(box[4]) | ((uint64_t)__float_as_uint(box[5]) << 32);
+    uint64_t w3 = (uint64_t)far_end | ((uint64_t)dl << 32);
+    uint64_t* p = (uint64_t*)slot;
+    if (FENCE) {
+        p[0] = w0; p[1] = w1; p[2] = w2; p[3] = w3;
+    } else {
+        __hip_atomic_store(p + 0, w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(p + 1, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(p + 2, w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(p + 3, w3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+template <bool FENCE>
+__device__ __forceinline__ void child_load(const ChildRec* slot, float* box, uint32_t* far_end, uint32_t* dl) {
+    uint64_t* p = (uint64_t*)slot;
+    uint64_t w0, w1, w2, w3;
+    if (FENCE) {
+        w0 = ((volatile uint64_t*)p)[0]; w1 = ((volatile uint64_t*)p)[1];
+        w2 = ((volatile uint64_t*)p)[2]; w3 = ((volatile uint64_t*)p)[3];
+    } else {
+        w0 = __hip_atomic_load(p + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        w1 = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        w2 = __hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        w3 = __hip_atomic_load(p + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    box[0] = __uint_as_float((uint32_t)w0); box[1] = __uint_as_float((uint32_t)(w0 >> 32));
+    box[2] = __uint_as_float((uint32_t)w1); box[3] = __uint_as_float((uint32_t)(w1 >> 32));
+    box[4] = __uint_as_float((uint32_t)w2); box[5] = __uint_as_float((uint32_t)(w2 >> 32));
+    *far_end = (uint32_t)w3;
+    *dl = (uint32_t)(w3 >> 32);
+}
+
+template <bool FENCE>
+__global__ __launch_bounds__(kBlock) void hierarchy_kernel(uint32_t n, const uint8_t* __restrict__ prio,
+                                                           const uint32_t* __restrict__ sorted_idx,
+                                                           const float* __restrict__ aabb6, ChildRec* child,
+                                                           uint32_t* flags, uint32_t* __restrict__ cnt_l) {
+    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    uint32_t l = i, r = i, dl = 0;
+    float box[6];
+    {
+        const float* b = aabb6 + 6 * (uint64_t)sorted_idx[i];  // node->aabb = in_aabbs[id - 1], lbvh.c:53
+#pragma unroll
+        for (int k = 0; k < 6; k++) box[k] = b[k];
+    }
+    for (;;) {
+        if (l == 0 && r == n - 1) {  // the root: top of the left spine that starts at leaf 0
+            cnt_l[0] = dl;
+            break;
+        }
+        // of the two gaps that bound [l, r] the parent is the one with the larger priority
+        bool parent_right = (l == 0) || (r != n - 1 && prio[r] > prio[l - 1]);
+        uint32_t parent = parent_right ? r : l - 1;
+        uint32_t side = parent_right ? 0u : 1u;  // 0: this node is the LEFT child
+        if (side == 1) cnt_l[l] = dl;            // a right child tops the left spine that starts at l
+        child_store<FENCE>(&child[2 * (uint64_t)parent + side], box, parent_right ? l : r, dl);
+        if (FENCE) __threadfence();
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        uint32_t old = atomicAdd(&flags[parent], 1u);
+        if (old == 0) break;  // first to arrive: the sibling's subtree carries on from here
+        if (FENCE) __threadfence();
+        float sbox[6];
+        uint32_t s_far, s_dl;
+        child_load<FENCE>(&child[2 * (uint64_t)parent + (1u - side)], sbox, &s_far, &s_dl);
+        if (side == 0) {  // sibling is the right child
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                box[k] = ref_min(box[k], sbox[k]);
+                box[k + 3] = ref_max(box[k + 3], sbox[k + 3]);
+            }
+            r = s_far;
+            dl = dl + 1;
+        } else {  // sibling is the left child
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                box[k] = ref_min(sbox[k], box[k]);
+                box[k + 3] = ref_max(sbox[k + 3], box[k + 3]);
+            }
+            l = s_far;
+            dl = s_dl + 1;
+        }
+    }
+}
+
+// ---- K7: pre-order records ------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void emit_kernel(uint32_t n, const uint32_t* __restrict__ sorted_idx,
+                                                      const float* __restrict__ aabb6,
+                                                      const ChildRec* __restrict__ child,
+                                                      const uint32_t* __restrict__ spine_scan,
+                                                      float4* __restrict__ nodes) {
+    uint64_t t = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (t < n) {  // leaf t (sorted position)
+        uint32_t i = (uint32_t)t;
+        uint32_t pre = i + spine_scan[i];
+        uint32_t prim = sorted_idx[i];
+        const float* b = aabb6 + 6 * (uint64_t)prim;
+        nodes[2 * (uint64_t)pre] = make_float4(b[0], b[1], b[2], __uint_as_float(pre + 1));
+        nodes[2 * (uint64_t)pre + 1] = make_float4(b[3], b[4], b[5], __uint_as_float(prim + 1));  // id = idx + 1, lbvh.c:116
+        return;
+    }
+    uint64_t g = t - n;
+    if (g + 1 >= n) return;
+    const ChildRec L = child[2 * g], R = child[2 * g + 1];
+    uint32_t l = L.far_end, r = R.far_end;
+    uint32_t dl = L.dl + 1;
+    uint32_t pre = l + spine_scan[l] - dl;
+    uint32_t size = 2 * (r - l + 1) - 1;
+    nodes[2 * (uint64_t)pre] = make_float4(ref_min(L.box[0], R.box[0]), ref_min(L.box[1], R.box[1]),
+                                           ref_min(L.box[2], R.box[2]), __uint_as_float(pre + size));
+    nodes[2 * (uint64_t)pre + 1] = make_float4(ref_max(L.box[3], R.box[3]), ref_max(L.box[4], R.box[4]),
+                                               ref_max(L.box[5], R.box[5]), __uint_as_float(0u));
+}
+
+// ---- K8: world box of every instance, rt_cpu_tlas_node_to_aabb, raytracer_cpu.c:131-147 ------
+__device__ __forceinline__ void rot_quat(const float p[3], const float q[4], float out[3]) {  // common_math.c:91
+    float qq = q[0] * q[0] + q[1] * q[1] + q[2] * q[2];
+    float s0 = q[3] * q[3] - qq;
+    float qp = q[0] * p[0] + q[1] * p[1] + q[2] * p[2];
+    float s1 = 2.f * qp;
+    float cx = q[1] * p[2] - q[2] * p[1];
+    float cy = -(q[0] * p[2] - q[2] * p[0]);
+    float cz = q[0] * p[1] - q[1] * p[0];
+    float s2 = 2.f * q[3];
+    out[0] = (p[0] * s0 + q[0] * s1) + cx * s2;
+    out[1] = (p[1] * s0 + q[1] * s1) + cy * s2;
+    out[2] = (p[2] * s0 + q[2] * s1) + cz * s2;
+}
+
+__global__ __launch_bounds__(kBlock) void instance_aabb_kernel(const DevInstance* __restrict__ inst, uint32_t n,
+                                                               const float4* __restrict__ blas,
+                                                               float* __restrict__ aabb6) {
+    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const DevInstance it = inst[i];
+    float* o = aabb6 + 6 * (uint64_t)i;
+    if (it.type == RTHIP_INST_SPHERE) {
+        float rr = it.sphere_radius;
+        for (int k = 0; k < 3; k++) {
+            o[k] = it.sphere_center[k] - rr;
+            o[k + 3] = it.sphere_center[k] + rr;
+        }
+        return;
+    }
+    float4 lo = blas[2 * (uint64_t)it.node_base], hi = blas[2 * (uint64_t)it.node_base + 1];
+    float bmin[3] = {lo.x, lo.y, lo.z}, bmax[3] = {hi.x, hi.y, hi.z};
+    float mn[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f};
+    float mx[3] = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
+    for (int c = 0; c < 8; c++) {  // corner order of rt_cpu_transform_aabb, raytracer_cpu.c:584-593
+        float p[3] = {(c & 4) ? bmax[0] : bmin[0], (c & 2) ? bmax[1] : bmin[1], (c & 1) ? bmax[2] : bmin[2]};
+        float ps[3] = {p[0] * it.scale[0], p[1] * it.scale[1], p[2] * it.scale[2]};
+        float w[3];
+        rot_quat(ps, it.rotation, w);
+        for (int k = 0; k < 3; k++) {
+            float v = w[k] + it.translation[k];
+            mn[k] = ref_min(mn[k], v);
+            mx[k] = ref_max(mx[k], v);
+        }
+    }
+    for (int k = 0; k < 3; k++) {
+        o[k] = mn[k];
+        o[k + 3] = mx[k];
+    }
+}
+
+inline uint32_t div_up(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+
+// exclusive / inclusive prefix sum of n uint32 in place; tmp holds the block sums of every level
+template <bool INCLUSIVE>
+int scan_u32(rthip_ctx* ctx, uint32_t* d, uint64_t n, uint32_t* tmp, hipStream_t s) {
+    uint32_t blocks = div_up(n, kScanTile);
+    if (blocks <= 1) {
+        scan_tile_kernel<INCLUSIVE><<<1, kBlock, 0, s>>>(d, n, nullptr);
+        RT_HIP(ctx, hipGetLastError());
+        return RTHIP_OK;
+    }
+    scan_tile_kernel<INCLUSIVE><<<blocks, kBlock, 0, s>>>(d, n, tmp);
+    RT_HIP(ctx, hipGetLastError());
+    RT_TRY((scan_u32<false>(ctx, tmp, blocks, tmp + ((blocks + 63) & ~63u), s)));
+    scan_add_kernel<<<blocks, kBlock, 0, s>>>(d, n, tmp);
+    RT_HIP(ctx, hipGetLastError());
+    return RTHIP_OK;
+}
+
+size_t scan_tmp_elems(uint64_t n) {
+    size_t total = 0;
+    while (n > (uint64_t)kScanTile) {
+        uint64_t blocks = (n + kScanTile - 1) / kScanTile;
+        total += (blocks + 63) & ~63ull;
+        n = blocks;
+    }
+    return total + 64;
+}
+
+}  // namespace
+
+int deinterleave_device(rthip_ctx* ctx, const void* d_interleaved, uint32_t vertex_count, uint32_t stride,
+                        uint32_t off, float* x, float* y, float* z, hipStream_t stream) {
+    if (vertex_count == 0) return RTHIP_OK;
+    deinterleave_kernel<<<div_up(vertex_count, kBlock), kBlock, 0, stream>>>((const uint8_t*)d_interleaved,
+                                                                              vertex_count, stride, off, x, y, z);
+    RT_HIP(ctx, hipGetLastError());
+    return RTHIP_OK;
+}
+
+int mesh_prepare_device(rthip_ctx* ctx, const float* px, const float* py, const float* pz, const float* nx,
+                        const float* ny, const float* nz, const uint32_t* indices, uint64_t n_tris,
+                        float* d_aabb6, float4* d_tri_v, float4* d_tri_n, hipStream_t stream) {
+    if (n_tris == 0) return RTHIP_OK;
+    tri_prepare_kernel<<<div_up(n_tris, kBlock), kBlock, 0, stream>>>(px, py, pz, nx, ny, nz, indices, n_tris,
+                                                                       d_aabb6, d_tri_v, d_tri_n);
+    RT_HIP(ctx, hipGetLastError());
+    return RTHIP_OK;
+}
+
+int instance_aabbs_device(rthip_ctx* ctx, const DevInstance* d_inst, uint32_t n, const float4* d_blas,
+                          float* d_aabb6, hipStream_t stream) {
+    if (n == 0) return RTHIP_OK;
+    instance_aabb_kernel<<<div_up(n, kBlock), kBlock, 0, stream>>>(d_inst, n, d_blas, d_aabb6);
+    RT_HIP(ctx, hipGetLastError());
+    return RTHIP_OK;
+}
+
+int lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, float4* d_nodes, hipStream_t s,
+                      uint64_t* d_codes_unsorted, uint64_t* d_keys_sorted, uint32_t* d_ids_sorted) {
+    if (n == 0) return rthip_fail(ctx, RTHIP_E_INVALID, "lbvh build needs at least one box");
+    if (n > (1ull << 30)) return rthip_fail(ctx, RTHIP_E_LIMIT, "lbvh build is limited to 2^30 boxes (got %llu)",
+                                            (unsigned long long)n);
+    LbvhWorkspace& w = ctx->ws;
+    const uint32_t tiles = div_up(n, kSortTile);
+    const uint64_t hist_elems = 256ull * tiles;
+    RT_TRY(rthip_reserve(ctx, w.keys[0], n * 8));
+    RT_TRY(rthip_reserve(ctx, w.keys[1], n * 8));
+    RT_TRY(rthip_reserve(ctx, w.vals[0], n * 4));
+    RT_TRY(rthip_reserve(ctx, w.vals[1], n * 4));
+    RT_TRY(rthip_reserve(ctx, w.block_hist, hist_elems * 4));
+    RT_TRY(rthip_reserve(ctx, w.scan_tmp, (scan_tmp_elems(hist_elems) + scan_tmp_elems(n)) * 4));
+    RT_TRY(rthip_reserve(ctx, w.prio, n));
+    RT_TRY(rthip_reserve(ctx, w.child, 2 * n * sizeof(ChildRec)));
+    RT_TRY(rthip_reserve(ctx, w.flags, n * 4));
+    RT_TRY(rthip_reserve(ctx, w.cnt_l, n * 4));
+    RT_TRY(rthip_reserve(ctx, w.bounds, 64));
+
+    uint32_t* bounds = (uint32_t*)w.bounds.p;
+    uint64_t* keys[2] = {(uint64_t*)w.keys[0].p, (uint64_t*)w.keys[1].p};
+    uint32_t* vals[2] = {(uint32_t*)w.vals[0].p, (uint32_t*)w.vals[1].p};
+    uint32_t* scan_tmp = (uint32_t*)w.scan_tmp.p;
+
+    bounds_init_kernel<<<1, 64, 0, s>>>(bounds);
+    uint32_t bblocks = div_up(n, kBlock);
+    if (bblocks > 2048) bblocks = 2048;
+    bounds_kernel<<<bblocks, kBlock, 0, s>>>(d_aabb6, n, bounds);
+    morton_kernel<<<div_up(n, kBlock), kBlock, 0, s>>>(d_aabb6, n, bounds, keys[0], vals[0]);
+    RT_HIP(ctx, hipGetLastError());
+    if (d_codes_unsorted)
+        RT_HIP(ctx, hipMemcpyAsync(d_codes_unsorted, keys[0], n * 8, hipMemcpyDeviceToDevice, s));
+
+    int cur = 0;
+    if (n > 1) {
+        for (int pass = 0; pass < 8; pass++) {
+            int shift = pass * 8;
+            radix_hist_kernel<<<tiles, kBlock, 0, s>>>(keys[cur], n, shift, (uint32_t*)w.block_hist.p, tiles);
+            RT_HIP(ctx, hipGetLastError());
+            RT_TRY((scan_u32<false>(ctx, (uint32_t*)w.block_hist.p, hist_elems, scan_tmp, s)));
+            radix_scatter_kernel<<<tiles, kBlock, 0, s>>>(keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, shift,
+                                                          (const uint32_t*)w.block_hist.p, tiles);
+            RT_HIP(ctx, hipGetLastError());
+            cur ^= 1;
+        }
+    }
+    if (d_keys_sorted) RT_HIP(ctx, hipMemcpyAsync(d_keys_sorted, keys[cur], n * 8, hipMemcpyDeviceToDevice, s));
+    if (d_ids_sorted) RT_HIP(ctx, hipMemcpyAsync(d_ids_sorted, vals[cur], n * 4, hipMemcpyDeviceToDevice, s));
+
+    const uint32_t n32 = (uint32_t)n;
+    if (n > 1) {
+        gap_priority_kernel<<<div_up(n - 1, kBlock), kBlock, 0, s>>>(keys[cur], n, (uint8_t*)w.prio.p);
+        RT_HIP(ctx, hipGetLastError());
+        RT_HIP(ctx, hipMemsetAsync(w.flags.p, 0, (n - 1) * 4, s));
+    }
+    if (ctx->refit_fence)
+        hierarchy_kernel<true><<<div_up(n, kBlock), kBlock, 0, s>>>(n32, (const uint8_t*)w.prio.p, vals[cur], d_aabb6,
+                                                                    (ChildRec*)w.child.p, (uint32_t*)w.flags.p,
+                                                                    (uint32_t*)w.cnt_l.p);
+    else
+        hierarchy_kernel<false><<<div_up(n, kBlock), kBlock, 0, s>>>(n32, (const uint8_t*)w.prio.p, vals[cur], d_aabb6,
+                                                                     (ChildRec*)w.child.p, (uint32_t*)w.flags.p,
+                                                                     (uint32_t*)w.cnt_l.p);
+    RT_HIP(ctx, hipGetLastError());
+    RT_TRY((scan_u32<true>(ctx, (uint32_t*)w.cnt_l.p, n, scan_tmp + scan_tmp_elems(hist_elems), s)));
+    emit_kernel<<<div_up(2 * n - 1, kBlock), kBlock, 0, s>>>(n32, vals[cur], d_aabb6, (const ChildRec*)w.child.p,
+                                                             (const uint32_t*)w.cnt_l.p, d_nodes);
+    RT_HIP(ctx, hipGetLastError());
+    return RTHIP_OK;
+}

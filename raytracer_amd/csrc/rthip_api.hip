@@ -1,0 +1,532 @@
+// The C ABI of include/rthip.h: context management, uploads, and the entry points that
+// sequence the kernels of lbvh_build.hip and trace.hip.  No computation happens on the
+// host: a missing or non-gfx950 GPU makes rthip_create fail.
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "rthip_internal.h"
+
+int rthip_fail(rthip_ctx* ctx, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    return code;
+}
+
+int rthip_reserve(rthip_ctx* ctx, DevBuf& b, size_t bytes) {
+    if (bytes == 0) bytes = 256;
+    if (b.cap >= bytes) return RTHIP_OK;
+    if (b.p) {
+        (void)hipFree(b.p);
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    size_t want = (bytes + 255) & ~(size_t)255;
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) {
+        b.p = nullptr;
+        return rthip_fail(ctx, RTHIP_E_NOMEM, "hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
+    }
+    b.cap = want;
+    return RTHIP_OK;
+}
+
+void rthip_release(DevBuf& b) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+}
+
+namespace {
+
+void release_mesh(HostMesh& m) {
+    rthip_release(m.interleaved);
+    rthip_release(m.indices);
+    rthip_release(m.px);
+    rthip_release(m.py);
+    rthip_release(m.pz);
+    rthip_release(m.nx);
+    rthip_release(m.ny);
+    rthip_release(m.nz);
+    m = HostMesh();
+}
+
+DevScene make_scene(const rthip_ctx* ctx) {
+    DevScene s;
+    s.tlas = (const float4*)ctx->tlas_nodes.p;
+    s.n_tlas = ctx->n_inst ? 2 * ctx->n_inst - 1 : 0;
+    s.blas = (const float4*)ctx->blas_nodes.p;
+    s.tri_v = (const float4*)ctx->tri_v.p;
+    s.tri_n = (const float4*)ctx->tri_n.p;
+    s.inst = (const DevInstance*)ctx->inst.p;
+    s.mats = (const rthip_material*)ctx->mats.p;
+    s.n_inst = ctx->n_inst;
+    s.n_mats = ctx->n_mats;
+    s.max_bounces = ctx->max_bounces;
+    s.sky = ctx->sky ? 1u : 0u;
+    return s;
+}
+
+int check_ready(rthip_ctx* ctx, const char* what) {
+    if (!ctx) return RTHIP_E_INVALID;
+    if (!ctx->tlas_built) return rthip_fail(ctx, RTHIP_E_INVALID, "%s: rthip_tlas_build has not run", what);
+    return RTHIP_OK;
+}
+
+int check_cast(rthip_ctx* ctx, const rthip_cast_settings* cast, int width, int height) {
+    if (!cast) return rthip_fail(ctx, RTHIP_E_INVALID, "cast settings are NULL");
+    if (width <= 0 || height <= 0) return rthip_fail(ctx, RTHIP_E_INVALID, "image size %dx%d is not positive", width, height);
+    if ((uint64_t)width * (uint64_t)height > (1ull << 31)) return rthip_fail(ctx, RTHIP_E_LIMIT, "image has more than 2^31 pixels");
+    if (cast->samples == 0 || cast->samples > 255)
+        return rthip_fail(ctx, RTHIP_E_INVALID, "samples must be in 1..255 (RT_CastSettings.samples is a u8), got %u", cast->samples);
+    return RTHIP_OK;
+}
+
+uint64_t* counters_or_null(rthip_ctx* ctx) { return ctx->counting ? (uint64_t*)ctx->counters.p : nullptr; }
+
+}  // namespace
+
+extern "C" {
+
+int rthip_abi_version(void) { return RTHIP_ABI_VERSION; }
+
+const char* rthip_last_error(const rthip_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int rthip_create(rthip_ctx** out_ctx, int device_id) {
+    if (!out_ctx) return RTHIP_E_INVALID;
+    *out_ctx = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device_id < 0 || device_id >= count) return RTHIP_E_HIP;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return RTHIP_E_HIP;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return RTHIP_E_HIP;  // the kernels exist for gfx950 only
+    if (hipSetDevice(device_id) != hipSuccess) return RTHIP_E_HIP;
+    rthip_ctx* ctx = new rthip_ctx();
+    ctx->device = device_id;
+    const char* fence = getenv("RTHIP_REFIT_FENCE");
+    ctx->refit_fence = (fence && fence[0] == '1') ? 1 : 0;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
+        rthip_reserve(ctx, ctx->counters, 64) != RTHIP_OK || hipMemset(ctx->counters.p, 0, 64) != hipSuccess) {
+        rthip_destroy(ctx);
+        return RTHIP_E_HIP;
+    }
+    *out_ctx = ctx;
+    return RTHIP_OK;
+}
+
+void rthip_destroy(rthip_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    for (auto& m : ctx->meshes) release_mesh(m);
+    LbvhWorkspace& w = ctx->ws;
+    DevBuf* all[] = {&w.aabb, &w.keys[0], &w.keys[1], &w.vals[0], &w.vals[1], &w.block_hist, &w.scan_tmp, &w.prio,
+                     &w.child, &w.flags, &w.cnt_l, &w.bounds, &ctx->blas_nodes, &ctx->tri_v, &ctx->tri_n,
+                     &ctx->tlas_nodes, &ctx->inst, &ctx->mats, &ctx->inst_aabb, &ctx->counters, &ctx->scratch_a,
+                     &ctx->scratch_b, &ctx->scratch_c, &ctx->scratch_d, &ctx->scratch_e};
+    for (DevBuf* b : all) rthip_release(*b);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int rthip_set_tracer(rthip_ctx* ctx, uint32_t max_bounces, int sky) {
+    if (!ctx) return RTHIP_E_INVALID;
+    if (max_bounces >= 64)  // Assert(settings.max_bounces < RT_MAX_MAX_BOUNCES), raytracer_cpu.c:15
+        return rthip_fail(ctx, RTHIP_E_LIMIT, "max_bounces must be < 64, got %u", max_bounces);
+    ctx->max_bounces = max_bounces;
+    ctx->sky = sky ? 1 : 0;
+    return RTHIP_OK;
+}
+
+int rthip_set_counting(rthip_ctx* ctx, int enabled) {
+    if (!ctx) return RTHIP_E_INVALID;
+    ctx->counting = enabled ? 1 : 0;
+    return RTHIP_OK;
+}
+
+// ---- BLAS ----------------------------------------------------------------------------
+
+int rthip_blas_begin(rthip_ctx* ctx, uint32_t n_meshes) {
+    if (!ctx) return RTHIP_E_INVALID;
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipDeviceSynchronize());
+    for (auto& m : ctx->meshes) release_mesh(m);
+    ctx->meshes.clear();
+    ctx->meshes.resize(n_meshes);
+    ctx->blas_committed = false;
+    ctx->tlas_built = false;
+    ctx->total_blas_nodes = 0;
+    ctx->total_tris = 0;
+    return RTHIP_OK;
+}
+
+int rthip_blas_add_mesh(rthip_ctx* ctx, uint32_t blas_id, const void* verts, uint32_t vertex_count,
+                        uint32_t stride_bytes, uint32_t pos_off, int32_t nrm_off, const uint32_t* idx,
+                        uint32_t index_count) {
+    if (!ctx) return RTHIP_E_INVALID;
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    if (blas_id >= ctx->meshes.size()) return rthip_fail(ctx, RTHIP_E_INVALID, "blas_id %u out of range (%zu meshes)", blas_id, ctx->meshes.size());
+    if (ctx->blas_committed) return rthip_fail(ctx, RTHIP_E_INVALID, "rthip_blas_add_mesh after rthip_blas_commit");
+    if (!verts || vertex_count == 0) return rthip_fail(ctx, RTHIP_E_INVALID, "mesh %u has no vertices", blas_id);
+    if (stride_bytes < 12 || (stride_bytes & 3) || (pos_off & 3) || pos_off + 12 > stride_bytes)
+        return rthip_fail(ctx, RTHIP_E_INVALID, "mesh %u: bad stride/offset (%u, %u)", blas_id, stride_bytes, pos_off);
+    if (nrm_off >= 0 && (((uint32_t)nrm_off & 3) || (uint32_t)nrm_off + 12 > stride_bytes))
+        return rthip_fail(ctx, RTHIP_E_INVALID, "mesh %u: bad normal offset %d", blas_id, nrm_off);
+    const bool indexed = idx != nullptr && index_count != 0;
+    const uint32_t n_tris = indexed ? index_count / 3 : vertex_count / 3;  // raytracer_cpu.c:63
+    if (n_tris == 0) return rthip_fail(ctx, RTHIP_E_INVALID, "mesh %u has no triangles", blas_id);
+    if (indexed) {
+        for (uint32_t k = 0; k < n_tris * 3; k++)
+            if (idx[k] >= vertex_count)
+                return rthip_fail(ctx, RTHIP_E_INVALID, "mesh %u: index %u at position %u exceeds vertex count %u", blas_id, idx[k], k, vertex_count);
+    }
+    HostMesh& m = ctx->meshes[blas_id];
+    release_mesh(m);
+    m.vertex_count = vertex_count;
+    m.stride = stride_bytes;
+    m.pos_off = pos_off;
+    m.nrm_off = nrm_off;
+    m.index_count = indexed ? n_tris * 3 : 0;
+    m.n_tris = n_tris;
+    const size_t vbytes = (size_t)vertex_count * stride_bytes;
+    RT_TRY(rthip_reserve(ctx, m.interleaved, vbytes));
+    RT_HIP(ctx, hipMemcpyAsync(m.interleaved.p, verts, vbytes, hipMemcpyHostToDevice, ctx->stream));
+    if (indexed) {
+        RT_TRY(rthip_reserve(ctx, m.indices, (size_t)m.index_count * 4));
+        RT_HIP(ctx, hipMemcpyAsync(m.indices.p, idx, (size_t)m.index_count * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
+    const size_t fbytes = (size_t)vertex_count * 4;
+    RT_TRY(rthip_reserve(ctx, m.px, fbytes));
+    RT_TRY(rthip_reserve(ctx, m.py, fbytes));
+    RT_TRY(rthip_reserve(ctx, m.pz, fbytes));
+    RT_TRY(deinterleave_device(ctx, m.interleaved.p, vertex_count, stride_bytes, pos_off, (float*)m.px.p,
+                               (float*)m.py.p, (float*)m.pz.p, ctx->stream));
+    if (nrm_off >= 0) {
+        RT_TRY(rthip_reserve(ctx, m.nx, fbytes));
+        RT_TRY(rthip_reserve(ctx, m.ny, fbytes));
+        RT_TRY(rthip_reserve(ctx, m.nz, fbytes));
+        RT_TRY(deinterleave_device(ctx, m.interleaved.p, vertex_count, stride_bytes, (uint32_t)nrm_off,
+                                   (float*)m.nx.p, (float*)m.ny.p, (float*)m.nz.p, ctx->stream));
+    }
+    // the caller's memory must not be referenced after this call returns
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    m.present = true;
+    return RTHIP_OK;
+}
+
+int rthip_blas_commit(rthip_ctx* ctx) {
+    if (!ctx) return RTHIP_E_INVALID;
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    uint64_t nodes = 0, tris = 0;
+    bool any_normals = false;
+    for (size_t k = 0; k < ctx->meshes.size(); k++) {
+        HostMesh& m = ctx->meshes[k];
+        if (!m.present) return rthip_fail(ctx, RTHIP_E_INVALID, "mesh %zu was never added", k);
+        m.dev.node_base = (uint32_t)nodes;
+        m.dev.n_nodes = 2 * m.n_tris - 1;
+        m.dev.tri_base = (uint32_t)tris;
+        m.dev.n_tris = m.n_tris;
+        m.dev.has_normals = m.nrm_off >= 0 ? 1u : 0u;
+        any_normals |= m.nrm_off >= 0;
+        nodes += m.dev.n_nodes;
+        tris += m.n_tris;
+        if (nodes > 0xffffffffull) return rthip_fail(ctx, RTHIP_E_LIMIT, "more than 2^32 BLAS nodes in total");
+    }
+    ctx->total_blas_nodes = nodes;
+    ctx->total_tris = tris;
+    RT_TRY(rthip_reserve(ctx, ctx->blas_nodes, nodes * 32));
+    RT_TRY(rthip_reserve(ctx, ctx->tri_v, tris * 48));
+    if (any_normals) RT_TRY(rthip_reserve(ctx, ctx->tri_n, tris * 48));
+    float total_ms = 0.f;
+    for (HostMesh& m : ctx->meshes) {
+        RT_TRY(rthip_reserve(ctx, ctx->ws.aabb, (size_t)m.n_tris * 24));
+        RT_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+        RT_TRY(mesh_prepare_device(ctx, (const float*)m.px.p, (const float*)m.py.p, (const float*)m.pz.p,
+                                   (const float*)m.nx.p, (const float*)m.ny.p, (const float*)m.nz.p,
+                                   m.index_count ? (const uint32_t*)m.indices.p : nullptr, m.n_tris,
+                                   (float*)ctx->ws.aabb.p, (float4*)ctx->tri_v.p + 3 * (size_t)m.dev.tri_base,
+                                   m.nrm_off >= 0 ? (float4*)ctx->tri_n.p + 3 * (size_t)m.dev.tri_base : nullptr,
+                                   ctx->stream));
+        RT_TRY(lbvh_build_device(ctx, (const float*)ctx->ws.aabb.p, m.n_tris,
+                                 (float4*)ctx->blas_nodes.p + 2 * (size_t)m.dev.node_base, ctx->stream, nullptr,
+                                 nullptr, nullptr));
+        RT_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+        RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        float ms = 0.f;
+        RT_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+        total_ms += ms;
+    }
+    ctx->last_build_ms = total_ms;
+    ctx->blas_committed = true;
+    return RTHIP_OK;
+}
+
+// ---- TLAS ----------------------------------------------------------------------------
+
+int rthip_tlas_build(rthip_ctx* ctx, const rthip_instance* instances, uint32_t n_instances,
+                     const rthip_material* materials, uint32_t n_materials) {
+    if (!ctx) return RTHIP_E_INVALID;
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->blas_committed) return rthip_fail(ctx, RTHIP_E_INVALID, "rthip_tlas_build before rthip_blas_commit");
+    if (n_instances && !instances) return rthip_fail(ctx, RTHIP_E_INVALID, "instances is NULL");
+    if (n_materials && !materials) return rthip_fail(ctx, RTHIP_E_INVALID, "materials is NULL");
+    if (n_instances > (1u << 30)) return rthip_fail(ctx, RTHIP_E_LIMIT, "more than 2^30 instances");
+    std::vector<DevInstance> dev(n_instances);
+    for (uint32_t k = 0; k < n_instances; k++) {
+        const rthip_instance& s = instances[k];
+        DevInstance& d = dev[k];
+        memset(&d, 0, sizeof d);
+        if (s.material >= (int32_t)n_materials)
+            return rthip_fail(ctx, RTHIP_E_INVALID, "instance %u: material %d out of range (%u materials)", k, s.material, n_materials);
+        d.type = s.type;
+        d.material = s.material < 0 ? -1 : s.material;
+        if (s.type == RTHIP_INST_SPHERE) {
+            memcpy(d.sphere_center, s.sphere_center, 12);
+            d.sphere_radius = s.sphere_radius;
+        } else if (s.type == RTHIP_INST_MESH) {
+            if (s.blas_id >= ctx->meshes.size())
+                return rthip_fail(ctx, RTHIP_E_INVALID, "instance %u: blas_id %u out of range (%zu meshes)", k, s.blas_id, ctx->meshes.size());
+            const DevMesh& m = ctx->meshes[s.blas_id].dev;
+            d.node_base = m.node_base;
+            d.n_nodes = m.n_nodes;
+            d.tri_base = m.tri_base;
+            d.has_normals = m.has_normals;
+            memcpy(d.translation, s.translation, 12);
+            memcpy(d.rotation, s.rotation, 16);
+            memcpy(d.scale, s.scale, 12);
+        } else {
+            return rthip_fail(ctx, RTHIP_E_INVALID, "instance %u: unknown type %u", k, s.type);
+        }
+    }
+    for (uint32_t k = 0; k < n_materials; k++)
+        if (materials[k].type > RTHIP_MAT_LIGHT)
+            return rthip_fail(ctx, RTHIP_E_INVALID, "material %u: unknown type %u", k, materials[k].type);
+
+    RT_HIP(ctx, hipDeviceSynchronize());  // the previous structure may still be in use by an enqueued cast
+    ctx->tlas_built = false;
+    ctx->n_inst = n_instances;
+    ctx->n_mats = n_materials;
+    RT_TRY(rthip_reserve(ctx, ctx->inst, (size_t)n_instances * sizeof(DevInstance)));
+    RT_TRY(rthip_reserve(ctx, ctx->mats, (size_t)n_materials * sizeof(rthip_material)));
+    RT_TRY(rthip_reserve(ctx, ctx->inst_aabb, (size_t)n_instances * 24));
+    RT_TRY(rthip_reserve(ctx, ctx->tlas_nodes, n_instances ? (2 * (size_t)n_instances - 1) * 32 : 32));
+    if (n_materials)
+        RT_HIP(ctx, hipMemcpyAsync(ctx->mats.p, materials, (size_t)n_materials * sizeof(rthip_material), hipMemcpyHostToDevice, ctx->stream));
+    if (n_instances) {
+        RT_HIP(ctx, hipMemcpyAsync(ctx->inst.p, dev.data(), (size_t)n_instances * sizeof(DevInstance), hipMemcpyHostToDevice, ctx->stream));
+        RT_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+        RT_TRY(instance_aabbs_device(ctx, (const DevInstance*)ctx->inst.p, n_instances, (const float4*)ctx->blas_nodes.p,
+                                     (float*)ctx->inst_aabb.p, ctx->stream));
+        RT_TRY(lbvh_build_device(ctx, (const float*)ctx->inst_aabb.p, n_instances, (float4*)ctx->tlas_nodes.p, ctx->stream,
+                                 nullptr, nullptr, nullptr));
+        RT_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    }
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));  // dev[] must outlive the copy
+    if (n_instances) RT_HIP(ctx, hipEventElapsedTime(&ctx->last_build_ms, ctx->ev0, ctx->ev1));
+    ctx->tlas_built = true;
+    return RTHIP_OK;
+}
+
+// ---- rendering ---------------------------------------------------------------------
+
+int rthip_cast_device(rthip_ctx* ctx, const rthip_cast_settings* cast, uint64_t seed, float* d_out_rgb, int width,
+                      int height, const rthip_shard* shard, void* stream) {
+    RT_TRY(check_ready(ctx, "rthip_cast_device"));
+    RT_TRY(check_cast(ctx, cast, width, height));
+    if (!d_out_rgb) return rthip_fail(ctx, RTHIP_E_INVALID, "framebuffer is NULL");
+    rthip_shard sh = {0, 0, 1};
+    if (shard) {
+        sh = *shard;
+        if (sh.mode > 2 || (sh.mode != 0 && (sh.world == 0 || sh.rank >= sh.world)))
+            return rthip_fail(ctx, RTHIP_E_INVALID, "bad shard {mode %u, rank %u, world %u}", sh.mode, sh.rank, sh.world);
+    }
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    return cast_launch(ctx, make_scene(ctx), *cast, seed, d_out_rgb, width, height, sh, counters_or_null(ctx),
+                       (hipStream_t)stream);
+}
+
+int rthip_cast(rthip_ctx* ctx, const rthip_cast_settings* cast, uint64_t seed, float* out_rgb, int width, int height) {
+    RT_TRY(check_ready(ctx, "rthip_cast"));
+    RT_TRY(check_cast(ctx, cast, width, height));
+    if (!out_rgb) return rthip_fail(ctx, RTHIP_E_INVALID, "out_rgb is NULL");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t bytes = (size_t)width * height * 3 * sizeof(float);
+    RT_TRY(rthip_reserve(ctx, ctx->scratch_a, bytes));
+    RT_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    RT_TRY(rthip_cast_device(ctx, cast, seed, (float*)ctx->scratch_a.p, width, height, nullptr, ctx->stream));
+    RT_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    RT_HIP(ctx, hipMemcpyAsync(out_rgb, ctx->scratch_a.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    RT_HIP(ctx, hipEventElapsedTime(&ctx->last_cast_ms, ctx->ev0, ctx->ev1));
+    return RTHIP_OK;
+}
+
+// ---- taps ------------------------------------------------------------------------------
+
+int rthip_lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, rthip_node* d_nodes, void* stream) {
+    if (!ctx) return RTHIP_E_INVALID;
+    if (!d_aabb6 || !d_nodes) return rthip_fail(ctx, RTHIP_E_INVALID, "NULL device pointer");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    return lbvh_build_device(ctx, d_aabb6, n, (float4*)d_nodes, (hipStream_t)stream, nullptr, nullptr, nullptr);
+}
+
+int rthip_mesh_build_device(rthip_ctx* ctx, const float* d_px, const float* d_py, const float* d_pz,
+                            uint32_t vertex_count, const uint32_t* d_indices, uint64_t n_tris, rthip_node* d_nodes,
+                            void* stream) {
+    if (!ctx) return RTHIP_E_INVALID;
+    if (!d_px || !d_py || !d_pz || !d_nodes) return rthip_fail(ctx, RTHIP_E_INVALID, "NULL device pointer");
+    if (n_tris == 0 || n_tris > (1ull << 30)) return rthip_fail(ctx, RTHIP_E_LIMIT, "triangle count %llu outside 1..2^30", (unsigned long long)n_tris);
+    if (!d_indices && 3 * n_tris > vertex_count) return rthip_fail(ctx, RTHIP_E_INVALID, "auto-indexed mesh needs 3 vertices per triangle");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_TRY(rthip_reserve(ctx, ctx->ws.aabb, n_tris * 24));
+    RT_TRY(mesh_prepare_device(ctx, d_px, d_py, d_pz, nullptr, nullptr, nullptr, d_indices, n_tris, (float*)ctx->ws.aabb.p,
+                               nullptr, nullptr, (hipStream_t)stream));
+    return lbvh_build_device(ctx, (const float*)ctx->ws.aabb.p, n_tris, (float4*)d_nodes, (hipStream_t)stream, nullptr,
+                             nullptr, nullptr);
+}
+
+int rthip_lbvh_build(rthip_ctx* ctx, const float* aabb6, uint64_t n, uint64_t* out_codes, uint64_t* out_codes_sorted,
+                     uint32_t* out_ids_sorted, rthip_node* out_nodes, float* out_ms) {
+    if (!ctx) return RTHIP_E_INVALID;
+    if (!aabb6 || n == 0) return rthip_fail(ctx, RTHIP_E_INVALID, "rthip_lbvh_build needs at least one box");
+    if (n > (1ull << 30)) return rthip_fail(ctx, RTHIP_E_LIMIT, "lbvh build is limited to 2^30 boxes");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_TRY(rthip_reserve(ctx, ctx->scratch_a, n * 24));
+    RT_TRY(rthip_reserve(ctx, ctx->scratch_b, (2 * n - 1) * 32));
+    RT_TRY(rthip_reserve(ctx, ctx->scratch_c, n * 8));
+    RT_TRY(rthip_reserve(ctx, ctx->scratch_d, n * 8));
+    RT_TRY(rthip_reserve(ctx, ctx->scratch_e, n * 4));
+    hipStream_t s = ctx->stream;
+    RT_HIP(ctx, hipMemcpyAsync(ctx->scratch_a.p, aabb6, n * 24, hipMemcpyHostToDevice, s));
+    RT_HIP(ctx, hipEventRecord(ctx->ev0, s));
+    RT_TRY(lbvh_build_device(ctx, (const float*)ctx->scratch_a.p, n, (float4*)ctx->scratch_b.p, s,
+                             out_codes ? (uint64_t*)ctx->scratch_c.p : nullptr,
+                             out_codes_sorted ? (uint64_t*)ctx->scratch_d.p : nullptr,
+                             out_ids_sorted ? (uint32_t*)ctx->scratch_e.p : nullptr));
+    RT_HIP(ctx, hipEventRecord(ctx->ev1, s));
+    if (out_codes) RT_HIP(ctx, hipMemcpyAsync(out_codes, ctx->scratch_c.p, n * 8, hipMemcpyDeviceToHost, s));
+    if (out_codes_sorted) RT_HIP(ctx, hipMemcpyAsync(out_codes_sorted, ctx->scratch_d.p, n * 8, hipMemcpyDeviceToHost, s));
+    if (out_ids_sorted) RT_HIP(ctx, hipMemcpyAsync(out_ids_sorted, ctx->scratch_e.p, n * 4, hipMemcpyDeviceToHost, s));
+    if (out_nodes) RT_HIP(ctx, hipMemcpyAsync(out_nodes, ctx->scratch_b.p, (2 * n - 1) * 32, hipMemcpyDeviceToHost, s));
+    RT_HIP(ctx, hipStreamSynchronize(s));
+    RT_HIP(ctx, hipEventElapsedTime(&ctx->last_build_ms, ctx->ev0, ctx->ev1));
+    if (out_ms) *out_ms = ctx->last_build_ms;
+    if (out_ids_sorted)
+        for (uint64_t i = 0; i < n; i++) out_ids_sorted[i] += 1;  // NodeIndex.id = idx + 1, lbvh.c:116
+    return RTHIP_OK;
+}
+
+static int unpack_hits(rthip_ctx* ctx, const void* d_hits4, uint64_t n, uint32_t* out_inst, uint32_t* out_tri, float* out_t,
+                       hipStream_t s) {
+    std::vector<uint32_t> h(4 * n);
+    RT_HIP(ctx, hipMemcpyAsync(h.data(), d_hits4, 16 * n, hipMemcpyDeviceToHost, s));
+    RT_HIP(ctx, hipStreamSynchronize(s));
+    for (uint64_t i = 0; i < n; i++) {
+        if (out_inst) out_inst[i] = h[4 * i];
+        if (out_tri) out_tri[i] = h[4 * i + 1];
+        if (out_t) memcpy(&out_t[i], &h[4 * i + 2], 4);
+    }
+    return RTHIP_OK;
+}
+
+int rthip_primary_hits(rthip_ctx* ctx, const rthip_cast_settings* cast, uint32_t* out_instance_id, uint32_t* out_tri_idx,
+                       float* out_t, int width, int height) {
+    RT_TRY(check_ready(ctx, "rthip_primary_hits"));
+    RT_TRY(check_cast(ctx, cast, width, height));
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    const uint64_t n = (uint64_t)width * height;
+    RT_TRY(rthip_reserve(ctx, ctx->scratch_a, n * 16));
+    RT_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    RT_TRY(primary_hits_launch(ctx, make_scene(ctx), *cast, width, height, (uint32_t*)ctx->scratch_a.p,
+                               counters_or_null(ctx), ctx->stream));
+    RT_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    RT_TRY(unpack_hits(ctx, ctx->scratch_a.p, n, out_instance_id, out_tri_idx, out_t, ctx->stream));
+    RT_HIP(ctx, hipEventElapsedTime(&ctx->last_cast_ms, ctx->ev0, ctx->ev1));
+    return RTHIP_OK;
+}
+
+int rthip_trace_rays_device(rthip_ctx* ctx, const float* d_origins, const float* d_directions, uint64_t n,
+                            uint32_t* d_hits, void* stream) {
+    RT_TRY(check_ready(ctx, "rthip_trace_rays_device"));
+    if (n && (!d_origins || !d_directions || !d_hits)) return rthip_fail(ctx, RTHIP_E_INVALID, "NULL device pointer");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    return trace_rays_launch(ctx, make_scene(ctx), d_origins, d_directions, n, d_hits, nullptr, nullptr,
+                             counters_or_null(ctx), (hipStream_t)stream);
+}
+
+int rthip_trace_rays(rthip_ctx* ctx, const float* origins, const float* directions, uint64_t n, uint32_t* out_instance_id,
+                     uint32_t* out_tri_idx, float* out_t, float* out_uv, float* out_normal) {
+    RT_TRY(check_ready(ctx, "rthip_trace_rays"));
+    if (n == 0) return RTHIP_OK;
+    if (!origins || !directions) return rthip_fail(ctx, RTHIP_E_INVALID, "ray arrays are NULL");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    RT_TRY(rthip_reserve(ctx, ctx->scratch_a, n * 16));
+    RT_TRY(rthip_reserve(ctx, ctx->scratch_b, n * 12));
+    RT_TRY(rthip_reserve(ctx, ctx->scratch_c, n * 12));
+    if (out_uv) RT_TRY(rthip_reserve(ctx, ctx->scratch_d, n * 8));
+    if (out_normal) RT_TRY(rthip_reserve(ctx, ctx->scratch_e, n * 12));
+    RT_HIP(ctx, hipMemcpyAsync(ctx->scratch_b.p, origins, n * 12, hipMemcpyHostToDevice, s));
+    RT_HIP(ctx, hipMemcpyAsync(ctx->scratch_c.p, directions, n * 12, hipMemcpyHostToDevice, s));
+    RT_HIP(ctx, hipEventRecord(ctx->ev0, s));
+    RT_TRY(trace_rays_launch(ctx, make_scene(ctx), (const float*)ctx->scratch_b.p, (const float*)ctx->scratch_c.p, n,
+                             (uint32_t*)ctx->scratch_a.p, out_uv ? (float*)ctx->scratch_d.p : nullptr,
+                             out_normal ? (float*)ctx->scratch_e.p : nullptr, counters_or_null(ctx), s));
+    RT_HIP(ctx, hipEventRecord(ctx->ev1, s));
+    if (out_uv) RT_HIP(ctx, hipMemcpyAsync(out_uv, ctx->scratch_d.p, n * 8, hipMemcpyDeviceToHost, s));
+    if (out_normal) RT_HIP(ctx, hipMemcpyAsync(out_normal, ctx->scratch_e.p, n * 12, hipMemcpyDeviceToHost, s));
+    RT_TRY(unpack_hits(ctx, ctx->scratch_a.p, n, out_instance_id, out_tri_idx, out_t, s));
+    RT_HIP(ctx, hipEventElapsedTime(&ctx->last_cast_ms, ctx->ev0, ctx->ev1));
+    return RTHIP_OK;
+}
+
+int rthip_get_stats(rthip_ctx* ctx, rthip_stats* out) {
+    if (!ctx || !out) return RTHIP_E_INVALID;
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipDeviceSynchronize());
+    uint64_t c[4];
+    RT_HIP(ctx, hipMemcpy(c, ctx->counters.p, 32, hipMemcpyDeviceToHost));
+    RT_HIP(ctx, hipMemset(ctx->counters.p, 0, 32));
+    out->rays = c[0];
+    out->nodes_tested = c[1];
+    out->tris_tested = c[2];
+    out->inst_entered = c[3];
+    out->last_cast_ms = ctx->last_cast_ms;
+    out->last_build_ms = ctx->last_build_ms;
+    return RTHIP_OK;
+}
+
+int rthip_get_tree(rthip_ctx* ctx, int which, rthip_node* out_nodes, uint64_t* out_count) {
+    if (!ctx) return RTHIP_E_INVALID;
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    const void* src = nullptr;
+    uint64_t n = 0;
+    if (which < 0) {
+        if (!ctx->tlas_built) return rthip_fail(ctx, RTHIP_E_INVALID, "no TLAS has been built");
+        src = ctx->tlas_nodes.p;
+        n = ctx->n_inst ? 2 * (uint64_t)ctx->n_inst - 1 : 0;
+    } else {
+        if (!ctx->blas_committed || (size_t)which >= ctx->meshes.size())
+            return rthip_fail(ctx, RTHIP_E_INVALID, "blas_id %d is not built", which);
+        const DevMesh& m = ctx->meshes[which].dev;
+        src = (const float4*)ctx->blas_nodes.p + 2 * (size_t)m.node_base;
+        n = m.n_nodes;
+    }
+    if (out_count) *out_count = n;
+    if (out_nodes && n) {
+        RT_HIP(ctx, hipDeviceSynchronize());
+        RT_HIP(ctx, hipMemcpy(out_nodes, src, n * 32, hipMemcpyDeviceToHost));
+    }
+    return RTHIP_OK;
+}
+
+}  // extern "C"

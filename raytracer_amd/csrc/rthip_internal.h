@@ -1,0 +1,173 @@
+// Internal declarations shared by the translation units of librthip.so.
+// gfx950 (MI355X) only: wave = 64 lanes, no other target is considered.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "rthip.h"
+
+// ---------------------------------------------------------------------------
+// device memory that grows on demand and is reused between calls
+// ---------------------------------------------------------------------------
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+// ---------------------------------------------------------------------------
+// LBVH builder workspace (lbvh_build.hip)
+// ---------------------------------------------------------------------------
+struct ChildInfo;  // 32-byte record a child leaves for its parent
+
+struct LbvhWorkspace {
+    DevBuf aabb;        // float[6n]   primitive boxes (when the builder owns them)
+    DevBuf keys[2];     // uint64[n]   Morton codes, ping-pong
+    DevBuf vals[2];     // uint32[n]   0-based primitive index, ping-pong
+    DevBuf block_hist;  // uint32[256 * tiles] per-tile digit counts, digit-major
+    DevBuf scan_tmp;    // uint32[...] block sums of the device-wide scans
+    DevBuf prio;        // uint8[n-1]  split priority of every gap
+    DevBuf child;       // ChildInfo[2(n-1)]
+    DevBuf flags;       // uint32[n-1] arrival counters
+    DevBuf cnt_l;       // uint32[n]   left-spine lengths, then their inclusive scan
+    DevBuf bounds;      // uint32[6]   ordered-int centroid bounds
+};
+
+// One LBVH in HBM, pre-order, 2 x float4 per node:
+//   lo = {min.x, min.y, min.z, bits(skip)}   hi = {max.x, max.y, max.z, bits(id)}
+struct DevTree {
+    float4* nodes = nullptr;
+    uint32_t n_nodes = 0;
+};
+
+// Per-mesh data the traversal kernels read.
+struct DevMesh {
+    uint32_t node_base;  // first node of this BLAS in the shared node array (in nodes, not float4s)
+    uint32_t n_nodes;
+    uint32_t tri_base;   // first triangle of this mesh in the shared triangle arrays
+    uint32_t n_tris;
+    uint32_t has_normals;
+};
+
+// Per-instance record, 96 bytes, read when a TLAS leaf is entered.
+struct DevInstance {
+    uint32_t type;
+    int32_t material;
+    uint32_t node_base;
+    uint32_t n_nodes;
+    uint32_t tri_base;
+    uint32_t has_normals;
+    float sphere_radius;
+    float pad0;
+    float sphere_center[4];
+    float translation[4];
+    float rotation[4];
+    float scale[4];
+};
+
+struct DevScene {
+    const float4* tlas;       // TLAS nodes
+    uint32_t n_tlas;          // node count (0: empty world)
+    const float4* blas;       // all BLAS nodes, mesh after mesh
+    const float4* tri_v;      // 3 x float4 per triangle: v0, v1, v2 (w unused), mesh after mesh
+    const float4* tri_n;      // 3 x float4 per triangle: n0, n1, n2 (meshes without normals: unused)
+    const DevInstance* inst;  // by TLAS id - 1
+    const rthip_material* mats;
+    uint32_t n_inst;
+    uint32_t n_mats;
+    uint32_t max_bounces;
+    uint32_t sky;
+};
+
+struct HostMesh {
+    DevBuf interleaved;  // raw copy of the caller's vertex buffer
+    DevBuf indices;      // uint32[index_count] (absent: auto-index)
+    DevBuf px, py, pz;   // SoA positions
+    DevBuf nx, ny, nz;   // SoA normals (optional)
+    uint32_t vertex_count = 0, stride = 0, pos_off = 0, index_count = 0;
+    int32_t nrm_off = -1;
+    uint32_t n_tris = 0;
+    bool present = false;
+    DevMesh dev{};
+};
+
+struct rthip_ctx {
+    int device = 0;
+    std::string err;
+    uint32_t max_bounces = 8;
+    int sky = 1;
+    int counting = 0;
+    int refit_fence = 0;  // 1: use __threadfence() hand-offs in the hierarchy kernel (diagnostic)
+
+    hipStream_t stream = nullptr;  // the context's own stream for host-blocking entry points
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    LbvhWorkspace ws;
+
+    std::vector<HostMesh> meshes;
+    bool blas_committed = false;
+    DevBuf blas_nodes;  // float4[2 * total nodes]
+    DevBuf tri_v;       // float4[3 * total tris]
+    DevBuf tri_n;       // float4[3 * total tris]
+    uint64_t total_blas_nodes = 0, total_tris = 0;
+
+    DevBuf tlas_nodes;  // float4[2 * (2 n_inst - 1)]
+    DevBuf inst;        // DevInstance[n_inst]
+    DevBuf mats;        // rthip_material[n_mats]
+    DevBuf inst_aabb;   // float[6 n_inst]
+    uint32_t n_inst = 0, n_mats = 0;
+    bool tlas_built = false;
+
+    DevBuf counters;  // uint64[4]
+    DevBuf scratch_a, scratch_b, scratch_c, scratch_d, scratch_e;  // staging for host <-> device taps
+    float last_cast_ms = 0.f, last_build_ms = 0.f;
+};
+
+// ---- helpers (rthip_api.hip) -------------------------------------------------
+int rthip_fail(rthip_ctx* ctx, int code, const char* fmt, ...);
+int rthip_reserve(rthip_ctx* ctx, DevBuf& b, size_t bytes);
+void rthip_release(DevBuf& b);
+
+#define RT_HIP(ctx, call)                                                                         \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return rthip_fail((ctx), RTHIP_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                              __FILE__, __LINE__);                                                \
+    } while (0)
+
+#define RT_TRY(expr)              \
+    do {                          \
+        int rc_ = (expr);         \
+        if (rc_ != RTHIP_OK) return rc_; \
+    } while (0)
+
+// ---- LBVH builder (lbvh_build.hip) ---------------------------------------------
+// Builds the pre-order tree of n boxes (d_aabb6: n x 6 floats in HBM) into d_nodes
+// (2n-1 nodes, 2 float4 each).  Enqueues on `stream`; no host synchronisation.
+// When d_codes_unsorted / d_keys_sorted / d_ids_sorted are non-null they receive
+// copies of the intermediate arrays (parity taps).
+int lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, float4* d_nodes, hipStream_t stream,
+                      uint64_t* d_codes_unsorted, uint64_t* d_keys_sorted, uint32_t* d_ids_sorted);
+
+// Triangle boxes (+ gathered per-triangle vertex / normal records) from SoA vertex data.
+int mesh_prepare_device(rthip_ctx* ctx, const float* px, const float* py, const float* pz, const float* nx,
+                        const float* ny, const float* nz, const uint32_t* indices, uint64_t n_tris,
+                        float* d_aabb6, float4* d_tri_v, float4* d_tri_n, hipStream_t stream);
+
+int deinterleave_device(rthip_ctx* ctx, const void* d_interleaved, uint32_t vertex_count, uint32_t stride,
+                        uint32_t off, float* x, float* y, float* z, hipStream_t stream);
+
+int instance_aabbs_device(rthip_ctx* ctx, const DevInstance* d_inst, uint32_t n, const float4* d_blas,
+                          float* d_aabb6, hipStream_t stream);
+
+// ---- tracing (trace.hip) ----------------------------------------------------------
+int trace_rays_launch(rthip_ctx* ctx, const DevScene& scene, const float* d_o, const float* d_d, uint64_t n,
+                      uint32_t* d_hits4, float* d_uv, float* d_normal, uint64_t* d_counters, hipStream_t stream);
+int primary_hits_launch(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_settings& cast, int width, int height,
+                        uint32_t* d_hits4, uint64_t* d_counters, hipStream_t stream);
+int cast_launch(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_settings& cast, uint64_t seed, float* d_rgb,
+                int width, int height, rthip_shard shard, uint64_t* d_counters, hipStream_t stream);

@@ -1,0 +1,67 @@
+"""The C-ABI library: it loads, exports every symbol include/rthip.h declares (and nothing is
+declared twice), and the record layouts used from Python equal the C structs.  No compute calls."""
+import os
+import re
+import subprocess
+
+import numpy as np
+
+from conftest import ROOT
+from raytracer_amd import abi
+
+HEADER = os.path.join(ROOT, "include", "rthip.h")
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rthip_[a-z_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = abi.load()
+    names = declared_functions()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(lib, n), f"librthip.so lacks {n}"
+    assert sorted(n for n, _, _ in abi.SYMBOLS) == names, "abi.SYMBOLS and include/rthip.h disagree"
+    assert lib.rthip_abi_version() == 1
+
+
+def test_struct_layouts_match_the_header(tmp_path):
+    src = tmp_path / "sizes.c"
+    src.write_text(
+        '#include <stdio.h>\n#include <stddef.h>\n#include "rthip.h"\n'
+        "int main(void){printf(\"%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n\", sizeof(rthip_material), sizeof(rthip_instance),"
+        " sizeof(rthip_cast_settings), sizeof(rthip_node), sizeof(rthip_shard), sizeof(rthip_stats),"
+        " offsetof(rthip_instance, rotation), offsetof(rthip_cast_settings, defocus_disk), offsetof(rthip_stats, last_cast_ms));return 0;}\n"
+    )
+    exe = tmp_path / "sizes"
+    subprocess.check_call(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    want = [abi.MATERIAL.itemsize, abi.INSTANCE.itemsize, abi.CAST.itemsize, abi.NODE.itemsize, abi.SHARD.itemsize,
+            abi.STATS.itemsize, abi.INSTANCE.fields["rotation"][1], abi.CAST.fields["defocus_disk"][1],
+            abi.STATS.fields["last_cast_ms"][1]]
+    assert got == want
+
+
+def test_no_cpu_fallback_without_a_gpu():
+    """rthip_create must fail (not fall back) where no gfx950 device exists."""
+    import ctypes as C
+
+    import torch
+
+    if torch.cuda.is_available():
+        return
+    h = C.c_void_p()
+    assert abi.load().rthip_create(C.byref(h), 0) != 0 and not h.value
+
+
+def test_product_does_not_touch_the_oracle():
+    """Nothing under raytracer_amd/ or include/ may reference oracle/ (test infrastructure)."""
+    for base in ("raytracer_amd", "include"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith((".py", ".hip", ".h", ".c", ".cpp")) or f == "Makefile":
+                    text = open(os.path.join(dirpath, f), errors="ignore").read()
+                    assert "oracle" not in text.replace("the host-side\n// checker", ""), f"{dirpath}/{f} mentions the oracle"

@@ -1,0 +1,241 @@
+"""Parity of the HIP path (through the C ABI of librthip.so) with the CPU oracle and with the
+reference's own outputs (tests/golden).  Integer results and float bit patterns must be equal."""
+import glob
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, golden
+from helpers import assert_same_tree, bits
+from raytracer_amd import abi, scenes, tracer as T, world
+
+pytestmark = pytest.mark.gpu
+
+LBVH_SETS = sorted(os.path.basename(p)[5:-4] for p in glob.glob(os.path.join(GOLDEN, "lbvh_*.npz")) if "big" not in p)
+
+
+def check_lbvh(oracle, gpu_tracer, boxes, what):
+    codes, cs, ids, nodes, ms = T.lbvh_build(gpu_tracer, boxes)
+    ocodes, ocs, oids, onodes = oracle.lbvh_build(boxes)
+    assert (codes == ocodes).all(), f"{what}: Morton codes"
+    assert (cs == ocs).all(), f"{what}: sorted codes"
+    assert (ids == oids).all(), f"{what}: sorted ids"
+    assert_same_tree(nodes, onodes, what)
+    return codes, nodes
+
+
+@pytest.mark.parametrize("name", LBVH_SETS)
+def test_lbvh_golden_sets(oracle, gpu_tracer, name):
+    g = golden("lbvh_" + name)
+    codes, nodes = check_lbvh(oracle, gpu_tracer, g["aabbs"], name)
+    assert (codes == g["ref_codes"]).all(), "Morton codes differ from the reference"
+    if codes.size <= 28 or np.unique(codes).size == codes.size:
+        assert oracle.dump_bytes(nodes) == g["ref_dump"].tobytes(), "tree dump differs from the reference's"
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 63, 64, 65, 255, 256, 257, 4095, 4096, 4097, 8193, 50_000])
+def test_lbvh_sizes(oracle, gpu_tracer, n):
+    rng = np.random.default_rng(n)
+    cen = rng.random((n, 3)).astype(np.float32)
+    half = (rng.random((n, 3)) * 0.01).astype(np.float32)
+    check_lbvh(oracle, gpu_tracer, np.concatenate([cen - half, cen + half], axis=1), f"n={n}")
+
+
+def test_lbvh_duplicate_heavy_large(oracle, gpu_tracer):
+    rng = np.random.default_rng(3)
+    n = 200_000
+    cen = rng.integers(0, 12, (n, 3)).astype(np.float32)  # <= 1728 distinct centroids: long runs
+    half = (rng.random((n, 3)) * 0.3).astype(np.float32)
+    check_lbvh(oracle, gpu_tracer, np.concatenate([cen - half, cen + half], axis=1), "duplicate-heavy")
+    same = np.tile(np.array([[1, 2, 3, 4, 5, 6]], dtype=np.float32), (5000, 1))
+    check_lbvh(oracle, gpu_tracer, same, "all-identical")
+
+
+def test_lbvh_one_million_digest(oracle, gpu_tracer):
+    g = golden("lbvh_big_digests")
+    rng = np.random.default_rng(7)
+    for n in (100_000, 1_000_000):
+        cen = rng.random((n, 3)).astype(np.float32)
+        half = (rng.random((n, 3)) * 0.001).astype(np.float32)
+        boxes = np.concatenate([cen - half, cen + half], axis=1).astype(np.float32)
+        codes, cs, ids, nodes, ms = T.lbvh_build(gpu_tracer, boxes)
+        assert hashlib.sha256(codes.tobytes()).hexdigest() == str(g[f"n{n}_codes"])
+        assert hashlib.sha256(ids.tobytes()).hexdigest() == str(g[f"n{n}_ids"])
+        assert hashlib.sha256(oracle.dump_bytes(nodes)).hexdigest() == str(g[f"n{n}_dump"]), "tree differs from the reference's"
+
+
+def test_lbvh_is_deterministic(gpu_tracer):
+    rng = np.random.default_rng(11)
+    n = 300_000
+    cen = rng.random((n, 3)).astype(np.float32)
+    boxes = np.concatenate([cen - 0.001, cen + 0.001], axis=1).astype(np.float32)
+    a = T.lbvh_build(gpu_tracer, boxes)[3]
+    for _ in range(3):
+        b = T.lbvh_build(gpu_tracer, boxes)[3]
+        assert a.tobytes() == b.tobytes()
+
+
+DEMOS = {"cornell": scenes.cornell, "tri": scenes.tri, "spheres": scenes.spheres}
+
+
+def build(gpu_tracer, w, bounces, sky):
+    gpu_tracer.check(gpu_tracer.lib.rthip_set_tracer(gpu_tracer.h, bounces, 1 if sky else 0), "set_tracer")
+    T.rt_tracer_build_blas(gpu_tracer, w)
+    T.rt_tracer_build_tlas(gpu_tracer, w)
+
+
+@pytest.mark.parametrize("name", sorted(DEMOS))
+def test_demo_scene(oracle, gpu_tracer, name):
+    g = golden("demo_" + name)
+    w, cam, sky = DEMOS[name]()
+    build(gpu_tracer, w, 8, sky)
+    flat = world.flatten_world(w)
+    sc = oracle.Scene(flat, 8, sky)
+    assert_same_tree(T.get_tree(gpu_tracer, -1), sc.tree(-1), name + " TLAS")
+    assert oracle.dump_bytes(T.get_tree(gpu_tracer, -1)) == g["ref_tlas_dump"].tobytes()
+    for k in range(len(flat.meshes)):
+        assert_same_tree(T.get_tree(gpu_tracer, k), sc.tree(k), f"{name} BLAS {k}")
+    # the reference's own answers for the pixel-centre rays
+    cast = cam(64, 64, 1)
+    inst, tri, t, uv, nrm = T.trace_rays(gpu_tracer, g["rays_o"], g["rays_d"])
+    assert (inst == g["ref_inst"]).all() and (tri == g["ref_tri"]).all() and (bits(t) == bits(g["ref_t"])).all()
+    oi, ot, ott, ouv, onrm, _ = sc.trace(g["rays_o"], g["rays_d"])
+    assert (bits(uv) == bits(ouv)).all() and (bits(nrm) == bits(onrm)).all()
+    if name != "spheres":  # the spheres camera has defocus, which primary_hits leaves out like the fixture does
+        pi, pt, ptt = T.primary_hits(gpu_tracer, cast, 64, 64)
+        assert (pi == g["ref_inst"]).all() and (pt == g["ref_tri"]).all() and (bits(ptt) == bits(g["ref_t"])).all()
+    # full path tracing: bit-exact against the oracle in counter-RNG mode
+    for (wd, ht, smp, seed) in ((64, 64, 1, 1), (48, 40, 2, 9), (33, 17, 3, 2)):
+        c = cam(wd, ht, smp)
+        img = np.zeros((ht, wd, 3), dtype=np.float32)
+        T.rt_tracer_cast(gpu_tracer, c, img, wd, ht, seed=seed)
+        want, _ = sc.cast(c, seed, wd, ht, rng_mode=oracle.RNG_COUNTER, threads=8)
+        bad = np.nonzero((bits(img) != bits(want)).any(axis=2))
+        assert bad[0].size == 0, f"{name} {wd}x{ht} s{smp}: {bad[0].size} pixels differ, first {bad[0][:4]},{bad[1][:4]}"
+
+
+def test_cornell_512_primary_hits_match_reference(gpu_tracer):
+    g = golden("demo_cornell")
+    w, cam, sky = scenes.cornell()
+    build(gpu_tracer, w, 8, sky)
+    inst, tri, t = T.primary_hits(gpu_tracer, cam(512, 512, 1), 512, 512)
+    assert int((inst > 0).sum()) == int(g["ref_512_hits"])
+    assert hashlib.sha256(inst.tobytes()).hexdigest() == str(g["ref_512_inst_sha"])
+    assert hashlib.sha256(tri.tobytes()).hexdigest() == str(g["ref_512_tri_sha"])
+    assert hashlib.sha256(t.tobytes()).hexdigest() == str(g["ref_512_t_sha"])
+
+
+def test_cornell_radiance_within_reference_noise(gpu_tracer):
+    g = golden("demo_cornell")
+    w, cam, sky = scenes.cornell()
+    build(gpu_tracer, w, 8, sky)
+    img = np.zeros((64, 64, 3), dtype=np.float32)
+    T.rt_tracer_cast(gpu_tracer, cam(64, 64, 8), img, 64, 64, seed=1)
+    a, b = g["ref_rgb_64_s8_seed1"], g["ref_rgb_64_s8_seed2"]
+    rmse = lambda x, y: float(np.sqrt(np.mean((x.astype(np.float64) - y) ** 2)))
+    # tolerance: the reference's own seed-to-seed RMSE at equal spp, times 1.25; mean luminance within 1 %
+    # (plus the reference's own seed-to-seed luminance spread)
+    assert rmse(img, a) <= 1.25 * rmse(a, b)
+    lum = lambda x: float(x.astype(np.float64).mean())
+    assert abs(lum(img) - lum(a)) <= 0.01 * lum(a) + 2.0 * abs(lum(a) - lum(b))
+
+
+def test_bunny_class_scene(oracle, gpu_tracer):
+    g = golden("demo_bunny_class")
+    verts, indices = scenes.bunny_class_mesh()
+    w, cam, sky = scenes.bunny(verts, indices)
+    build(gpu_tracer, w, 2, sky)
+    assert hashlib.sha256(oracle.dump_bytes(T.get_tree(gpu_tracer, 0))).hexdigest() == str(g["ref_blas_dump_sha"])
+    cast = cam(160, 90, 1)
+    o, d = oracle.primary_rays(cast, 160, 90)
+    inst, tri, t, uv, nrm = T.trace_rays(gpu_tracer, o, d)
+    assert (inst == g["ref_inst"]).all() and (tri == g["ref_tri"]).all() and (bits(t) == bits(g["ref_t"])).all()
+    assert (bits(uv) == bits(g["ref_uv"])).all() and (bits(nrm) == bits(g["ref_normal"])).all()
+    inst, tri, t = T.primary_hits(gpu_tracer, cam(1920, 1080, 1), 1920, 1080)
+    assert int((inst > 0).sum()) == int(g["ref_1080_hits"])
+    assert hashlib.sha256(inst.tobytes()).hexdigest() == str(g["ref_1080_inst_sha"])
+    assert hashlib.sha256(tri.tobytes()).hexdigest() == str(g["ref_1080_tri_sha"])
+    assert hashlib.sha256(t.tobytes()).hexdigest() == str(g["ref_1080_t_sha"])
+    sc = oracle.Scene(world.flatten_world(w), 2, sky)
+    c = cam(96, 54, 2)
+    img = np.zeros((54, 96, 3), dtype=np.float32)
+    T.rt_tracer_cast(gpu_tracer, c, img, 96, 54, seed=5)
+    want, _ = sc.cast(c, 5, 96, 54, rng_mode=oracle.RNG_COUNTER, threads=8)
+    assert (bits(img) == bits(want)).all()
+
+
+def test_instanced_scene_and_counters(oracle, gpu_tracer):
+    verts, indices = scenes.bunny_class_mesh(3)  # 1280 triangles
+    w, cam, sky = scenes.instanced_grid(12, seed=1, verts=verts, indices=indices)
+    build(gpu_tracer, w, 4, sky)
+    flat = world.flatten_world(w)
+    sc = oracle.Scene(flat, 4, sky)
+    assert_same_tree(T.get_tree(gpu_tracer, -1), sc.tree(-1), "instanced TLAS")
+    o, d = scenes.random_rays(20_000, seed=2, lo=(-15, -2, -15), hi=(15, 3, 15))
+    T.set_counting(gpu_tracer, True)
+    T.get_stats(gpu_tracer)
+    inst, tri, t, uv, nrm = T.trace_rays(gpu_tracer, o, d)
+    st = T.get_stats(gpu_tracer)
+    T.set_counting(gpu_tracer, False)
+    oi, ot, ott, ouv, onrm, cnt = sc.trace(o, d, threads=8)
+    assert (inst == oi).all() and (tri == ot).all() and (bits(t) == bits(ott)).all()
+    assert (bits(uv) == bits(ouv)).all() and (bits(nrm) == bits(onrm)).all()
+    assert int((inst > 0).sum()) > 1000
+    for k in ("rays", "nodes_tested", "tris_tested", "inst_entered"):
+        assert st[k] == cnt[k], f"traversal counter {k}: {st[k]} vs {cnt[k]}"
+    c = cam(80, 45, 2)
+    img = np.zeros((45, 80, 3), dtype=np.float32)
+    T.rt_tracer_cast(gpu_tracer, c, img, 80, 45, seed=4)
+    want, _ = sc.cast(c, 4, 80, 45, rng_mode=oracle.RNG_COUNTER, threads=8)
+    assert (bits(img) == bits(want)).all()
+
+
+def test_shards_sum_to_the_frame(oracle, gpu_tracer):
+    import ctypes as C
+
+    import torch
+
+    w, cam, sky = scenes.cornell()
+    build(gpu_tracer, w, 8, sky)
+    wd, ht, smp = 160, 130, 2
+    c = cam(wd, ht, smp)
+    full = np.zeros((ht, wd, 3), dtype=np.float32)
+    T.rt_tracer_cast(gpu_tracer, c, full, wd, ht, seed=3)
+    for mode, world_size in ((1, 4), (2, 3)):
+        parts = []
+        for rank in range(world_size):
+            buf = torch.zeros((ht, wd, 3), dtype=torch.float32, device="cuda:0")
+            sh = np.zeros(1, dtype=abi.SHARD)
+            sh[0] = (mode, rank, world_size)
+            rc = gpu_tracer.lib.rthip_cast_device(gpu_tracer.h, abi.ptr(c), 3, buf.data_ptr(), wd, ht, abi.ptr(sh),
+                                                  torch.cuda.current_stream().cuda_stream)
+            gpu_tracer.check(rc, "rthip_cast_device")
+            torch.cuda.synchronize()
+            parts.append(buf.cpu().numpy())
+            want, _ = oracle.Scene(world.flatten_world(w), 8, sky).cast(c, 3, wd, ht, rng_mode=oracle.RNG_COUNTER,
+                                                                       shard=(mode, rank, world_size), threads=8)
+            assert (bits(parts[-1]) == bits(want)).all(), f"shard mode {mode} rank {rank}"
+        total = np.sum(np.stack(parts), axis=0, dtype=np.float32)
+        if mode == 1:
+            assert (bits(total + np.float32(0)) == bits(full + np.float32(0))).all(), "tiles do not add up to the frame"
+        else:
+            total = total * np.float32(1.0 / (smp * smp))
+            assert np.allclose(total, full, rtol=1e-5, atol=1e-6)
+
+
+def test_errors_are_reported(gpu_tracer):
+    lib = gpu_tracer.lib
+    assert lib.rthip_set_tracer(gpu_tracer.h, 64, 1) == 4  # RTHIP_E_LIMIT, max_bounces < 64
+    assert b"max_bounces" in lib.rthip_last_error(gpu_tracer.h)
+    assert lib.rthip_blas_begin(gpu_tracer.h, 1) == 0
+    v = np.zeros((3, 4), dtype=np.float32)
+    bad_idx = np.array([0, 1, 7], dtype=np.uint32)
+    assert lib.rthip_blas_add_mesh(gpu_tracer.h, 0, abi.ptr(v), 3, 16, 0, -1, abi.ptr(bad_idx), 3) == 1
+    assert lib.rthip_blas_add_mesh(gpu_tracer.h, 5, abi.ptr(v), 3, 16, 0, -1, None, 0) == 1
+    assert lib.rthip_blas_commit(gpu_tracer.h) == 1  # mesh 0 never added
+    assert lib.rthip_tlas_build(gpu_tracer.h, None, 0, None, 0) == 1  # before a committed BLAS set
+    img = np.zeros((4, 4, 3), dtype=np.float32)
+    c = scenes.get_rt_cast_settings(4, 4, 1, (0, 0, 1), (0, 0, 0))
+    assert lib.rthip_cast(gpu_tracer.h, abi.ptr(c), 0, abi.ptr(img), 4, 4) == 1  # no TLAS

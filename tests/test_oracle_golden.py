@@ -1,0 +1,128 @@
+"""The CPU oracle against outputs of the reference itself (tests/golden, written by
+oracle/make_golden.py from oracle/_ref).  Bit-exact everywhere the reference is deterministic."""
+import glob
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, golden
+from helpers import assert_same_tree, assert_same_tree_modulo_runs, bits
+from raytracer_amd import scenes, world
+
+LBVH_SETS = sorted(os.path.basename(p)[5:-4] for p in glob.glob(os.path.join(GOLDEN, "lbvh_*.npz")) if "big" not in p)
+
+
+@pytest.mark.parametrize("name", LBVH_SETS)
+def test_lbvh_matches_reference(oracle, name):
+    g = golden("lbvh_" + name)
+    codes, codes_sorted, ids, nodes = oracle.lbvh_build(g["aabbs"])
+    assert (codes == g["ref_codes"]).all(), "Morton codes differ from the reference"
+    assert (np.sort(g["ref_codes"]) == codes_sorted).all()
+    want = oracle.parse_dump(g["ref_dump"].tobytes())
+    if codes.size <= 28 or np.unique(codes).size == codes.size:
+        # no duplicate codes (or a set the reference sorts stably): byte-identical dump
+        assert oracle.dump_bytes(nodes) == g["ref_dump"].tobytes()
+        assert (ids == g["ref_ids_tree_order"]).all()
+        assert_same_tree(nodes, want, name)
+    else:
+        assert_same_tree_modulo_runs(nodes, want, codes_sorted, name)
+
+
+def test_lbvh_big_digests(oracle):
+    g = golden("lbvh_big_digests")
+    rng = np.random.default_rng(7)
+    for n in (100_000, 1_000_000):
+        cen = rng.random((n, 3)).astype(np.float32)
+        half = (rng.random((n, 3)) * 0.001).astype(np.float32)
+        boxes = np.concatenate([cen - half, cen + half], axis=1).astype(np.float32)
+        assert hashlib.sha256(boxes.tobytes()).hexdigest() == str(g[f"n{n}_aabbs"]), "input generator drifted"
+        if n > 100_000:
+            continue  # the 1M case is covered on the GPU side; keep the CPU suite short
+        codes, cs, ids, nodes = oracle.lbvh_build(boxes)
+        assert int(str(g[f"n{n}_unique_codes"])) == n, "fixture was meant to be duplicate-free"
+        assert hashlib.sha256(codes.tobytes()).hexdigest() == str(g[f"n{n}_codes"])
+        assert hashlib.sha256(ids.tobytes()).hexdigest() == str(g[f"n{n}_ids"])
+        assert hashlib.sha256(oracle.dump_bytes(nodes)).hexdigest() == str(g[f"n{n}_dump"])
+
+
+DEMOS = {"cornell": scenes.cornell, "tri": scenes.tri, "spheres": scenes.spheres}
+
+
+@pytest.mark.parametrize("name", sorted(DEMOS))
+def test_demo_scene_matches_reference(oracle, name):
+    g = golden("demo_" + name)
+    w, cam, sky = DEMOS[name]()
+    flat = world.flatten_world(w)
+    cast = cam(64, 64, 1)
+    assert cast.tobytes() == g["ref_cast"].tobytes(), "camera record differs from get_rt_cast_settings"
+    sc = oracle.Scene(flat, 8, sky)
+    assert oracle.dump_bytes(sc.tree(-1)) == g["ref_tlas_dump"].tobytes(), "TLAS differs from the reference's out.bvh"
+    # camera rays: the oracle's generator vs the reference's own ray dump (debug build)
+    c16 = cam(16, 16, 1)
+    if name == "spheres":
+        pass  # defocus draws random numbers; covered by the radiance comparison below
+    else:
+        o, d = oracle.primary_rays(c16, 16, 16)
+        assert (bits(o) == bits(g["ref_debug_rays_16_o"])).all() and (bits(d) == bits(g["ref_debug_rays_16_d"])).all()
+    inst, tri, t, uv, nrm, _ = sc.trace(g["rays_o"], g["rays_d"])
+    assert (inst == g["ref_inst"]).all() and (tri == g["ref_tri"]).all() and (bits(t) == bits(g["ref_t"])).all()
+    img, _ = sc.cast(cast, 1, 64, 64, rng_mode=oracle.RNG_GLIBC)
+    assert img.tobytes() == g["ref_rgb_s1_seed1"].tobytes(), "radiance (samples=1, seed 1) is not bit-exact"
+    img, _ = sc.cast(cam(32, 32, 2), 3, 32, 32, rng_mode=oracle.RNG_GLIBC)
+    assert img.tobytes() == g["ref_rgb_32_s2_seed3"].tobytes(), "radiance (samples=2, seed 3) is not bit-exact"
+
+
+def test_cornell_512_primary_hits(oracle):
+    g = golden("demo_cornell")
+    w, cam, sky = scenes.cornell()
+    sc = oracle.Scene(world.flatten_world(w), 8, sky)
+    o, d = oracle.primary_rays(cam(512, 512, 1), 512, 512)
+    inst, tri, t, _, _, _ = sc.trace(o, d, threads=4, want_normal=False)
+    assert int((inst > 0).sum()) == int(g["ref_512_hits"]) == 251920
+    assert hashlib.sha256(inst.tobytes()).hexdigest() == str(g["ref_512_inst_sha"])
+    assert hashlib.sha256(tri.tobytes()).hexdigest() == str(g["ref_512_tri_sha"])
+    assert hashlib.sha256(t.tobytes()).hexdigest() == str(g["ref_512_t_sha"])
+
+
+def test_bunny_class_matches_reference(oracle):
+    g = golden("demo_bunny_class")
+    verts, indices = scenes.bunny_class_mesh()
+    assert hashlib.sha256(verts.tobytes()).hexdigest() == str(g["mesh_verts_sha"]), "stand-in mesh is not reproducible"
+    assert hashlib.sha256(indices.tobytes()).hexdigest() == str(g["mesh_indices_sha"])
+    w, cam, sky = scenes.bunny(verts, indices)
+    sc = oracle.Scene(world.flatten_world(w), 2, sky)
+    assert hashlib.sha256(oracle.dump_bytes(sc.tree(0))).hexdigest() == str(g["ref_blas_dump_sha"])
+    cast = cam(160, 90, 1)
+    assert cast.tobytes() == g["cast_160x90"].tobytes()
+    o, d = oracle.primary_rays(cast, 160, 90)
+    inst, tri, t, uv, nrm, _ = sc.trace(o, d)
+    assert (inst == g["ref_inst"]).all() and (tri == g["ref_tri"]).all() and (bits(t) == bits(g["ref_t"])).all()
+    assert (bits(uv) == bits(g["ref_uv"])).all() and (bits(nrm) == bits(g["ref_normal"])).all()
+    img, _ = sc.cast(cam(96, 54, 2), 5, 96, 54, rng_mode=oracle.RNG_GLIBC)
+    assert img.tobytes() == g["ref_rgb_96x54_s2_b2_seed5"].tobytes()
+
+
+def test_glibc_rand_clone(oracle):
+    import ctypes
+
+    libc = ctypes.CDLL("libc.so.6")
+    for seed in (0, 1, 2, 12345, 2**31 - 1):
+        libc.srand(seed)
+        oracle.lib().ora_srand(seed)
+        for _ in range(1000):
+            assert libc.rand() == oracle.lib().ora_rand()
+
+
+def test_counter_modes_agree_statistically(oracle):
+    """The counter-RNG flavour (what the GPU computes) against the reference's own seed-to-seed noise."""
+    g = golden("demo_cornell")
+    w, cam, sky = scenes.cornell()
+    sc = oracle.Scene(world.flatten_world(w), 8, sky)
+    a, b = g["ref_rgb_64_s8_seed1"], g["ref_rgb_64_s8_seed2"]
+    img, _ = sc.cast(cam(64, 64, 8), 1, 64, 64, rng_mode=oracle.RNG_COUNTER, threads=8)
+    rmse = lambda x, y: float(np.sqrt(np.mean((x.astype(np.float64) - y) ** 2)))
+    assert rmse(img, a) <= 1.25 * rmse(a, b)
+    lum = lambda x: float(x.astype(np.float64).mean())
+    assert abs(lum(img) - lum(a)) <= 0.01 * lum(a) + 2.0 * abs(lum(a) - lum(b))
