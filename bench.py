@@ -1,0 +1,249 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mrays/s of the HIP rendering backend (whole job) + LBVH build time.
+
+    python bench.py [--gpus N --steps K --warmup W --workload bunny|instanced|soup|cornell]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One step = one frame of the workload rendered through rthip_cast_device with everything
+(BVHs, triangles, framebuffer) resident in HBM.  With N > 1 every rank renders the same frame
+with its own sample set (seed + rank) and the framebuffers are summed onto rank 0 with RCCL
+(`torch.distributed.reduce`), i.e. N times the samples in the same wall time: weak scaling.
+A ray is one TLAS closest-hit query (primary and bounce rays alike).
+
+Rank 0 prints ONE JSON line.  `roofline` prices the cast kernel against HBM bandwidth using
+the algorithmic byte model 48 + 32*nodes + 48*triangles + 64*instances per ray, with the
+node / triangle / instance counts taken from the kernel's own traversal counters (a separate,
+untimed launch).  `cpu_baseline` times the CPU reference on the host cores of the same box.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
+
+
+def make_workload(name: str):
+    from raytracer_amd import scenes
+
+    if name == "bunny":
+        verts, idx = scenes.bunny_class_mesh()
+        w, cam, sky = scenes.bunny(verts, idx)
+        return dict(world=w, cam=cam, sky=sky, width=1920, height=1080, samples=1, bounces=2,
+                    label="bunny-class stand-in mesh (81920 triangles, 1 instance), 1920x1080, samples=1, bounces=2, sky on")
+    if name == "instanced":
+        verts, idx = scenes.bunny_class_mesh()
+        w, cam, sky = scenes.instanced_grid(100, seed=1, verts=verts, indices=idx)
+        return dict(world=w, cam=cam, sky=sky, width=1920, height=1080, samples=2, bounces=8,
+                    label="bunny-class mesh x 10000 instances under a TLAS, 1920x1080, samples=2, bounces=8, sky on")
+    if name == "soup":
+        w, cam, sky = scenes.soup_world(10_000_000, seed=1)
+        return dict(world=w, cam=cam, sky=sky, width=1920, height=1080, samples=1, bounces=4,
+                    label="10M-triangle soup (1 BLAS), 1920x1080, samples=1, bounces=4, sky on")
+    if name == "cornell":
+        w, cam, sky = scenes.cornell()
+        return dict(world=w, cam=cam, sky=sky, width=512, height=512, samples=2, bounces=8,
+                    label="Cornell box demo, 512x512, samples=2, bounces=8")
+    raise SystemExit(f"unknown workload {name}")
+
+
+def build_times(tracer, torch, sizes):
+    """LBVH build (triangle boxes -> Morton -> sort -> hierarchy+refit -> pre-order layout) with
+    the vertices already in HBM, timed with events on the launch stream."""
+    from raytracer_amd import abi
+
+    out = {}
+    stream = torch.cuda.current_stream()
+    for n in sizes:
+        g = torch.Generator(device="cuda")
+        g.manual_seed(1)
+        cen = torch.rand((n, 1, 3), device="cuda", generator=g)
+        off = (torch.rand((n, 3, 3), device="cuda", generator=g) * 2 - 1) * 0.001
+        p = (cen + off).reshape(3 * n, 3).float()
+        px, py, pz = (p[:, k].contiguous() for k in range(3))
+        nodes = torch.empty((2 * n - 1, 8), dtype=torch.float32, device="cuda")
+        best = None
+        for it in range(4):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            rc = tracer.lib.rthip_mesh_build_device(tracer.h, px.data_ptr(), py.data_ptr(), pz.data_ptr(), 3 * n, None,
+                                                    n, nodes.data_ptr(), stream.cuda_stream)
+            tracer.check(rc, "rthip_mesh_build_device")
+            e1.record(stream)
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1)
+            if it > 0:
+                best = ms if best is None else min(best, ms)
+        # size-independent validity: pre-order root covers everything, skip of the root == node count
+        root = nodes[0].cpu().numpy().view(np.uint32)
+        assert int(root[3]) == 2 * n - 1 and int(root[7]) == 0, "root record is malformed"
+        out[str(n)] = dict(ms=round(best, 4), ms_per_1M=round(best * 1e6 / n, 4),
+                           hbm_roofline_frac=round((444.0 * n / (best * 1e-3)) / (HBM_PEAK_GBS * 1e9), 4))
+        del cen, off, p, px, py, pz, nodes
+    return out
+
+
+def cpu_baseline(wl, cast, flat, budget_s=20.0):
+    """The CPU path on this box's host cores: the unmodified reference when oracle/_ref travelled
+    with the tree (kind 'reference'), otherwise the repo's CPU restatement (kind 'port')."""
+    from oracle import oracle as O
+
+    W, H = wl["width"], wl["height"]
+    ora = O.Scene(flat, wl["bounces"], wl["sky"])
+    # the oracle in glibc-rand mode reproduces the reference's paths exactly, so its ray count is the reference's
+    t0 = time.time()
+    _, cnt = ora.cast(cast, 1, W, H, rng_mode=O.RNG_GLIBC)
+    port_s = time.time() - t0
+    rays = cnt["rays"]
+    if O.have_ref("core"):
+        rs = O.RefScene(flat, wl["bounces"], wl["sky"])
+        reps, spent, best = 0, 0.0, None
+        while reps < 3 or (spent < budget_s and reps < 10):
+            _, sec = rs.cast(cast, 1, W, H)
+            spent += sec
+            best = sec if best is None else min(best, sec)
+            reps += 1
+            if spent > budget_s:
+                break
+        return dict(value=round(rays / best / 1e6, 3), unit="Mrays/s", cores=1, kind="reference",
+                    sample=f"the full {W}x{H} frame of the same workload, {reps} repeats, best of them; rays counted by the "
+                           "oracle run with the same glibc rand() stream")
+    return dict(value=round(rays / port_s / 1e6, 3), unit="Mrays/s", cores=1, kind="port",
+                sample=f"the full {W}x{H} frame of the same workload, one pass of the CPU restatement")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="bunny")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--build-sizes", default="81920,1000000,10000000")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from raytracer_amd import abi, tracer as T, world as Wd
+
+    wl = make_workload(args.workload)
+    W, H = wl["width"], wl["height"]
+    tr = T.rt_make_tracer(T.RT_TracerSettings(max_bounces=wl["bounces"], sky=wl["sky"]), device_id=local_rank)
+    T.rt_tracer_build_blas(tr, wl["world"])
+    blas_ms = T.get_stats(tr)["last_build_ms"]
+    T.rt_tracer_build_tlas(tr, wl["world"])
+    cast = wl["cam"](W, H, wl["samples"])
+    flat = Wd.flatten_world(wl["world"])
+
+    fb = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream()
+    seed = 1 + rank
+
+    def step():
+        rc = tr.lib.rthip_cast_device(tr.h, abi.ptr(cast), seed, fb.data_ptr(), W, H, None, stream.cuda_stream)
+        tr.check(rc, "rthip_cast_device")
+        if world > 1:
+            dist.reduce(fb, dst=0, op=dist.ReduceOp.SUM)
+
+    # traversal counters of this rank's frame (untimed launch with counting on)
+    T.set_counting(tr, True)
+    T.get_stats(tr)
+    step()
+    torch.cuda.synchronize()
+    st = T.get_stats(tr)
+    T.set_counting(tr, False)
+    rays = st["rays"]
+    algo_bytes = 48 * st["rays"] + 32 * st["nodes_tested"] + 48 * st["tris_tested"] + 64 * st["inst_entered"]
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record(stream)
+        rc = tr.lib.rthip_cast_device(tr.h, abi.ptr(cast), seed, fb.data_ptr(), W, H, None, stream.cuda_stream)
+        ev[k][1].record(stream)
+        tr.check(rc, "rthip_cast_device")
+        if world > 1:
+            dist.reduce(fb, dst=0, op=dist.ReduceOp.SUM)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+    t_all = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    r_all = torch.tensor([float(rays)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
+        dist.all_reduce(r_all, op=dist.ReduceOp.SUM)
+    elapsed = float(t_all.item())
+    total_rays = float(r_all.item())
+
+    if rank == 0:
+        value = total_rays * args.steps / elapsed / 1e6
+        achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+        line = {
+            "metric": "Mrays/sec (whole node); LBVH build ms per 1M triangles",
+            "value": round(value, 2),
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": wl["label"], "rays_per_frame_per_gpu": int(rays), "sharding": "every rank renders the "
+                       "frame with its own sample set; framebuffers summed onto rank 0 with RCCL" if world > 1 else "none"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "kernel": "cast_kernel",
+                         "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": int(algo_bytes),
+                         "per_ray": {"nodes": round(st["nodes_tested"] / max(rays, 1), 2),
+                                     "triangles": round(st["tris_tested"] / max(rays, 1), 3),
+                                     "instances": round(st["inst_entered"] / max(rays, 1), 3)}},
+            "scene_build_ms": {"blas": round(blas_ms, 4)},
+        }
+        if args.build_sizes:
+            line["lbvh_build"] = build_times(tr, torch, [int(s) for s in args.build_sizes.split(",") if s])
+            big = max(line["lbvh_build"], key=lambda k: int(k))
+            line["lbvh_build_ms_per_1M_triangles"] = line["lbvh_build"][big]["ms_per_1M"]
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(wl, cast, flat)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    T.rt_tracer_cleanup(tr)
+
+
+if __name__ == "__main__":
+    main()
