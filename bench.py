@@ -146,7 +146,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
-    from raytracer_amd import abi, tracer as T, world as Wd
+    from raytracer_amd import abi, dist as rdist, tracer as T, world as Wd
 
     wl = make_workload(args.workload)
     W, H = wl["width"], wl["height"]
@@ -164,8 +164,7 @@ def main():
     def step():
         rc = tr.lib.rthip_cast_device(tr.h, abi.ptr(cast), seed, fb.data_ptr(), W, H, None, stream.cuda_stream)
         tr.check(rc, "rthip_cast_device")
-        if world > 1:
-            dist.reduce(fb, dst=0, op=dist.ReduceOp.SUM)
+        rdist.combine_framebuffer(fb, "frames", wl["samples"], world, dst=0)
 
     # traversal counters of this rank's frame (untimed launch with counting on)
     T.set_counting(tr, True)
@@ -189,8 +188,7 @@ def main():
         rc = tr.lib.rthip_cast_device(tr.h, abi.ptr(cast), seed, fb.data_ptr(), W, H, None, stream.cuda_stream)
         ev[k][1].record(stream)
         tr.check(rc, "rthip_cast_device")
-        if world > 1:
-            dist.reduce(fb, dst=0, op=dist.ReduceOp.SUM)
+        rdist.combine_framebuffer(fb, "frames", wl["samples"], world, dst=0)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

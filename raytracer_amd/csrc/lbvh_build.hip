@@ -417,12 +417,31 @@ __global__ __launch_bounds__(kBlock) void gap_priority_kernel(const uint64_t* __
 // ---- K5 + K6: hierarchy emission with box refit ------------------------------------------
 // lbvh_create_subtree, lbvh.c:44-72, bottom-up.  A child publishes its record in its
 // parent's slot and bumps the parent's arrival counter; the second child to arrive
-// reads its sibling's record, merges (merge_rng3_f32(left, right), lbvh.c:58) and walks on.
+// reads its sibling's record, merges (merge_rng3_f32(left, right), lbvh.c:58), records the
+// finished node and walks on.
 //
-// Hand-off between workgroups: the record is written with device-scope (write-through)
-// stores, the wave drains them (s_waitcnt vmcnt(0)) before its counter add, and the
-// sibling is read with device-scope loads only after the add has returned.  FENCE = true
-// replaces that with plain accesses bracketed by __threadfence().
+// A workgroup owns kChunk consecutive sorted leaves.  A gap whose node lies entirely inside
+// the chunk (it is bounded on both sides, inside the chunk, by gaps of smaller priority) is
+// "local": both of its children are produced by this workgroup, so their hand-off goes
+// through LDS.  Only the few nodes on the chunk's two boundary staircases leave the chunk;
+// their hand-off goes through HBM between workgroups: the record is written with
+// device-scope (write-through) stores, the wave drains them (s_waitcnt vmcnt(0)) before its
+// device-scope counter add, and the sibling is read with device-scope loads only after the
+// add has returned.  FENCE = true replaces that with plain accesses bracketed by
+// __threadfence() (diagnostic switch RTHIP_REFIT_FENCE=1).
+constexpr int kChunk = 512;  // sorted leaves per workgroup (2 per thread)
+
+struct alignas(16) NodeInfo {  // a finished inner node, indexed by its gap
+    float box[6];
+    uint32_t l, r;  // leaf range
+};
+struct alignas(16) LeafRec {  // a leaf in sorted order
+    float box[6];
+    uint32_t id;  // 1-based primitive id
+    uint32_t pad;
+};
+static_assert(sizeof(NodeInfo) == 32 && sizeof(LeafRec) == 32, "32-byte records");
+
 template <bool FENCE>
 __device__ __forceinline__ void child_store(ChildRec* slot, const float* box, uint32_t far_end, uint32_t dl) {
     uint64_t w0 = (uint64_t)__float_as_uint(box[0]) | ((uint64_t)__float_as_uint(box[1]) << 32);
@@ -463,82 +482,178 @@ template <bool FENCE>
 __global__ __launch_bounds__(kBlock) void hierarchy_kernel(uint32_t n, const uint8_t* __restrict__ prio,
                                                            const uint32_t* __restrict__ sorted_idx,
                                                            const float* __restrict__ aabb6, ChildRec* child,
-                                                           uint32_t* flags, uint32_t* __restrict__ cnt_l) {
-    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    uint32_t l = i, r = i, dl = 0;
-    float box[6];
-    {
-        const float* b = aabb6 + 6 * (uint64_t)sorted_idx[i];  // node->aabb = in_aabbs[id - 1], lbvh.c:53
-#pragma unroll
-        for (int k = 0; k < 6; k++) box[k] = b[k];
+                                                           uint32_t* flags, uint32_t* __restrict__ cnt_l,
+                                                           NodeInfo* __restrict__ node_info,
+                                                           uint8_t* __restrict__ node_dl,
+                                                           LeafRec* __restrict__ leaf_sorted) {
+    // window of gap priorities: entry k is gap c0 - 1 + k, k = 0 .. kChunk; bit 7 marks a local gap.
+    // Gaps that do not exist (-1, >= n-1) read as 0, below every real priority (>= 1).
+    __shared__ uint8_t win[kChunk + 8];
+    __shared__ uint32_t lflag[kChunk];
+    __shared__ ChildRec lrec[2 * kChunk];
+    __shared__ uint32_t wmin_l[kBlock / 64], wmin_r[kBlock / 64];
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const uint32_t c0 = blockIdx.x * (uint32_t)kChunk;
+
+    for (int k = tid; k <= kChunk; k += kBlock) {
+        int64_t g = (int64_t)c0 - 1 + k;
+        win[k] = (g >= 0 && g + 1 < (int64_t)n) ? prio[g] : (uint8_t)0;
     }
-    for (;;) {
-        if (l == 0 && r == n - 1) {  // the root: top of the left spine that starts at leaf 0
-            cnt_l[0] = dl;
-            break;
+    lflag[tid] = 0;
+    lflag[tid + kBlock] = 0;
+    __syncthreads();
+
+    {   // local[k] <=> win[k] > min(win[0..k-1]) and win[k] > min(win[k+1..kChunk]), k = 1 .. kChunk-1
+        // thread t owns entries 2t and 2t+1 (entry kChunk is folded into the suffix minima)
+        const uint32_t e0 = win[2 * tid], e1 = win[2 * tid + 1];
+        const uint32_t m = e0 < e1 ? e0 : e1;
+        uint32_t pre = m, suf = m;  // inclusive over threads
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            uint32_t a = __shfl_up(pre, o), b = __shfl_down(suf, o);
+            if (lane >= o) pre = a < pre ? a : pre;
+            if (lane + o < 64) suf = b < suf ? b : suf;
         }
-        // of the two gaps that bound [l, r] the parent is the one with the larger priority
-        bool parent_right = (l == 0) || (r != n - 1 && prio[r] > prio[l - 1]);
-        uint32_t parent = parent_right ? r : l - 1;
-        uint32_t side = parent_right ? 0u : 1u;  // 0: this node is the LEFT child
-        if (side == 1) cnt_l[l] = dl;            // a right child tops the left spine that starts at l
-        child_store<FENCE>(&child[2 * (uint64_t)parent + side], box, parent_right ? l : r, dl);
-        if (FENCE) __threadfence();
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        uint32_t old = atomicAdd(&flags[parent], 1u);
-        if (old == 0) break;  // first to arrive: the sibling's subtree carries on from here
-        if (FENCE) __threadfence();
-        float sbox[6];
-        uint32_t s_far, s_dl;
-        child_load<FENCE>(&child[2 * (uint64_t)parent + (1u - side)], sbox, &s_far, &s_dl);
-        if (side == 0) {  // sibling is the right child
+        if (lane == 63) wmin_l[wave] = pre;
+        if (lane == 0) wmin_r[wave] = suf;
+        __syncthreads();
+        uint32_t before = 0xffu, after = win[kChunk];  // minima over the threads before / after this one
+        for (int w = 0; w < kBlock / 64; w++) {
+            if (w < wave) before = wmin_l[w] < before ? wmin_l[w] : before;
+            if (w > wave) after = wmin_r[w] < after ? wmin_r[w] : after;
+        }
+        uint32_t pl = __shfl_up(pre, 1), sr = __shfl_down(suf, 1);
+        if (lane > 0) before = pl < before ? pl : before;
+        if (lane < 63) after = sr < after ? sr : after;
+        // entry 2t: left = before, right = min(e1, after); entry 2t+1: left = min(before, e0), right = after
+        const uint32_t r0 = e1 < after ? e1 : after, l1 = before < e0 ? before : e0;
+        const bool loc0 = (2 * tid >= 1) && e0 > before && e0 > r0;
+        const bool loc1 = e1 > l1 && e1 > after;
+        __syncthreads();
+        win[2 * tid] = (uint8_t)(e0 | (loc0 ? 0x80u : 0u));
+        win[2 * tid + 1] = (uint8_t)(e1 | (loc1 ? 0x80u : 0u));
+    }
+    __syncthreads();
+
+    for (int half = 0; half < 2; half++) {
+        const uint32_t i = c0 + (uint32_t)half * kBlock + (uint32_t)tid;
+        if (i >= n) continue;
+        uint32_t l = i, r = i, dl = 0;
+        float box[6];
+        {
+            const uint32_t prim = sorted_idx[i];
+            const float* b = aabb6 + 6 * (uint64_t)prim;  // node->aabb = in_aabbs[id - 1], lbvh.c:53
 #pragma unroll
-            for (int k = 0; k < 3; k++) {
-                box[k] = ref_min(box[k], sbox[k]);
-                box[k + 3] = ref_max(box[k + 3], sbox[k + 3]);
-            }
-            r = s_far;
-            dl = dl + 1;
-        } else {  // sibling is the left child
+            for (int k = 0; k < 6; k++) box[k] = b[k];
+            LeafRec lr;
 #pragma unroll
-            for (int k = 0; k < 3; k++) {
-                box[k] = ref_min(sbox[k], box[k]);
-                box[k + 3] = ref_max(sbox[k + 3], box[k + 3]);
+            for (int k = 0; k < 6; k++) lr.box[k] = box[k];
+            lr.id = prim + 1;  // id = idx + 1, lbvh.c:116
+            lr.pad = 0;
+            leaf_sorted[i] = lr;
+        }
+        for (;;) {
+            if (l == 0 && r == n - 1) {  // the root: top of the left spine that starts at leaf 0
+                cnt_l[0] = dl;
+                break;
             }
-            l = s_far;
-            dl = s_dl + 1;
+            // priorities of the two gaps that bound [l, r]; the parent is the one with the larger priority
+            uint32_t pr_r = 0, pr_l = 0;
+            if (r != n - 1) {
+                const uint32_t k = r + 1 - c0;  // window index of gap r (unsigned wrap when r + 1 < c0)
+                pr_r = (k <= (uint32_t)kChunk) ? (uint32_t)win[k] : (uint32_t)prio[r];
+            }
+            if (l != 0) {
+                const uint32_t k = l - c0;  // window index of gap l - 1
+                pr_l = (k <= (uint32_t)kChunk) ? (uint32_t)win[k] : (uint32_t)prio[l - 1];
+            }
+            const bool parent_right = (l == 0) || (r != n - 1 && (pr_r & 0x7fu) > (pr_l & 0x7fu));
+            const uint32_t parent = parent_right ? r : l - 1;
+            const uint32_t side = parent_right ? 0u : 1u;  // 0: this node is the LEFT child
+            const bool local = ((parent_right ? pr_r : pr_l) & 0x80u) != 0;
+            if (side == 1) cnt_l[l] = dl;  // a right child tops the left spine that starts at l
+            float sbox[6];
+            uint32_t s_far, s_dl;
+            if (local) {
+                const uint32_t slot = parent - c0;
+                ChildRec mine;
+#pragma unroll
+                for (int k = 0; k < 6; k++) mine.box[k] = box[k];
+                mine.far_end = parent_right ? l : r;
+                mine.dl = dl;
+                lrec[2 * slot + side] = mine;
+                __threadfence_block();
+                const uint32_t old = atomicAdd(&lflag[slot], 1u);
+                if (old == 0) break;
+                __threadfence_block();
+                const ChildRec sib = lrec[2 * slot + (1u - side)];
+#pragma unroll
+                for (int k = 0; k < 6; k++) sbox[k] = sib.box[k];
+                s_far = sib.far_end;
+                s_dl = sib.dl;
+            } else {
+                child_store<FENCE>(&child[2 * (uint64_t)parent + side], box, parent_right ? l : r, dl);
+                if (FENCE) __threadfence();
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const uint32_t old = atomicAdd(&flags[parent], 1u);
+                if (old == 0) break;  // first to arrive: the sibling's subtree carries on from here
+                if (FENCE) __threadfence();
+                child_load<FENCE>(&child[2 * (uint64_t)parent + (1u - side)], sbox, &s_far, &s_dl);
+            }
+            if (side == 0) {  // sibling is the right child
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    box[k] = ref_min(box[k], sbox[k]);
+                    box[k + 3] = ref_max(box[k + 3], sbox[k + 3]);
+                }
+                r = s_far;
+                dl = dl + 1;
+            } else {  // sibling is the left child
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    box[k] = ref_min(sbox[k], box[k]);
+                    box[k + 3] = ref_max(sbox[k + 3], box[k + 3]);
+                }
+                l = s_far;
+                dl = s_dl + 1;
+            }
+            NodeInfo ni;
+#pragma unroll
+            for (int k = 0; k < 6; k++) ni.box[k] = box[k];
+            ni.l = l;
+            ni.r = r;
+            node_info[parent] = ni;
+            node_dl[parent] = (uint8_t)dl;
         }
     }
 }
 
 // ---- K7: pre-order records ------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void emit_kernel(uint32_t n, const uint32_t* __restrict__ sorted_idx,
-                                                      const float* __restrict__ aabb6,
-                                                      const ChildRec* __restrict__ child,
+// Thread t writes leaf t and inner node (gap) t: neighbours in pre-order are written by
+// neighbouring threads, so the 32-byte records combine into full lines on their way to HBM.
+__global__ __launch_bounds__(kBlock) void emit_kernel(uint32_t n, const LeafRec* __restrict__ leaf_sorted,
+                                                      const NodeInfo* __restrict__ node_info,
+                                                      const uint8_t* __restrict__ node_dl,
                                                       const uint32_t* __restrict__ spine_scan,
                                                       float4* __restrict__ nodes) {
-    uint64_t t = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (t < n) {  // leaf t (sorted position)
-        uint32_t i = (uint32_t)t;
-        uint32_t pre = i + spine_scan[i];
-        uint32_t prim = sorted_idx[i];
-        const float* b = aabb6 + 6 * (uint64_t)prim;
-        nodes[2 * (uint64_t)pre] = make_float4(b[0], b[1], b[2], __uint_as_float(pre + 1));
-        nodes[2 * (uint64_t)pre + 1] = make_float4(b[3], b[4], b[5], __uint_as_float(prim + 1));  // id = idx + 1, lbvh.c:116
-        return;
+    const uint64_t t = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= n) return;
+    {
+        const uint32_t i = (uint32_t)t;
+        const uint32_t pre = i + spine_scan[i];
+        const LeafRec lr = leaf_sorted[i];
+        nodes[2 * (uint64_t)pre] = make_float4(lr.box[0], lr.box[1], lr.box[2], __uint_as_float(pre + 1));
+        nodes[2 * (uint64_t)pre + 1] = make_float4(lr.box[3], lr.box[4], lr.box[5], __uint_as_float(lr.id));
     }
-    uint64_t g = t - n;
-    if (g + 1 >= n) return;
-    const ChildRec L = child[2 * g], R = child[2 * g + 1];
-    uint32_t l = L.far_end, r = R.far_end;
-    uint32_t dl = L.dl + 1;
-    uint32_t pre = l + spine_scan[l] - dl;
-    uint32_t size = 2 * (r - l + 1) - 1;
-    nodes[2 * (uint64_t)pre] = make_float4(ref_min(L.box[0], R.box[0]), ref_min(L.box[1], R.box[1]),
-                                           ref_min(L.box[2], R.box[2]), __uint_as_float(pre + size));
-    nodes[2 * (uint64_t)pre + 1] = make_float4(ref_max(L.box[3], R.box[3]), ref_max(L.box[4], R.box[4]),
-                                               ref_max(L.box[5], R.box[5]), __uint_as_float(0u));
+    if (t + 1 < n) {
+        const NodeInfo ni = node_info[t];
+        const uint32_t dl = node_dl[t];
+        const uint32_t pre = ni.l + spine_scan[ni.l] - dl;
+        const uint32_t size = 2 * (ni.r - ni.l + 1) - 1;
+        nodes[2 * (uint64_t)pre] = make_float4(ni.box[0], ni.box[1], ni.box[2], __uint_as_float(pre + size));
+        nodes[2 * (uint64_t)pre + 1] = make_float4(ni.box[3], ni.box[4], ni.box[5], __uint_as_float(0u));
+    }
 }
 
 // ---- K8: world box of every instance, rt_cpu_tlas_node_to_aabb, raytracer_cpu.c:131-147 ------
@@ -666,6 +781,9 @@ int lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, float4* 
     RT_TRY(rthip_reserve(ctx, w.scan_tmp, (scan_tmp_elems(hist_elems) + scan_tmp_elems(n)) * 4));
     RT_TRY(rthip_reserve(ctx, w.prio, n));
     RT_TRY(rthip_reserve(ctx, w.child, 2 * n * sizeof(ChildRec)));
+    RT_TRY(rthip_reserve(ctx, w.node_info, n * sizeof(NodeInfo)));
+    RT_TRY(rthip_reserve(ctx, w.node_dl, n));
+    RT_TRY(rthip_reserve(ctx, w.leaf_sorted, n * sizeof(LeafRec)));
     RT_TRY(rthip_reserve(ctx, w.flags, n * 4));
     RT_TRY(rthip_reserve(ctx, w.cnt_l, n * 4));
     RT_TRY(rthip_reserve(ctx, w.bounds, 64));
@@ -706,18 +824,21 @@ int lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, float4* 
         RT_HIP(ctx, hipGetLastError());
         RT_HIP(ctx, hipMemsetAsync(w.flags.p, 0, (n - 1) * 4, s));
     }
+    const uint32_t chunks = div_up(n, kChunk);
     if (ctx->refit_fence)
-        hierarchy_kernel<true><<<div_up(n, kBlock), kBlock, 0, s>>>(n32, (const uint8_t*)w.prio.p, vals[cur], d_aabb6,
-                                                                    (ChildRec*)w.child.p, (uint32_t*)w.flags.p,
-                                                                    (uint32_t*)w.cnt_l.p);
+        hierarchy_kernel<true><<<chunks, kBlock, 0, s>>>(n32, (const uint8_t*)w.prio.p, vals[cur], d_aabb6,
+                                                         (ChildRec*)w.child.p, (uint32_t*)w.flags.p, (uint32_t*)w.cnt_l.p,
+                                                         (NodeInfo*)w.node_info.p, (uint8_t*)w.node_dl.p,
+                                                         (LeafRec*)w.leaf_sorted.p);
     else
-        hierarchy_kernel<false><<<div_up(n, kBlock), kBlock, 0, s>>>(n32, (const uint8_t*)w.prio.p, vals[cur], d_aabb6,
-                                                                     (ChildRec*)w.child.p, (uint32_t*)w.flags.p,
-                                                                     (uint32_t*)w.cnt_l.p);
+        hierarchy_kernel<false><<<chunks, kBlock, 0, s>>>(n32, (const uint8_t*)w.prio.p, vals[cur], d_aabb6,
+                                                          (ChildRec*)w.child.p, (uint32_t*)w.flags.p, (uint32_t*)w.cnt_l.p,
+                                                          (NodeInfo*)w.node_info.p, (uint8_t*)w.node_dl.p,
+                                                          (LeafRec*)w.leaf_sorted.p);
     RT_HIP(ctx, hipGetLastError());
     RT_TRY((scan_u32<true>(ctx, (uint32_t*)w.cnt_l.p, n, scan_tmp + scan_tmp_elems(hist_elems), s)));
-    emit_kernel<<<div_up(2 * n - 1, kBlock), kBlock, 0, s>>>(n32, vals[cur], d_aabb6, (const ChildRec*)w.child.p,
-                                                             (const uint32_t*)w.cnt_l.p, d_nodes);
+    emit_kernel<<<div_up(n, kBlock), kBlock, 0, s>>>(n32, (const LeafRec*)w.leaf_sorted.p, (const NodeInfo*)w.node_info.p,
+                                                    (const uint8_t*)w.node_dl.p, (const uint32_t*)w.cnt_l.p, d_nodes);
     RT_HIP(ctx, hipGetLastError());
     return RTHIP_OK;
 }

@@ -32,6 +32,9 @@ struct LbvhWorkspace {
     DevBuf prio;        // uint8[n-1]  split priority of every gap
     DevBuf child;       // ChildInfo[2(n-1)]
     DevBuf flags;       // uint32[n-1] arrival counters
+    DevBuf node_info;   // NodeInfo[n-1] finished inner nodes by gap
+    DevBuf node_dl;     // uint8[n-1]  left-spine length of every inner node
+    DevBuf leaf_sorted; // LeafRec[n]  leaves in sorted order
     DevBuf cnt_l;       // uint32[n]   left-spine lengths, then their inclusive scan
     DevBuf bounds;      // uint32[6]   ordered-int centroid bounds
 };

@@ -1,0 +1,196 @@
+// HIP backend of the tracer hooks; see raytracer_hip.h.
+//
+// What stays on the host: walking the world's linked lists and copying their records into the
+// arrays rthip_* takes.  Everything else (BLAS/TLAS construction, traversal, shading) runs on
+// the GPU.  The hooks keep the reference's void/handle signatures; a failing rthip_* call is
+// fatal (AssertAlways), because the reference's callers have no error path either.
+
+#include <stdio.h>
+#include <stdlib.h>
+
+internal RT_HIP_Tracer* rt_hip_handle_to_tracer(RT_Handle handle) {
+    return (RT_HIP_Tracer*)handle.v64[0];
+}
+internal RT_Handle rt_hip_tracer_to_handle(RT_HIP_Tracer* tracer) {
+    RT_Handle handle = zero_struct;
+    handle.v64[0] = (u64)tracer;
+    return handle;
+}
+
+static void rt_hip_check(RT_HIP_Tracer* tracer, int rc, const char* what) {
+    if (rc != RTHIP_OK) {
+        fprintf(stderr, "rthip: %s failed (%d): %s\n", what, rc, tracer->ctx ? rthip_last_error(tracer->ctx) : "no context");
+    }
+    AssertAlways(rc == RTHIP_OK);
+}
+
+// rt_make_tracer: one GPU context per tracer.  The device is GPU 0 unless RT_HIP_DEVICE says otherwise.
+//
+// Random numbers: the CPU backend consumes the process-wide rand() stream that the demo seeded with
+// srand(--seed) (src/demos/demos_inc.c:97).  A GPU cannot share that stream, so this backend takes ONE
+// value from it -- here, before the GPU runtime is initialised, because that initialisation draws from
+// rand() itself -- and uses it as the seed of the GPU's counter-based generator: the image depends on
+// --seed and on nothing else.
+rt_hook RT_Handle rt_make_tracer(RT_TracerSettings settings) {
+    Assert(settings.max_bounces < RT_MAX_MAX_BOUNCES);
+    u64 seed = (u64)rand();
+
+    Arena* arena = arena_alloc();
+    RT_HIP_Tracer* tracer = push_array(arena, RT_HIP_Tracer, 1);
+    tracer->arena = arena;
+    tracer->max_bounces = settings.max_bounces;
+    tracer->sky = settings.sky;
+    tracer->seed = seed;
+
+    const char* dev = getenv("RT_HIP_DEVICE");
+    int rc = rthip_create(&tracer->ctx, dev ? atoi(dev) : 0);
+    if (rc != RTHIP_OK) fprintf(stderr, "rthip: no usable MI355X (gfx950) device; this backend has no CPU path\n");
+    AssertAlways(rc == RTHIP_OK);
+    rt_hip_check(tracer, rthip_set_tracer(tracer->ctx, settings.max_bounces, settings.sky ? 1 : 0), "rthip_set_tracer");
+    return rt_hip_tracer_to_handle(tracer);
+}
+
+// rt_tracer_build_blas: meshes in list order; the position in that order becomes RT_Mesh.blas_id,
+// exactly as the CPU backend assigns it.  Vertex and index memory is copied to the GPU during the
+// call and not referenced afterwards.
+rt_hook void rt_tracer_build_blas(RT_Handle handle, RT_World* world) {
+    RT_HIP_Tracer* tracer = rt_hip_handle_to_tracer(handle);
+    RT_MeshList* meshes = &world->meshes;
+
+    u32 count = 0;
+    for EachList(node, RT_MeshNode, meshes->first) count++;
+    rt_hip_check(tracer, rthip_blas_begin(tracer->ctx, count), "rthip_blas_begin");
+
+    u32 idx = 0;
+    for EachList(node, RT_MeshNode, meshes->first) {
+        RT_Mesh* mesh = &node->v;
+        Assert(mesh->primitive == GEO_Primitive_TRI_LIST);
+        u32 stride = (u32)geo_vertex_stride(mesh->attrs, GEO_VertexAttributes_P);
+        u32 pos_off = (u32)geo_vertex_offset(mesh->attrs, GEO_VertexAttributes_P);
+        s32 nrm_off = (mesh->attrs & GEO_VertexAttributes_N) ? (s32)geo_vertex_offset(mesh->attrs, GEO_VertexAttributes_N) : -1;
+        rt_hip_check(tracer,
+                     rthip_blas_add_mesh(tracer->ctx, idx, mesh->vertices, mesh->vertices_count, stride, pos_off, nrm_off,
+                                         mesh->indices, mesh->indices_count),
+                     "rthip_blas_add_mesh");
+        mesh->blas_id = idx;
+        idx++;
+    }
+    rt_hip_check(tracer, rthip_blas_commit(tracer->ctx), "rthip_blas_commit");
+}
+
+// rt_tracer_build_tlas: instances and materials in list order.  Instances refer to materials by the
+// address of the material's list node; those addresses are turned into array indices here.
+rt_hook void rt_tracer_build_tlas(RT_Handle handle, RT_World* world) {
+    RT_HIP_Tracer* tracer = rt_hip_handle_to_tracer(handle);
+
+    {DeferResource(Temp scratch = scratch_begin(NULL, 0), scratch_end(scratch)) {
+        u32 mat_count = 0, inst_count = 0;
+        for EachList(node, RT_MaterialNode, world->materials.first) mat_count++;
+        for EachList(node, RT_InstanceNode, world->instances.first) inst_count++;
+
+        rthip_material* mats = push_array(scratch.arena, rthip_material, mat_count + 1);
+        // open-addressing table: material node address -> index
+        u32 slots = 16;
+        while (slots < 2*(mat_count + 1)) slots *= 2;
+        u64* keys = push_array(scratch.arena, u64, slots);
+        u32* vals = push_array(scratch.arena, u32, slots);
+
+        u32 mi = 0;
+        for EachList(node, RT_MaterialNode, world->materials.first) {
+            const RT_Material* m = &node->v;
+            rthip_material* o = &mats[mi];
+            o->type = (u32)m->type;
+            o->albedo[0] = m->albedo.x;     o->albedo[1] = m->albedo.y;     o->albedo[2] = m->albedo.z;
+            o->emissive[0] = m->emissive.x; o->emissive[1] = m->emissive.y; o->emissive[2] = m->emissive.z;
+            o->roughness = m->roughness;
+            o->ior = m->ior;
+            o->billboard = m->billboard ? 1u : 0u;
+
+            u64 key = (u64)node;
+            u32 slot = (u32)((key >> 4) * 0x9E3779B97F4A7C15ull >> 32) & (slots - 1);
+            while (keys[slot] != 0) slot = (slot + 1) & (slots - 1);
+            keys[slot] = key;
+            vals[slot] = mi;
+            mi++;
+        }
+
+        rthip_instance* insts = push_array(scratch.arena, rthip_instance, inst_count + 1);
+        u32 ii = 0;
+        for EachList(node, RT_InstanceNode, world->instances.first) {
+            const RT_Instance* in = &node->v;
+            rthip_instance* o = &insts[ii];
+            o->type = (u32)in->type;
+            o->material = -1;
+            if (!rt_is_zero_handle(in->material)) {
+                u64 key = in->material.v64[0];
+                u32 slot = (u32)((key >> 4) * 0x9E3779B97F4A7C15ull >> 32) & (slots - 1);
+                while (keys[slot] != 0 && keys[slot] != key) slot = (slot + 1) & (slots - 1);
+                AssertAlways(keys[slot] == key); // a material that is not in this world's list
+                o->material = (s32)vals[slot];
+            }
+            switch (in->type) {
+                case RT_InstanceType_Sphere:{
+                    o->sphere_center[0] = in->sphere.center.x;
+                    o->sphere_center[1] = in->sphere.center.y;
+                    o->sphere_center[2] = in->sphere.center.z;
+                    o->sphere_radius = in->sphere.radius;
+                }break;
+                case RT_InstanceType_Mesh:{
+                    RT_Mesh* mesh = rt_world_resolve_mesh(world, in->mesh.handle);
+                    o->blas_id = (u32)mesh->blas_id;
+                    o->translation[0] = in->mesh.translation.x;
+                    o->translation[1] = in->mesh.translation.y;
+                    o->translation[2] = in->mesh.translation.z;
+                    o->rotation[0] = in->mesh.rotation.x;
+                    o->rotation[1] = in->mesh.rotation.y;
+                    o->rotation[2] = in->mesh.rotation.z;
+                    o->rotation[3] = in->mesh.rotation.w;
+                    o->scale[0] = in->mesh.scale.x;
+                    o->scale[1] = in->mesh.scale.y;
+                    o->scale[2] = in->mesh.scale.z;
+                }break;
+                default: break;
+            }
+            ii++;
+        }
+        rt_hip_check(tracer, rthip_tlas_build(tracer->ctx, insts, inst_count, mats, mat_count), "rthip_tlas_build");
+    }}
+}
+
+rt_hook void rt_tracer_cleanup(RT_Handle handle) {
+    RT_HIP_Tracer* tracer = rt_hip_handle_to_tracer(handle);
+    rthip_destroy(tracer->ctx);
+    arena_release(tracer->arena);
+}
+
+// rt_tracer_cast.  Every cast of a tracer uses the seed taken in rt_make_tracer plus the number of casts
+// made so far.  RT_HIP_DUMP_F32=<path> additionally writes the raw float framebuffer (width*height*3 floats).
+rt_hook void rt_tracer_cast(RT_Handle handle, RT_CastSettings settings, vec3_f32* out_radiance, int width, int height) {
+    RT_HIP_Tracer* tracer = rt_hip_handle_to_tracer(handle);
+
+    rthip_cast_settings c = zero_struct;
+    c.eye[0] = settings.eye.x;           c.eye[1] = settings.eye.y;           c.eye[2] = settings.eye.z;
+    c.up[0] = settings.up.x;             c.up[1] = settings.up.y;             c.up[2] = settings.up.z;
+    c.forward[0] = settings.forward.x;   c.forward[1] = settings.forward.y;   c.forward[2] = settings.forward.z;
+    c.right[0] = settings.right.x;       c.right[1] = settings.right.y;       c.right[2] = settings.right.z;
+    c.viewport[0] = settings.viewport.x; c.viewport[1] = settings.viewport.y; c.viewport[2] = settings.viewport.z;
+    c.samples = settings.samples;
+    c.ior = settings.ior;
+    c.defocus = settings.defocus ? 1u : 0u;
+    c.defocus_disk[0] = settings.defocus_disk.x;
+    c.defocus_disk[1] = settings.defocus_disk.y;
+    c.orthographic = settings.orthographic ? 1u : 0u;
+
+    u64 seed = tracer->seed + tracer->casts;
+    tracer->casts++;
+    rt_hip_check(tracer, rthip_cast(tracer->ctx, &c, seed, &out_radiance[0].v[0], width, height), "rthip_cast");
+
+    const char* dump = getenv("RT_HIP_DUMP_F32");
+    if (dump) {
+        FILE* f = fopen(dump, "wb");
+        if (f) {
+            fwrite(out_radiance, sizeof(vec3_f32), (size_t)width*height, f);
+            fclose(f);
+        }
+    }
+}

@@ -1,0 +1,25 @@
+// HIP (MI355X / gfx950) backend of the raytracer's tracer hooks.
+//
+// This header/source pair is written for the reference's unity build: it is meant to be
+// #included by src/raytracer/raytracer_inc.h / raytracer_inc.c next to the CPU backend
+// (src/raytracer/cpu/raytracer_cpu.{h,c}) and implements the same five `rt_hook` functions
+// (src/raytracer/raytracer_core.h:180-184) by flattening the RT_World lists into plain arrays
+// and calling the C ABI of librthip.so (include/rthip.h).  It relies on the reference's own
+// types and macros (RT_World, Arena, EachList, ...) and therefore only compiles inside the
+// reference's translation unit.
+#pragma once
+
+#include "rthip.h"
+
+typedef struct RT_HIP_Tracer RT_HIP_Tracer;
+struct RT_HIP_Tracer {
+    Arena* arena;
+    rthip_ctx* ctx;
+    u8 max_bounces;
+    bool sky;
+    u64 seed;   // first rand() after the caller's srand(): seeds the GPU generator
+    u64 casts;  // casts made with this tracer
+};
+
+internal RT_HIP_Tracer* rt_hip_handle_to_tracer(RT_Handle handle);
+internal RT_Handle      rt_hip_tracer_to_handle(RT_HIP_Tracer* tracer);

@@ -1,0 +1,75 @@
+"""The N > 1 path on CPU: two gloo ranks, each holding the share of a frame that its GPU would have
+rendered (here: rendered by the oracle with the same shard record), combined with the product's
+`combine_framebuffer`.  Tiles must reproduce the single-rank frame bit for bit."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from raytracer_amd import dist as rdist, scenes, world
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world_size, port, mode, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    from oracle import oracle as O
+
+    w, cam, sky = scenes.cornell()
+    flat = world.flatten_world(w)
+    wd, ht, smp = 96, 80, 2
+    c = cam(wd, ht, smp)
+    sc = O.Scene(flat, 8, sky)
+    sh = rdist.shard_record(mode, rank, world_size)
+    seed = 5 + (rank if mode == "frames" else 0)
+    share, _ = sc.cast(c, seed, wd, ht, rng_mode=O.RNG_COUNTER, shard=tuple(int(x) for x in sh[0]), threads=2)
+    fb = torch.from_numpy(share.copy())
+    rdist.combine_framebuffer(fb, mode, smp, world_size, dst=0)
+    if rank == 0:
+        np.save(os.path.join(out_dir, f"{mode}.npy"), fb.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(mode, tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, mode, str(tmp_path)), nprocs=2, join=True)
+    return np.load(os.path.join(str(tmp_path), f"{mode}.npy"))
+
+
+def _full(seed):
+    from oracle import oracle as O
+
+    w, cam, sky = scenes.cornell()
+    sc = O.Scene(world.flatten_world(w), 8, sky)
+    img, _ = sc.cast(cam(96, 80, 2), seed, 96, 80, rng_mode=O.RNG_COUNTER, threads=4)
+    return img
+
+
+def test_tile_shards_reproduce_the_frame(tmp_path):
+    got = _run("tiles", tmp_path)
+    want = _full(5)
+    assert ((got + np.float32(0)).view(np.uint32) == (want + np.float32(0)).view(np.uint32)).all()
+
+
+def test_sample_shards_sum_to_the_frame(tmp_path):
+    got = _run("samples", tmp_path)
+    want = _full(5)
+    assert np.allclose(got, want, rtol=2e-6, atol=1e-7)
+
+
+def test_frame_replicas_average(tmp_path):
+    got = _run("frames", tmp_path)
+    want = (_full(5).astype(np.float32) + _full(6).astype(np.float32)) * np.float32(0.5)
+    assert np.allclose(got, want, rtol=1e-6, atol=1e-7)
