@@ -227,7 +227,8 @@ def main():
                          "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": int(algo_bytes),
                          "per_ray": {"nodes": round(st["nodes_tested"] / max(rays, 1), 2),
                                      "triangles": round(st["tris_tested"] / max(rays, 1), 3),
-                                     "instances": round(st["inst_entered"] / max(rays, 1), 3)}},
+                                     "instances": round(st["inst_entered"] / max(rays, 1), 3)},
+                         "lane_utilisation": round(st["nodes_tested"] / max(64 * st["wave_steps"], 1), 4)},
             "scene_build_ms": {"blas": round(blas_ms, 4)},
         }
         if args.build_sizes:

@@ -124,6 +124,8 @@ typedef struct rthip_stats {
     uint64_t nodes_tested;  /* BVH nodes whose box was tested (both levels)   */
     uint64_t tris_tested;   /* triangles handed to the triangle test          */
     uint64_t inst_entered;  /* TLAS leaves entered                            */
+    uint64_t wave_steps;    /* traversal-loop iterations summed over waves:
+                               nodes_tested / (64 * wave_steps) = lane utilisation */
     float last_cast_ms;     /* device time of the last cast / trace kernel(s) */
     float last_build_ms;    /* device time of the last LBVH build             */
 } rthip_stats;
@@ -234,6 +236,16 @@ int rthip_trace_rays_device(rthip_ctx* ctx, const float* d_origins, const float*
 int rthip_get_stats(rthip_ctx* ctx, rthip_stats* out);
 /* Turns traversal counting on or off (off by default: counting costs atomics). */
 int rthip_set_counting(rthip_ctx* ctx, int enabled);
+
+/* Which kernel rthip_cast / rthip_cast_device run.  All of them produce the same bits.  No
+ * counterpart in the reference (its renderer is one loop, raytracer_cpu.c:179-242).
+ *   RTHIP_KERNEL_AUTO        static for small scenes, persistent for deep ones (default)
+ *   RTHIP_KERNEL_PERSISTENT  resident waves, lanes take a new path as soon as theirs ends
+ *   RTHIP_KERNEL_STATIC      one pixel per thread
+ *   RTHIP_KERNEL_WAVEFRONT   ray generation, traversal, shading and resolve as separate kernels
+ * The environment variable RTHIP_CAST=auto|persistent|static|wavefront sets the initial value. */
+enum { RTHIP_KERNEL_PERSISTENT = 0, RTHIP_KERNEL_STATIC = 1, RTHIP_KERNEL_WAVEFRONT = 2, RTHIP_KERNEL_AUTO = 3 };
+int rthip_set_cast_kernel(rthip_ctx* ctx, int kernel);
 
 /* TLAS / BLAS tree read-back for dumps in the reference's format
  * (src/lbvh/extra/dump.c): which = -1 for the TLAS, otherwise a blas_id.

@@ -40,11 +40,11 @@ SHARD = np.dtype([("mode", "<u4"), ("rank", "<u4"), ("world", "<u4")], align=Fal
 # rthip_stats
 STATS = np.dtype(
     [("rays", "<u8"), ("nodes_tested", "<u8"), ("tris_tested", "<u8"), ("inst_entered", "<u8"),
-     ("last_cast_ms", "<f4"), ("last_build_ms", "<f4")],
+     ("wave_steps", "<u8"), ("last_cast_ms", "<f4"), ("last_build_ms", "<f4")],
     align=False,
 )
 assert MATERIAL.itemsize == 40 and INSTANCE.itemsize == 68 and CAST.itemsize == 84
-assert NODE.itemsize == 32 and SHARD.itemsize == 12 and STATS.itemsize == 40
+assert NODE.itemsize == 32 and SHARD.itemsize == 12 and STATS.itemsize == 48
 
 MAT_LAMBERTIAN, MAT_DIELECTRIC, MAT_METAL, MAT_NORMAL, MAT_LIGHT = range(5)
 INST_SPHERE, INST_MESH = 0, 1
@@ -72,6 +72,7 @@ SYMBOLS = [
     ("rthip_trace_rays_device", C.c_int, [_P, _P, _P, C.c_uint64, _P, _P]),
     ("rthip_get_stats", C.c_int, [_P, _P]),
     ("rthip_set_counting", C.c_int, [_P, C.c_int]),
+    ("rthip_set_cast_kernel", C.c_int, [_P, C.c_int]),
     ("rthip_get_tree", C.c_int, [_P, C.c_int, _P, _P]),
 ]
 

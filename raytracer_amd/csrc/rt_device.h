@@ -1,0 +1,522 @@
+// Device-side building blocks shared by the rendering kernels (trace.hip, wavefront.hip):
+// binary32 vector helpers in the reference's operation order, the slab / triangle / sphere
+// tests, the resumable two-level BVH walk, hit epilogue, random numbers, camera rays and the
+// per-bounce shading step.
+//
+// Traversal is the reference's: depth-first, always left before right, a leaf's primitive
+// tested after its box, the interval shrinking at every accepted hit (src/lbvh/lbvh.c:127-161).
+// On the pre-order node array that recursion is a linear walk: next = index + 1 to descend,
+// next = skip when a box is missed or a leaf is done.  TLAS and BLAS walks run in ONE loop per
+// lane (a lane switches arrays when it enters or leaves an instance), so lanes of a wave that
+// are in different levels still advance together.
+//
+// Arithmetic is binary32 in the reference's operation order; every file that includes this
+// header must be compiled with -ffp-contract=off (no fused multiply-add) and without fast-math.
+#pragma once
+
+#include "rthip_internal.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr float kEps = 1.1920929E-7f;       // EPSILON_F32, src/common/common_math.h:288
+constexpr float kMaxF = 3.402823466e+38f;   // MAX_F32
+constexpr float kPi = 3.1415926535897932384626433832795028841971693993751058209749445923078164062f;
+constexpr float kSurfaceOffset = 0.001f;    // RT_CPU_SURFACE_OFFSET, raytracer_cpu.c:257
+
+struct V3 {
+    float x, y, z;
+};
+__device__ __forceinline__ V3 mk(float x, float y, float z) { return V3{x, y, z}; }
+__device__ __forceinline__ V3 add(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 sub(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 scale(V3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ V3 mul(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ V3 divv(V3 a, V3 b) { return mk(a.x / b.x, a.y / b.y, a.z / b.z); }
+__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) {  // common_math.c:29
+    return mk(a.y * b.z - a.z * b.y, -(a.x * b.z - a.z * b.x), a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ V3 normalize(V3 a) {  // common_math.c:27-28: three divisions by the length
+    float l = sqrtf(a.x * a.x + a.y * a.y + a.z * a.z);
+    return mk(a.x / l, a.y / l, a.z / l);
+}
+__device__ __forceinline__ V3 rot_quat(V3 p, V3 qv, float qw) {  // common_math.c:91
+    V3 a = scale(p, qw * qw - dot(qv, qv));
+    V3 b = scale(qv, 2.f * dot(qv, p));
+    V3 c = scale(cross(qv, p), 2.f * qw);
+    return add(add(a, b), c);
+}
+__device__ __forceinline__ V3 reflect(V3 i, V3 n) { return sub(i, scale(n, 2.f * dot(i, n))); }  // common_math.c:30
+__device__ __forceinline__ V3 orthogonal(V3 x) {  // common_math.c:37-46
+    float ax = fabsf(x.x), ay = fabsf(x.y), az = fabsf(x.z);
+    float mx = ((ax <= ay) & (ax <= az)) ? 1.f : 0.f;
+    float my = ((ay < ax) & (ay <= az)) ? 1.f : 0.f;
+    float mz = 1.f - mx - my;
+    return cross(x, mk(mx, my, mz));
+}
+__device__ __forceinline__ V3 refract(V3 i, V3 n, float eta) {  // common_math.c:47-53
+    float ndoti = dot(n, i);
+    float k = 1.f - eta * eta * (1.f - ndoti * ndoti);
+    if (k < 0.f) return mk(0.f, 0.f, 0.f);
+    return sub(scale(i, eta), scale(n, eta * ndoti + sqrtf(k)));
+}
+
+struct Hit {
+    uint32_t inst;  // 1-based TLAS id, 0 = miss
+    uint32_t tri;   // index-buffer offset of the triangle ((id-1)*3), meshes only
+    float u, v;
+    float t;        // interval.max after the query
+};
+
+struct Counters {
+    uint32_t nodes, tris, insts;
+    uint32_t wave_steps;  // node steps issued by this lane's wave (counted on one lane per step)
+};
+
+// lbvh_aabb_query_ray, lbvh.c:127-149, with 1/d hoisted (the same correctly rounded
+// quotient every time, so hoisting does not change a bit).  Works on a copy of the
+// interval, as the reference does.
+__device__ __forceinline__ bool slab(float4 lo, float4 hi, V3 o, V3 inv, float tmin, float tmax) {
+    {
+        float t0 = (lo.x - o.x) * inv.x, t1 = (hi.x - o.x) * inv.x;
+        if (t0 < t1) { if (t0 > tmin) tmin = t0; if (t1 < tmax) tmax = t1; }
+        else         { if (t1 > tmin) tmin = t1; if (t0 < tmax) tmax = t0; }
+        if (tmax < tmin) return false;
+    }
+    {
+        float t0 = (lo.y - o.y) * inv.y, t1 = (hi.y - o.y) * inv.y;
+        if (t0 < t1) { if (t0 > tmin) tmin = t0; if (t1 < tmax) tmax = t1; }
+        else         { if (t1 > tmin) tmin = t1; if (t0 < tmax) tmax = t0; }
+        if (tmax < tmin) return false;
+    }
+    {
+        float t0 = (lo.z - o.z) * inv.z, t1 = (hi.z - o.z) * inv.z;
+        if (t0 < t1) { if (t0 > tmin) tmin = t0; if (t1 < tmax) tmax = t1; }
+        else         { if (t1 > tmin) tmin = t1; if (t0 < tmax) tmax = t0; }
+        if (tmax < tmin) return false;
+    }
+    return true;
+}
+
+// geo_intersect_tri, src/geo/geo.c:72-109
+__device__ __forceinline__ bool tri_test(V3 o, V3 d, V3 a, V3 b, V3 c, float tmin, float& tmax, float& u_out,
+                                         float& v_out) {
+    V3 edge1 = sub(b, a);
+    V3 edge2 = sub(c, a);
+    V3 rxe2 = cross(d, edge2);
+    float det = dot(edge1, rxe2);
+    if (det == 0.f) return false;
+    float inv_det = 1.f / det;
+    V3 s = sub(o, a);
+    float u = inv_det * dot(s, rxe2);
+    if ((u < 0.f && fabsf(u) > kEps) || (u > 1.f && fabsf(u - 1.f) > kEps)) return false;
+    V3 sxe1 = cross(s, edge1);
+    float v = inv_det * dot(d, sxe1);
+    if ((v < 0.f && fabsf(v) > kEps) || (u + v > 1.f && fabsf(u + v - 1.f) > kEps)) return false;
+    float t = inv_det * dot(edge2, sxe1);
+    if (!(t >= tmin && t <= tmax)) return false;  // geo_in_interval, geo.c:32-34
+    tmax = t;
+    u_out = u;
+    v_out = v;
+    return true;
+}
+
+// geo_intersect_sphere, geo.c:36-69
+__device__ __forceinline__ bool sphere_test(V3 o, V3 d, V3 center, float radius, float tmin, float& tmax) {
+    V3 omc = sub(o, center);
+    float a = dot(d, d);
+    float half_b = dot(d, omc);
+    float c = dot(omc, omc) - radius * radius;
+    float qtr_d = half_b * half_b - a * c;
+    if (qtr_d < 0.f) return false;
+    float half_sqrt_d = sqrtf(qtr_d);
+    float t = (-half_b - half_sqrt_d) / a;
+    if (!(t >= tmin && t <= tmax)) {
+        t = (-half_b + half_sqrt_d) / a;
+        if (!(t >= tmin && t <= tmax)) return false;
+    }
+    tmax = t;
+    return true;
+}
+
+// rt_cpu_intersect's query, raytracer_cpu.c:402-407: lbvh_query_ray over the TLAS with
+// rt_cpu_tlas_hit -> rt_cpu_intersect_tlas_node (:494-531) -> BLAS query with
+// rt_cpu_blas_node_hit (:459-492).  The walk is kept in a struct so that a lane can be
+// suspended between two steps (the persistent kernel refills idle lanes in between).
+struct Trav {
+    V3 wo, wd, winv;    // world-space ray and 1/d
+    V3 o, d, inv;       // ray of the level being walked (model space inside an instance)
+    float tmax;         // interval.max; interval.min stays EPSILON_F32 (geo_make_pos_interval, geo.c:28-30)
+    uint32_t idx, end;  // next node and node count of the array being walked
+    uint32_t base;      // first float4 of that array inside S.blas (unused in the TLAS)
+    uint32_t resume;    // TLAS index to continue from when the current BLAS walk ends
+    uint32_t cur_inst;  // TLAS id of the instance being walked (0: in the TLAS)
+    uint32_t tri_base;
+    Hit h;
+};
+
+__device__ __forceinline__ void trav_begin(Trav& T, const DevScene& S, V3 o, V3 d) {
+    T.wo = o;
+    T.wd = d;
+    T.winv = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);
+    T.o = o;
+    T.d = d;
+    T.inv = T.winv;
+    T.tmax = kMaxF;
+    T.idx = 0;
+    T.end = S.n_tlas;
+    T.base = 0;
+    T.resume = 0;
+    T.cur_inst = 0;
+    T.tri_base = 0;
+    T.h.inst = 0;
+    T.h.tri = 0;
+    T.h.u = 0.f;
+    T.h.v = 0.f;
+    T.h.t = kMaxF;
+}
+
+// One step of the walk.  Returns true when the query has ended (T.h is final).
+template <bool COUNT>
+__device__ __forceinline__ bool trav_step(Trav& T, const DevScene& S, Counters& cnt) {
+    if (T.idx >= T.end) {
+        if (T.cur_inst == 0) {
+            T.h.t = T.tmax;
+            return true;
+        }
+        // leave the instance: back to the TLAS walk with the world-space ray
+        T.cur_inst = 0;
+        T.idx = T.resume;
+        T.end = S.n_tlas;
+        T.o = T.wo;
+        T.d = T.wd;
+        T.inv = T.winv;
+        return false;
+    }
+    const float4* nodes = (T.cur_inst != 0) ? (S.blas + T.base) : S.tlas;
+    const float4 lo = nodes[2 * (size_t)T.idx], hi = nodes[2 * (size_t)T.idx + 1];
+    if (COUNT) cnt.nodes++;
+    const uint32_t id = __float_as_uint(hi.w);
+    uint32_t skip = __float_as_uint(lo.w);
+    if (skip <= T.idx) skip = T.end;  // a well-formed tree never needs this; it bounds the walk on a corrupt one
+    if (!slab(lo, hi, T.o, T.inv, kEps, T.tmax)) {
+        T.idx = skip;
+        return false;
+    }
+    if (id == 0) {  // inner node: left child is the next record
+        T.idx = T.idx + 1;
+        return false;
+    }
+    if (T.cur_inst != 0) {
+        // BLAS leaf: triangle id (1-based), vertices pre-gathered per triangle
+        const float4* tv = S.tri_v + 3 * (size_t)(T.tri_base + (id - 1));
+        const float4 a = tv[0], b = tv[1], c = tv[2];
+        if (COUNT) cnt.tris++;
+        float u, v;
+        if (tri_test(T.o, T.d, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), kEps, T.tmax, u, v)) {
+            T.h.inst = T.cur_inst;
+            T.h.tri = (id - 1) * 3;  // idx = (id - 1)*3, raytracer_cpu.c:467,479
+            T.h.u = u;
+            T.h.v = v;
+        }
+        T.idx = skip;
+        return false;
+    }
+    // TLAS leaf: enter the instance
+    const DevInstance* it = &S.inst[id - 1];
+    if (COUNT) cnt.insts++;
+    if (it->type == RTHIP_INST_SPHERE) {
+        const float4 cr = *(const float4*)it->sphere_center;
+        if (sphere_test(T.o, T.d, mk(cr.x, cr.y, cr.z), it->sphere_radius, kEps, T.tmax)) {
+            T.h.inst = id;
+            T.h.tri = 0;
+            T.h.u = 0.f;
+            T.h.v = 0.f;
+        }
+        T.idx = skip;
+        return false;
+    }
+    // rt_cpu_inv_transform_ray, raytracer_cpu.c:572-580,607-612; the model-space direction is
+    // not renormalised, so t is shared between the two spaces
+    const float4 tr = *(const float4*)it->translation;
+    const float4 q = *(const float4*)it->rotation;
+    const float4 sc = *(const float4*)it->scale;
+    const V3 qv = mk(-q.x, -q.y, -q.z);  // inv_quat, common_math.c:90
+    const V3 s3 = mk(sc.x, sc.y, sc.z);
+    T.o = divv(rot_quat(sub(T.wo, mk(tr.x, tr.y, tr.z)), qv, q.w), s3);
+    T.d = divv(rot_quat(T.wd, qv, q.w), s3);
+    T.inv = mk(1.f / T.d.x, 1.f / T.d.y, 1.f / T.d.z);
+    T.resume = skip;
+    T.cur_inst = id;
+    T.tri_base = it->tri_base;
+    T.base = 2u * it->node_base;
+    T.idx = 0;
+    T.end = it->n_nodes;
+    return false;
+}
+
+template <bool COUNT>
+__device__ __forceinline__ Hit closest_hit_query(const DevScene& S, V3 wo, V3 wd, Counters& cnt) {
+    Trav T;
+    trav_begin(T, S, wo, wd);
+    for (;;) {
+        if (COUNT) {
+            const uint64_t walking = __ballot(1);
+            if ((int)(threadIdx.x & 63) == __ffsll((long long)walking) - 1) cnt.wave_steps++;
+        }
+        if (trav_step<COUNT>(T, S, cnt)) break;
+    }
+    return T.h;
+}
+
+// epilogue of rt_cpu_intersect, raytracer_cpu.c:411-454: position and shading normal
+__device__ __forceinline__ void finish_hit(const DevScene& S, V3 o, V3 d, const Hit& h, V3& p, V3& n, int& material) {
+    const DevInstance* it = &S.inst[h.inst - 1];
+    p = add(o, scale(d, h.t));
+    material = it->material;
+    if (it->type == RTHIP_INST_SPHERE) {
+        const float4 cr = *(const float4*)it->sphere_center;
+        n = scale(sub(p, mk(cr.x, cr.y, cr.z)), 1.f / it->sphere_radius);
+        return;
+    }
+    const size_t t3 = 3 * (size_t)(it->tri_base + h.tri / 3);
+    V3 tri_n;
+    if (it->has_normals) {
+        // U weights vertex 0 and V vertex 1, as the reference writes it (:441-445)
+        const float4 n0 = S.tri_n[t3], n1 = S.tri_n[t3 + 1], n2 = S.tri_n[t3 + 2];
+        tri_n = add(add(scale(mk(n0.x, n0.y, n0.z), h.u), scale(mk(n1.x, n1.y, n1.z), h.v)),
+                    scale(mk(n2.x, n2.y, n2.z), 1.f - h.u - h.v));
+    } else {
+        const float4 a = S.tri_v[t3], b = S.tri_v[t3 + 1], c = S.tri_v[t3 + 2];
+        tri_n = cross(sub(mk(b.x, b.y, b.z), mk(a.x, a.y, a.z)), sub(mk(c.x, c.y, c.z), mk(a.x, a.y, a.z)));
+    }
+    const float4 q = *(const float4*)it->rotation;
+    const float4 sc = *(const float4*)it->scale;
+    n = normalize(rot_quat(mul(tri_n, mk(sc.x, sc.y, sc.z)), mk(q.x, q.y, q.z), q.w));  // rt_cpu_transform_dir, :575-577
+}
+
+// ---- random numbers -------------------------------------------------------------------
+// The reference draws from one global rand() stream (src/common/common_math.h:310), which
+// ties the image to the serial pixel order.  Here every draw is a pure function of
+// (seed, pixel, sample, draw index): two rounds of the splitmix64 finaliser, 31 bits out,
+// converted exactly like (f32)rand()/(f32)RAND_MAX (RAND_MAX rounds to 2^31).
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 27; z *= 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return z;
+}
+struct Rng {
+    uint64_t key;
+    uint32_t draw;
+};
+__device__ __forceinline__ Rng rng_make(uint64_t seed, uint32_t pixel, uint32_t sample) {
+    Rng g;
+    g.key = mix64(seed ^ mix64(((uint64_t)pixel << 32) | (uint64_t)sample));
+    g.draw = 0;
+    return g;
+}
+__device__ __forceinline__ float rand_unit(Rng& g) {
+    uint32_t v = (uint32_t)(mix64(g.key + ((uint64_t)g.draw + 1ull) * 0x9E3779B97F4A7C15ull) >> 33);
+    g.draw++;
+    return (float)(int)v / 2147483648.0f;
+}
+
+// sin and cos for 0 <= x <= 2*pi in binary32 without fused operations: Cody-Waite
+// reduction by pi/2 and the classic single-precision minimax kernels.  The host-side
+// checker evaluates the same expressions, so both produce the same bits.
+__device__ __forceinline__ void poly_sincos(float x, float& s_out, float& c_out) {
+    int k = (int)(x * 0.636619772367581343f + 0.5f);
+    float kf = (float)k;
+    float r = ((x - kf * 1.5703125f) - kf * 4.837512969970703125e-4f) - kf * 7.54978995489188216e-8f;
+    float r2 = r * r;
+    float s = r + r * r2 * (-1.6666667163e-01f + r2 * (8.3333337680e-03f + r2 * (-1.9841270114e-04f + r2 * 2.7557314297e-06f)));
+    float c = (1.f - 0.5f * r2) + r2 * r2 * (4.1666667908e-02f + r2 * (-1.3888889225e-03f + r2 * (2.4801587642e-05f + r2 * -2.7557314297e-07f)));
+    switch (k & 3) {
+        case 0: s_out = s; c_out = c; break;
+        case 1: s_out = c; c_out = -s; break;
+        case 2: s_out = -s; c_out = -c; break;
+        default: s_out = -c; c_out = s; break;
+    }
+}
+
+// rt_cpu_cosine_sample_hemisphere + rt_cpu_transform_uvw_to_hemisphere, raytracer_cpu.c:536-559
+__device__ __forceinline__ V3 cosine_sample(V3 n, Rng& g) {
+    float r1 = rand_unit(g);
+    float r2 = rand_unit(g);
+    float phi = 2.f * kPi * r1;
+    float sn, cs;
+    poly_sincos(phi, sn, cs);
+    float sq = sqrtf(r2);
+    float u = cs * sq;
+    float v = sn * sq;
+    float w = sqrtf(1.f - r2);
+    V3 ub = orthogonal(n);
+    V3 vb = cross(ub, n);
+    return normalize(add(add(scale(ub, u), scale(vb, v)), scale(n, w)));
+}
+
+// camera ray of rt_cpu_raygen, raytracer_cpu.c:195-231.  `randomise` selects the
+// samples > 1 jitter and the defocus offset (both draw random numbers).
+__device__ __forceinline__ void camera_ray(const rthip_cast_settings& c, int width, int height, int x, int y, int xs,
+                                           int ys, bool randomise, Rng& g, V3& origin, V3& dir) {
+    const int samples = (int)c.samples;
+    const float x_size = 1.f / (float)(width * samples);
+    const float y_size = 1.f / (float)(height * samples);
+    float x_norm = ((float)x / (float)width) + ((float)xs / (float)samples) * x_size;
+    float y_norm = ((float)y / (float)height) + ((float)ys / (float)samples) * y_size;
+    if (randomise && samples > 1) {
+        x_norm += rand_unit(g) * x_size;
+        y_norm += rand_unit(g) * y_size;
+    } else {
+        x_norm += 0.5f * x_size;
+        y_norm += 0.5f * y_size;
+    }
+    const V3 ndc = mk(2.f * x_norm - 1.f, 1.f - 2.f * y_norm, 1.f);
+    const V3 view = mul(ndc, mk(c.viewport[0], c.viewport[1], c.viewport[2]));
+    const V3 eye = mk(c.eye[0], c.eye[1], c.eye[2]);
+    const V3 right = mk(c.right[0], c.right[1], c.right[2]);
+    const V3 up = mk(c.up[0], c.up[1], c.up[2]);
+    const V3 fwd = mk(c.forward[0], c.forward[1], c.forward[2]);
+    const V3 sample = add(add(add(eye, scale(right, view.x)), scale(up, view.y)), scale(fwd, view.z));
+    origin = (!c.orthographic) ? eye : sub(sample, fwd);
+    if (randomise && c.defocus) {
+        float dx, dy;
+        for (;;) {  // rand_unit_sphere_2f32, common_math.c:10-16: positive quadrant only
+            dx = rand_unit(g);
+            dy = rand_unit(g);
+            if (dx * dx + dy * dy <= 1.f) break;
+        }
+        dx = dx * c.defocus_disk[0];
+        dy = dy * c.defocus_disk[1];
+        origin = add(add(origin, scale(right, dx)), scale(up, dy));
+    }
+    dir = normalize(sub(sample, origin));
+}
+
+// rt_cpu_miss, raytracer_cpu.c:354-371 (pow(y, 0.5) evaluated as a correctly rounded sqrt)
+__device__ __forceinline__ V3 miss_radiance(const DevScene& S, V3 d) {
+    if (!S.sky) return mk(0.f, 0.f, 0.f);
+    float y = (d.y < 0.f) ? 0.f : ((d.y > 1.f) ? 1.f : d.y);
+    float t = sqrtf(y);
+    V3 sky = mk((1.f - t) * 1.f + t * 0.5f, (1.f - t) * 1.f + t * 0.7f, (1.f - t) * 1.f + t * 1.f);
+    return scale(sky, 0.7f + 0.25f * y);
+}
+
+// One bounce of rt_cpu_closest_hit / rt_cpu_miss, raytracer_cpu.c:259-371, for a ray whose query
+// has ended.  Either starts the next ray of the path (returns false; o, d hold the new ray) or ends
+// the path (returns true; L holds the terminal radiance before it is folded back through the
+// stack).  The reference returns albedo * L_in + emissive from the inside out; to keep that
+// order of operations the materials of the scattering bounces are recorded on a per-lane stack
+// in LDS and the radiance is folded back through it once the path has ended (path_fold).
+struct PathState {
+    uint32_t depth;   // bounces left (rt_cpu_trace_ray's depth argument)
+    uint32_t sp;      // entries on the material stack
+    float ior_top, ior_below;  // RT_CPU_TraceContext (raytracer_cpu.h:52-56): only the top two entries
+                               // of its ior stack are ever read, and pops happen after the recursion
+    Rng g;
+};
+
+__device__ __forceinline__ bool path_bounce(const DevScene& S, PathState& P, const Hit& h, V3& o, V3& d, V3& L,
+                                            uint32_t* stack, uint32_t stride) {
+    if (h.inst == 0) {
+        L = miss_radiance(S, d);
+        return true;
+    }
+    V3 p, n;
+    int material;
+    finish_hit(S, o, d, h, p, n, material);
+    if (material < 0) {  // zero handle, raytracer_cpu.c:264-266
+        L = mk(1.f, 1.f, 1.f);
+        return true;
+    }
+    const rthip_material* mat = &S.mats[material];
+    const uint32_t type = mat->type;
+    if (mat->billboard && dot(n, d) > 0.f) n = scale(n, -1.f);
+    if (type == RTHIP_MAT_LAMBERTIAN) {
+        o = add(p, scale(n, kSurfaceOffset));
+        d = cosine_sample(n, P.g);
+        stack[P.sp * stride] = (uint32_t)material;
+        P.sp++;
+    } else if (type == RTHIP_MAT_DIELECTRIC) {
+        float idotn = -dot(n, d);
+        bool backface = idotn < 0.f;
+        V3 n_corr = scale(n, backface ? -1.f : 1.f);
+        float eta_i = P.ior_top;
+        float eta_t = backface ? mat->ior : P.ior_below;
+        float eta = eta_i / eta_t;
+        bool tir = sqrtf(1.f - idotn * idotn) * eta > 1.f;
+        bool refl = tir;
+        if (!tir) {  // rt_cpu_fresnel_schlick, :560-564, pow(x, 5) by multiplication
+            float sr0 = (eta_i - eta_t) / (eta_i + eta_t);
+            float r0 = sr0 * sr0;
+            float x = 1.f - fabsf(idotn);
+            float x2 = x * x;
+            float f = r0 + (1.f - r0) * (x2 * x2 * x);
+            refl = f > rand_unit(P.g);
+        }
+        if (refl) {
+            o = add(p, scale(n_corr, kSurfaceOffset));
+            d = reflect(d, n_corr);
+        } else {
+            o = add(p, scale(n_corr, -kSurfaceOffset));
+            d = refract(d, n_corr, eta);
+            P.ior_below = P.ior_top;
+            P.ior_top = eta_t;
+        }
+        stack[P.sp * stride] = (uint32_t)material;
+        P.sp++;
+    } else if (type == RTHIP_MAT_METAL) {
+        V3 i = reflect(d, n);
+        V3 r;
+        for (;;) {  // rand_unit_sphere_3f32, common_math.c:54-60: positive octant only
+            r.x = rand_unit(P.g);
+            r.y = rand_unit(P.g);
+            r.z = rand_unit(P.g);
+            if (dot(r, r) <= 1.f) break;
+        }
+        i = add(i, scale(r, mat->roughness));
+        o = add(p, scale(n, kSurfaceOffset));
+        d = normalize(i);
+    } else if (type == RTHIP_MAT_NORMAL) {  // rt_cpu_normal_to_radiance, :565-567
+        L = scale(add(n, mk(1.f, 1.f, 1.f)), 0.5f);
+        return true;
+    } else {  // RTHIP_MAT_LIGHT
+        L = mk(mat->emissive[0], mat->emissive[1], mat->emissive[2]);
+        return true;
+    }
+    P.depth--;
+    if (P.depth == 0) {  // rt_cpu_trace_ray with depth 0 returns black (:247-249)
+        L = mk(0.f, 0.f, 0.f);
+        return true;
+    }
+    return false;
+}
+
+__device__ __forceinline__ V3 path_fold(const DevScene& S, PathState& P, V3 L, const uint32_t* stack, uint32_t stride) {
+    while (P.sp > 0) {
+        P.sp--;
+        const rthip_material* mat = &S.mats[stack[P.sp * stride]];
+        const V3 e = mk(mat->emissive[0], mat->emissive[1], mat->emissive[2]);
+        if (mat->type == RTHIP_MAT_LAMBERTIAN)
+            L = add(mul(mk(mat->albedo[0], mat->albedo[1], mat->albedo[2]), L), e);  // :286-289
+        else
+            L = add(L, e);  // dielectric, :327
+    }
+    return L;
+}
+
+__device__ __forceinline__ void flush_counters(uint64_t* counters, const Counters& c, uint32_t rays) {
+    // one atomic per wave and counter
+    uint32_t v[5] = {rays, c.nodes, c.tris, c.insts, c.wave_steps};
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        uint32_t x = v[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+        if ((threadIdx.x & 63) == 0 && x) atomicAdd((unsigned long long*)&counters[k], (unsigned long long)x);
+    }
+}
+
+}  // namespace

@@ -111,9 +111,20 @@ int rthip_create(rthip_ctx** out_ctx, int device_id) {
     ctx->device = device_id;
     const char* fence = getenv("RTHIP_REFIT_FENCE");
     ctx->refit_fence = (fence && fence[0] == '1') ? 1 : 0;
+    const char* mode = getenv("RTHIP_CAST");
+    if (mode && strcmp(mode, "static") == 0) ctx->cast_mode = 1;
+    if (mode && strcmp(mode, "wavefront") == 0) ctx->cast_mode = 2;
+    if (mode && strcmp(mode, "persistent") == 0) ctx->cast_mode = 0;
+    if (mode && strcmp(mode, "auto") == 0) ctx->cast_mode = 3;
+    ctx->persistent_blocks = (uint32_t)prop.multiProcessorCount * 5u;
+    const char* stat = getenv("RTHIP_STATIC");
+    if (stat && atoi(stat) >= 0 && atoi(stat) <= 100) ctx->static_percent = (uint32_t)atoi(stat);
+    const char* refill = getenv("RTHIP_REFILL");
+    if (refill && atoi(refill) >= 1 && atoi(refill) <= 64) ctx->refill_lanes = (uint32_t)atoi(refill);
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
-        rthip_reserve(ctx, ctx->counters, 64) != RTHIP_OK || hipMemset(ctx->counters.p, 0, 64) != hipSuccess) {
+        rthip_reserve(ctx, ctx->counters, 64) != RTHIP_OK || hipMemset(ctx->counters.p, 0, 64) != hipSuccess ||
+        rthip_reserve(ctx, ctx->work_ring, 16 * 1024) != RTHIP_OK) {
         rthip_destroy(ctx);
         return RTHIP_E_HIP;
     }
@@ -129,9 +140,10 @@ void rthip_destroy(rthip_ctx* ctx) {
     LbvhWorkspace& w = ctx->ws;
     DevBuf* all[] = {&w.aabb, &w.keys[0], &w.keys[1], &w.vals[0], &w.vals[1], &w.block_hist, &w.scan_tmp, &w.prio,
                      &w.child, &w.flags, &w.node_info, &w.node_dl, &w.leaf_sorted, &w.cnt_l, &w.bounds, &ctx->blas_nodes, &ctx->tri_v, &ctx->tri_n,
-                     &ctx->tlas_nodes, &ctx->inst, &ctx->mats, &ctx->inst_aabb, &ctx->counters, &ctx->scratch_a,
+                     &ctx->tlas_nodes, &ctx->inst, &ctx->mats, &ctx->inst_aabb, &ctx->counters, &ctx->work_ring, &ctx->scratch_a,
                      &ctx->scratch_b, &ctx->scratch_c, &ctx->scratch_d, &ctx->scratch_e};
     for (DevBuf* b : all) rthip_release(*b);
+    for (DevBuf& b : ctx->wf) rthip_release(b);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -150,6 +162,13 @@ int rthip_set_tracer(rthip_ctx* ctx, uint32_t max_bounces, int sky) {
 int rthip_set_counting(rthip_ctx* ctx, int enabled) {
     if (!ctx) return RTHIP_E_INVALID;
     ctx->counting = enabled ? 1 : 0;
+    return RTHIP_OK;
+}
+
+int rthip_set_cast_kernel(rthip_ctx* ctx, int kernel) {
+    if (!ctx) return RTHIP_E_INVALID;
+    if (kernel < 0 || kernel > 3) return rthip_fail(ctx, RTHIP_E_INVALID, "unknown cast kernel %d", kernel);
+    ctx->cast_mode = kernel;
     return RTHIP_OK;
 }
 
@@ -493,13 +512,14 @@ int rthip_get_stats(rthip_ctx* ctx, rthip_stats* out) {
     if (!ctx || !out) return RTHIP_E_INVALID;
     RT_HIP(ctx, hipSetDevice(ctx->device));
     RT_HIP(ctx, hipDeviceSynchronize());
-    uint64_t c[4];
-    RT_HIP(ctx, hipMemcpy(c, ctx->counters.p, 32, hipMemcpyDeviceToHost));
-    RT_HIP(ctx, hipMemset(ctx->counters.p, 0, 32));
+    uint64_t c[8];
+    RT_HIP(ctx, hipMemcpy(c, ctx->counters.p, 64, hipMemcpyDeviceToHost));
+    RT_HIP(ctx, hipMemset(ctx->counters.p, 0, 64));
     out->rays = c[0];
     out->nodes_tested = c[1];
     out->tris_tested = c[2];
     out->inst_entered = c[3];
+    out->wave_steps = c[4];
     out->last_cast_ms = ctx->last_cast_ms;
     out->last_build_ms = ctx->last_build_ms;
     return RTHIP_OK;

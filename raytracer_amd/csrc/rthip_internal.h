@@ -125,6 +125,14 @@ struct rthip_ctx {
     bool tlas_built = false;
 
     DevBuf counters;  // uint64[4]
+    DevBuf work_ring;  // 16 x 1 KiB: eight 128-byte-spaced work counters per launch of the persistent cast kernel
+    uint32_t work_next = 0;
+    int cast_mode = 3;           // 0: persistent kernel, 1: fixed pixel per thread, 2: wavefront, 3: 0 or 1 by scene size (RTHIP_CAST=...)
+    uint32_t persistent_blocks = 256u * 5u;  // resident workgroups of the persistent kernel (CUs x 5)
+    DevBuf wf[11];               // path-state arrays of the wavefront renderer
+    uint64_t wf_capacity = 1ull << 23;  // paths per wavefront batch
+    uint32_t static_percent = 0;   // share of the tiles dealt round-robin up front (RTHIP_STATIC overrides)
+    uint32_t refill_lanes = 16;  // lanes with other work that end a traversal phase (RTHIP_REFILL overrides)
     DevBuf scratch_a, scratch_b, scratch_c, scratch_d, scratch_e;  // staging for host <-> device taps
     float last_cast_ms = 0.f, last_build_ms = 0.f;
 };
@@ -172,5 +180,8 @@ int trace_rays_launch(rthip_ctx* ctx, const DevScene& scene, const float* d_o, c
                       uint32_t* d_hits4, float* d_uv, float* d_normal, uint64_t* d_counters, hipStream_t stream);
 int primary_hits_launch(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_settings& cast, int width, int height,
                         uint32_t* d_hits4, uint64_t* d_counters, hipStream_t stream);
+int cast_wavefront_launch(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_settings& cast, uint64_t seed,
+                          float* d_rgb, int width, int height, rthip_shard shard, uint64_t* d_counters,
+                          hipStream_t stream);
 int cast_launch(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_settings& cast, uint64_t seed, float* d_rgb,
                 int width, int height, rthip_shard shard, uint64_t* d_counters, hipStream_t stream);

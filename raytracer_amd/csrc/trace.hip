@@ -1,483 +1,201 @@
-// Two-level BVH traversal, ray/triangle and ray/sphere intersection, shading and
-// bounce generation for gfx950.
-//
-// Traversal is the reference's: depth-first, always left before right, a leaf's
-// primitive tested after its box, the interval shrinking at every accepted hit
-// (src/lbvh/lbvh.c:127-161).  On the pre-order node array that recursion is a
-// linear walk: next = index + 1 to descend, next = skip when a box is missed or a
-// leaf is done.  TLAS and BLAS walks run in ONE loop per lane (a lane switches
-// arrays when it enters or leaves an instance), so lanes of a wave that are in
-// different levels still advance together.
-//
-// Arithmetic is binary32 in the reference's operation order; this file must be
-// compiled with -ffp-contract=off (no fused multiply-add) and without fast-math.
+// Rendering kernels that keep a whole camera path inside one lane: the persistent kernel with
+// per-lane refill, the fixed pixel-per-thread kernel, and the parity taps (primary hits, caller
+// supplied rays).  Device-side building blocks live in rt_device.h.
 
-#include "rthip_internal.h"
+#include "rt_device.h"
 
 namespace {
 
-constexpr int kBlock = 256;
-constexpr float kEps = 1.1920929E-7f;       // EPSILON_F32, src/common/common_math.h:288
-constexpr float kMaxF = 3.402823466e+38f;   // MAX_F32
-constexpr float kPi = 3.1415926535897932384626433832795028841971693993751058209749445923078164062f;
-constexpr float kSurfaceOffset = 0.001f;    // RT_CPU_SURFACE_OFFSET, raytracer_cpu.c:257
+// rt_cpu_raygen, raytracer_cpu.c:179-242, as a persistent kernel.
+//
+// Work item = one pixel (all of its samples, in the reference's order: y_sample outer, x_sample
+// inner, summed in that order, then scaled by 1/samples^2).  8x8-pixel tiles are dealt to the
+// waves round-robin and a lane that has finished its pixel takes the next pixel of its wave's
+// tile sequence, so a wave that starts together starts on one tile.  Every lane is a small
+// state machine:
+//
+//   NEED_PIXEL -> NEED_SAMPLE -> TRAVERSE -> SHADE -> TRAVERSE ... -> NEED_SAMPLE ... -> NEED_PIXEL
+//
+// and the wave loops over three phases: fetch/raygen for the lanes that need it, a traversal
+// loop in which every TRAVERSE lane advances one node per iteration, and shading for the lanes
+// whose query has ended.  The traversal loop is left as soon as `refill` lanes have something else
+// to do (or nobody traverses), so finished lanes get their next ray instead of idling until the
+// longest ray of the wave is done.  Refill slots are handed out with one ballot + mbcnt-style
+// prefix; there is no global queue and no lane ever waits for another wave.
+enum : uint32_t { ST_NEED_PIXEL = 0, ST_NEED_SAMPLE = 1, ST_TRAVERSE = 2, ST_SHADE = 3, ST_DONE = 4 };
 
-struct V3 {
-    float x, y, z;
-};
-__device__ __forceinline__ V3 mk(float x, float y, float z) { return V3{x, y, z}; }
-__device__ __forceinline__ V3 add(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
-__device__ __forceinline__ V3 sub(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
-__device__ __forceinline__ V3 scale(V3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
-__device__ __forceinline__ V3 mul(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
-__device__ __forceinline__ V3 divv(V3 a, V3 b) { return mk(a.x / b.x, a.y / b.y, a.z / b.z); }
-__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-__device__ __forceinline__ V3 cross(V3 a, V3 b) {  // common_math.c:29
-    return mk(a.y * b.z - a.z * b.y, -(a.x * b.z - a.z * b.x), a.x * b.y - a.y * b.x);
-}
-__device__ __forceinline__ V3 normalize(V3 a) {  // common_math.c:27-28: three divisions by the length
-    float l = sqrtf(a.x * a.x + a.y * a.y + a.z * a.z);
-    return mk(a.x / l, a.y / l, a.z / l);
-}
-__device__ __forceinline__ V3 rot_quat(V3 p, V3 qv, float qw) {  // common_math.c:91
-    V3 a = scale(p, qw * qw - dot(qv, qv));
-    V3 b = scale(qv, 2.f * dot(qv, p));
-    V3 c = scale(cross(qv, p), 2.f * qw);
-    return add(add(a, b), c);
-}
-__device__ __forceinline__ V3 reflect(V3 i, V3 n) { return sub(i, scale(n, 2.f * dot(i, n))); }  // common_math.c:30
-__device__ __forceinline__ V3 orthogonal(V3 x) {  // common_math.c:37-46
-    float ax = fabsf(x.x), ay = fabsf(x.y), az = fabsf(x.z);
-    float mx = ((ax <= ay) & (ax <= az)) ? 1.f : 0.f;
-    float my = ((ay < ax) & (ay <= az)) ? 1.f : 0.f;
-    float mz = 1.f - mx - my;
-    return cross(x, mk(mx, my, mz));
-}
-__device__ __forceinline__ V3 refract(V3 i, V3 n, float eta) {  // common_math.c:47-53
-    float ndoti = dot(n, i);
-    float k = 1.f - eta * eta * (1.f - ndoti * ndoti);
-    if (k < 0.f) return mk(0.f, 0.f, 0.f);
-    return sub(scale(i, eta), scale(n, eta * ndoti + sqrtf(k)));
-}
-
-struct Hit {
-    uint32_t inst;  // 1-based TLAS id, 0 = miss
-    uint32_t tri;   // index-buffer offset of the triangle ((id-1)*3), meshes only
-    float u, v;
-    float t;        // interval.max after the query
-};
-
-struct Counters {
-    uint32_t nodes, tris, insts;
-};
-
-// lbvh_aabb_query_ray, lbvh.c:127-149, with 1/d hoisted (the same correctly rounded
-// quotient every time, so hoisting does not change a bit).  Works on a copy of the
-// interval, as the reference does.
-__device__ __forceinline__ bool slab(float4 lo, float4 hi, V3 o, V3 inv, float tmin, float tmax) {
-    {
-        float t0 = (lo.x - o.x) * inv.x, t1 = (hi.x - o.x) * inv.x;
-        if (t0 < t1) { if (t0 > tmin) tmin = t0; if (t1 < tmax) tmax = t1; }
-        else         { if (t1 > tmin) tmin = t1; if (t0 < tmax) tmax = t0; }
-        if (tmax < tmin) return false;
-    }
-    {
-        float t0 = (lo.y - o.y) * inv.y, t1 = (hi.y - o.y) * inv.y;
-        if (t0 < t1) { if (t0 > tmin) tmin = t0; if (t1 < tmax) tmax = t1; }
-        else         { if (t1 > tmin) tmin = t1; if (t0 < tmax) tmax = t0; }
-        if (tmax < tmin) return false;
-    }
-    {
-        float t0 = (lo.z - o.z) * inv.z, t1 = (hi.z - o.z) * inv.z;
-        if (t0 < t1) { if (t0 > tmin) tmin = t0; if (t1 < tmax) tmax = t1; }
-        else         { if (t1 > tmin) tmin = t1; if (t0 < tmax) tmax = t0; }
-        if (tmax < tmin) return false;
-    }
-    return true;
-}
-
-// geo_intersect_tri, src/geo/geo.c:72-109
-__device__ __forceinline__ bool tri_test(V3 o, V3 d, V3 a, V3 b, V3 c, float tmin, float& tmax, float& u_out,
-                                         float& v_out) {
-    V3 edge1 = sub(b, a);
-    V3 edge2 = sub(c, a);
-    V3 rxe2 = cross(d, edge2);
-    float det = dot(edge1, rxe2);
-    if (det == 0.f) return false;
-    float inv_det = 1.f / det;
-    V3 s = sub(o, a);
-    float u = inv_det * dot(s, rxe2);
-    if ((u < 0.f && fabsf(u) > kEps) || (u > 1.f && fabsf(u - 1.f) > kEps)) return false;
-    V3 sxe1 = cross(s, edge1);
-    float v = inv_det * dot(d, sxe1);
-    if ((v < 0.f && fabsf(v) > kEps) || (u + v > 1.f && fabsf(u + v - 1.f) > kEps)) return false;
-    float t = inv_det * dot(edge2, sxe1);
-    if (!(t >= tmin && t <= tmax)) return false;  // geo_in_interval, geo.c:32-34
-    tmax = t;
-    u_out = u;
-    v_out = v;
-    return true;
-}
-
-// geo_intersect_sphere, geo.c:36-69
-__device__ __forceinline__ bool sphere_test(V3 o, V3 d, V3 center, float radius, float tmin, float& tmax) {
-    V3 omc = sub(o, center);
-    float a = dot(d, d);
-    float half_b = dot(d, omc);
-    float c = dot(omc, omc) - radius * radius;
-    float qtr_d = half_b * half_b - a * c;
-    if (qtr_d < 0.f) return false;
-    float half_sqrt_d = sqrtf(qtr_d);
-    float t = (-half_b - half_sqrt_d) / a;
-    if (!(t >= tmin && t <= tmax)) {
-        t = (-half_b + half_sqrt_d) / a;
-        if (!(t >= tmin && t <= tmax)) return false;
-    }
-    tmax = t;
-    return true;
-}
-
-// rt_cpu_intersect's query, raytracer_cpu.c:402-407: lbvh_query_ray over the TLAS with
-// rt_cpu_tlas_hit -> rt_cpu_intersect_tlas_node (:494-531) -> BLAS query with
-// rt_cpu_blas_node_hit (:459-492).
 template <bool COUNT>
-__device__ __forceinline__ Hit closest_hit_query(const DevScene& S, V3 wo, V3 wd, Counters& cnt) {
-    Hit h;
-    h.inst = 0;
-    h.tri = 0;
-    h.u = 0.f;
-    h.v = 0.f;
-    const float tmin = kEps;  // geo_make_pos_interval, geo.c:28-30
-    float tmax = kMaxF;
-
-    const float4* nodes = S.tlas;
-    uint32_t idx = 0, end = S.n_tlas;
-    uint32_t resume = 0;   // TLAS index to continue from when the current BLAS walk ends
-    uint32_t cur_inst = 0; // TLAS id of the instance being walked (0: in the TLAS)
-    uint32_t tri_base = 0;
-    V3 o = wo, d = wd;
-    V3 inv = mk(1.f / wd.x, 1.f / wd.y, 1.f / wd.z);
-    const V3 winv = inv;
-
-    for (;;) {
-        if (idx >= end) {
-            if (cur_inst == 0) break;
-            // leave the instance: back to the TLAS walk with the world-space ray
-            cur_inst = 0;
-            nodes = S.tlas;
-            idx = resume;
-            end = S.n_tlas;
-            o = wo;
-            d = wd;
-            inv = winv;
-            continue;
-        }
-        const float4 lo = nodes[2 * (size_t)idx], hi = nodes[2 * (size_t)idx + 1];
-        if (COUNT) cnt.nodes++;
-        const uint32_t id = __float_as_uint(hi.w);
-        uint32_t skip = __float_as_uint(lo.w);
-        if (skip <= idx) skip = end;  // a well-formed tree never needs this; it bounds the walk on a corrupt one
-        if (!slab(lo, hi, o, inv, tmin, tmax)) {
-            idx = skip;
-            continue;
-        }
-        if (id == 0) {  // inner node: left child is the next record
-            idx = idx + 1;
-            continue;
-        }
-        if (cur_inst != 0) {
-            // BLAS leaf: triangle id (1-based), vertices pre-gathered per triangle
-            const float4* tv = S.tri_v + 3 * (size_t)(tri_base + (id - 1));
-            const float4 a = tv[0], b = tv[1], c = tv[2];
-            if (COUNT) cnt.tris++;
-            float u, v;
-            if (tri_test(o, d, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), tmin, tmax, u, v)) {
-                h.inst = cur_inst;
-                h.tri = (id - 1) * 3;  // idx = (id - 1)*3, raytracer_cpu.c:467,479
-                h.u = u;
-                h.v = v;
-            }
-            idx = skip;
-            continue;
-        }
-        // TLAS leaf: enter the instance
-        const DevInstance* it = &S.inst[id - 1];
-        if (COUNT) cnt.insts++;
-        if (it->type == RTHIP_INST_SPHERE) {
-            const float4 cr = *(const float4*)it->sphere_center;
-            if (sphere_test(o, d, mk(cr.x, cr.y, cr.z), it->sphere_radius, tmin, tmax)) {
-                h.inst = id;
-                h.tri = 0;
-                h.u = 0.f;
-                h.v = 0.f;
-            }
-            idx = skip;
-            continue;
-        }
-        {
-            // rt_cpu_inv_transform_ray, raytracer_cpu.c:572-580,607-612; the model-space
-            // direction is not renormalised, so t is shared between the two spaces
-            const float4 tr = *(const float4*)it->translation;
-            const float4 q = *(const float4*)it->rotation;
-            const float4 sc = *(const float4*)it->scale;
-            const V3 qv = mk(-q.x, -q.y, -q.z);  // inv_quat, common_math.c:90
-            const V3 s3 = mk(sc.x, sc.y, sc.z);
-            o = divv(rot_quat(sub(wo, mk(tr.x, tr.y, tr.z)), qv, q.w), s3);
-            d = divv(rot_quat(wd, qv, q.w), s3);
-            inv = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);
-            resume = skip;
-            cur_inst = id;
-            tri_base = it->tri_base;
-            nodes = S.blas + 2 * (size_t)it->node_base;
-            idx = 0;
-            end = it->n_nodes;
-        }
-    }
-    h.t = tmax;
-    return h;
-}
-
-// epilogue of rt_cpu_intersect, raytracer_cpu.c:411-454: position and shading normal
-__device__ __forceinline__ void finish_hit(const DevScene& S, V3 o, V3 d, const Hit& h, V3& p, V3& n, int& material) {
-    const DevInstance* it = &S.inst[h.inst - 1];
-    p = add(o, scale(d, h.t));
-    material = it->material;
-    if (it->type == RTHIP_INST_SPHERE) {
-        const float4 cr = *(const float4*)it->sphere_center;
-        n = scale(sub(p, mk(cr.x, cr.y, cr.z)), 1.f / it->sphere_radius);
-        return;
-    }
-    const size_t t3 = 3 * (size_t)(it->tri_base + h.tri / 3);
-    V3 tri_n;
-    if (it->has_normals) {
-        // U weights vertex 0 and V vertex 1, as the reference writes it (:441-445)
-        const float4 n0 = S.tri_n[t3], n1 = S.tri_n[t3 + 1], n2 = S.tri_n[t3 + 2];
-        tri_n = add(add(scale(mk(n0.x, n0.y, n0.z), h.u), scale(mk(n1.x, n1.y, n1.z), h.v)),
-                    scale(mk(n2.x, n2.y, n2.z), 1.f - h.u - h.v));
-    } else {
-        const float4 a = S.tri_v[t3], b = S.tri_v[t3 + 1], c = S.tri_v[t3 + 2];
-        tri_n = cross(sub(mk(b.x, b.y, b.z), mk(a.x, a.y, a.z)), sub(mk(c.x, c.y, c.z), mk(a.x, a.y, a.z)));
-    }
-    const float4 q = *(const float4*)it->rotation;
-    const float4 sc = *(const float4*)it->scale;
-    n = normalize(rot_quat(mul(tri_n, mk(sc.x, sc.y, sc.z)), mk(q.x, q.y, q.z), q.w));  // rt_cpu_transform_dir, :575-577
-}
-
-// ---- random numbers -------------------------------------------------------------------
-// The reference draws from one global rand() stream (src/common/common_math.h:310), which
-// ties the image to the serial pixel order.  Here every draw is a pure function of
-// (seed, pixel, sample, draw index): two rounds of the splitmix64 finaliser, 31 bits out,
-// converted exactly like (f32)rand()/(f32)RAND_MAX (RAND_MAX rounds to 2^31).
-__device__ __forceinline__ uint64_t mix64(uint64_t z) {
-    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
-    z ^= z >> 27; z *= 0x94D049BB133111EBull;
-    z ^= z >> 31;
-    return z;
-}
-struct Rng {
-    uint64_t key;
-    uint32_t draw;
-};
-__device__ __forceinline__ Rng rng_make(uint64_t seed, uint32_t pixel, uint32_t sample) {
-    Rng g;
-    g.key = mix64(seed ^ mix64(((uint64_t)pixel << 32) | (uint64_t)sample));
-    g.draw = 0;
-    return g;
-}
-__device__ __forceinline__ float rand_unit(Rng& g) {
-    uint32_t v = (uint32_t)(mix64(g.key + ((uint64_t)g.draw + 1ull) * 0x9E3779B97F4A7C15ull) >> 33);
-    g.draw++;
-    return (float)(int)v / 2147483648.0f;
-}
-
-// sin and cos for 0 <= x <= 2*pi in binary32 without fused operations: Cody-Waite
-// reduction by pi/2 and the classic single-precision minimax kernels.  The host-side
-// checker evaluates the same expressions, so both produce the same bits.
-__device__ __forceinline__ void poly_sincos(float x, float& s_out, float& c_out) {
-    int k = (int)(x * 0.636619772367581343f + 0.5f);
-    float kf = (float)k;
-    float r = ((x - kf * 1.5703125f) - kf * 4.837512969970703125e-4f) - kf * 7.54978995489188216e-8f;
-    float r2 = r * r;
-    float s = r + r * r2 * (-1.6666667163e-01f + r2 * (8.3333337680e-03f + r2 * (-1.9841270114e-04f + r2 * 2.7557314297e-06f)));
-    float c = (1.f - 0.5f * r2) + r2 * r2 * (4.1666667908e-02f + r2 * (-1.3888889225e-03f + r2 * (2.4801587642e-05f + r2 * -2.7557314297e-07f)));
-    switch (k & 3) {
-        case 0: s_out = s; c_out = c; break;
-        case 1: s_out = c; c_out = -s; break;
-        case 2: s_out = -s; c_out = -c; break;
-        default: s_out = -c; c_out = s; break;
-    }
-}
-
-// rt_cpu_cosine_sample_hemisphere + rt_cpu_transform_uvw_to_hemisphere, raytracer_cpu.c:536-559
-__device__ __forceinline__ V3 cosine_sample(V3 n, Rng& g) {
-    float r1 = rand_unit(g);
-    float r2 = rand_unit(g);
-    float phi = 2.f * kPi * r1;
-    float sn, cs;
-    poly_sincos(phi, sn, cs);
-    float sq = sqrtf(r2);
-    float u = cs * sq;
-    float v = sn * sq;
-    float w = sqrtf(1.f - r2);
-    V3 ub = orthogonal(n);
-    V3 vb = cross(ub, n);
-    return normalize(add(add(scale(ub, u), scale(vb, v)), scale(n, w)));
-}
-
-// camera ray of rt_cpu_raygen, raytracer_cpu.c:195-231.  `randomise` selects the
-// samples > 1 jitter and the defocus offset (both draw random numbers).
-__device__ __forceinline__ void camera_ray(const rthip_cast_settings& c, int width, int height, int x, int y, int xs,
-                                           int ys, bool randomise, Rng& g, V3& origin, V3& dir) {
+__global__ __launch_bounds__(kBlock, 5) void cast_kernel(DevScene S, rthip_cast_settings c, uint64_t seed,
+                                                      float* __restrict__ out, int width, int height,
+                                                      rthip_shard shard, uint32_t* work_counters,
+                                                      uint32_t static_rounds, uint32_t refill,
+                                                      uint64_t* counters) {
+    extern __shared__ uint32_t bounce_stack[];
+    uint32_t* stack = bounce_stack + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
     const int samples = (int)c.samples;
-    const float x_size = 1.f / (float)(width * samples);
-    const float y_size = 1.f / (float)(height * samples);
-    float x_norm = ((float)x / (float)width) + ((float)xs / (float)samples) * x_size;
-    float y_norm = ((float)y / (float)height) + ((float)ys / (float)samples) * y_size;
-    if (randomise && samples > 1) {
-        x_norm += rand_unit(g) * x_size;
-        y_norm += rand_unit(g) * y_size;
-    } else {
-        x_norm += 0.5f * x_size;
-        y_norm += 0.5f * y_size;
-    }
-    const V3 ndc = mk(2.f * x_norm - 1.f, 1.f - 2.f * y_norm, 1.f);
-    const V3 view = mul(ndc, mk(c.viewport[0], c.viewport[1], c.viewport[2]));
-    const V3 eye = mk(c.eye[0], c.eye[1], c.eye[2]);
-    const V3 right = mk(c.right[0], c.right[1], c.right[2]);
-    const V3 up = mk(c.up[0], c.up[1], c.up[2]);
-    const V3 fwd = mk(c.forward[0], c.forward[1], c.forward[2]);
-    const V3 sample = add(add(add(eye, scale(right, view.x)), scale(up, view.y)), scale(fwd, view.z));
-    origin = (!c.orthographic) ? eye : sub(sample, fwd);
-    if (randomise && c.defocus) {
-        float dx, dy;
-        for (;;) {  // rand_unit_sphere_2f32, common_math.c:10-16: positive quadrant only
-            dx = rand_unit(g);
-            dy = rand_unit(g);
-            if (dx * dx + dy * dy <= 1.f) break;
-        }
-        dx = dx * c.defocus_disk[0];
-        dy = dy * c.defocus_disk[1];
-        origin = add(add(origin, scale(right, dx)), scale(up, dy));
-    }
-    dir = normalize(sub(sample, origin));
-}
+    const uint32_t spp = (uint32_t)(samples * samples);
+    const uint32_t tiles_x = (uint32_t)(width + 7) / 8, tiles_y = (uint32_t)(height + 7) / 8;
+    const uint64_t n_tiles = (uint64_t)tiles_x * tiles_y;
+    const uint32_t n_waves = gridDim.x * (kBlock / 64);
+    const uint32_t wave_id = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    // wave-uniform bookkeeping of the tile the wave is handing out
+    uint64_t tile_id = 0;
+    uint32_t tile_pos = 64;  // positions of tile_id already handed out (64: none left)
+    uint32_t static_left = static_rounds;
+    const uint64_t dyn_first = (uint64_t)static_rounds * n_waves;  // first tile of the dynamically shared part
+    uint32_t qslot = wave_id & 7u, qtried = 0;  // which of the 8 dynamic counters, and how many ran dry
+    const uint32_t shard_tiles_x = (uint32_t)(width + 63) / 64;
 
-// rt_cpu_miss, raytracer_cpu.c:354-371 (pow(y, 0.5) evaluated as a correctly rounded sqrt)
-__device__ __forceinline__ V3 miss_radiance(const DevScene& S, V3 d) {
-    if (!S.sky) return mk(0.f, 0.f, 0.f);
-    float y = (d.y < 0.f) ? 0.f : ((d.y > 1.f) ? 1.f : d.y);
-    float t = sqrtf(y);
-    V3 sky = mk((1.f - t) * 1.f + t * 0.5f, (1.f - t) * 1.f + t * 0.7f, (1.f - t) * 1.f + t * 1.f);
-    return scale(sky, 0.7f + 0.25f * y);
-}
+    Counters cnt = {0, 0, 0, 0};
+    uint32_t rays = 0;
+    uint32_t state = ST_NEED_PIXEL;
+    bool exhausted = false;  // wave-uniform: the work counter has run past the last pixel
+    uint32_t pixel = 0, px = 0, py = 0, sidx = 0;
+    V3 acc = mk(0.f, 0.f, 0.f);
+    PathState P;
+    P.depth = 0;
+    P.sp = 0;
+    P.ior_top = P.ior_below = c.ior;
+    P.g.key = 0;
+    P.g.draw = 0;
+    Trav T;
+    trav_begin(T, S, mk(0.f, 0.f, 0.f), mk(0.f, 0.f, 1.f));
 
-// One camera path: rt_cpu_trace_ray / rt_cpu_closest_hit, raytracer_cpu.c:244-352, as a
-// loop.  The reference returns albedo * L_in + emissive from the inside out; to keep that
-// order of operations the loop records the material of every scattering bounce on a
-// per-lane stack in LDS and folds the radiance back through it once the path has ended.
-template <bool COUNT>
-__device__ __forceinline__ V3 trace_path(const DevScene& S, V3 o, V3 d, float cast_ior, Rng& g, uint32_t* stack,
-                                         uint32_t stride, Counters& cnt, uint32_t& rays) {
-    uint32_t depth = S.max_bounces;
-    uint32_t sp = 0;
-    // RT_CPU_TraceContext, raytracer_cpu.h:52-56: only the top two entries of the ior stack are
-    // ever read and entries are only popped after the recursion returns
-    float ior_top = cast_ior, ior_below = cast_ior;
-    V3 L = mk(0.f, 0.f, 0.f);
     for (;;) {
-        if (depth == 0) break;  // L = 0
-        rays++;
-        const Hit h = closest_hit_query<COUNT>(S, o, d, cnt);
-        if (h.inst == 0) {
-            L = miss_radiance(S, d);
-            break;
-        }
-        V3 p, n;
-        int material;
-        finish_hit(S, o, d, h, p, n, material);
-        if (material < 0) {  // zero handle, raytracer_cpu.c:264-266
-            L = mk(1.f, 1.f, 1.f);
-            break;
-        }
-        const rthip_material* mat = &S.mats[material];
-        const uint32_t type = mat->type;
-        if (mat->billboard && dot(n, d) > 0.f) n = scale(n, -1.f);
-        if (type == RTHIP_MAT_LAMBERTIAN) {
-            o = add(p, scale(n, kSurfaceOffset));
-            d = cosine_sample(n, g);
-            stack[sp * stride] = (uint32_t)material;
-            sp++;
-        } else if (type == RTHIP_MAT_DIELECTRIC) {
-            float idotn = -dot(n, d);
-            bool backface = idotn < 0.f;
-            V3 n_corr = scale(n, backface ? -1.f : 1.f);
-            float eta_i = ior_top;
-            float eta_t = backface ? mat->ior : ior_below;
-            float eta = eta_i / eta_t;
-            bool tir = sqrtf(1.f - idotn * idotn) * eta > 1.f;
-            bool refl = tir;
-            if (!tir) {  // rt_cpu_fresnel_schlick, :560-564, pow(x, 5) by multiplication
-                float sr0 = (eta_i - eta_t) / (eta_i + eta_t);
-                float r0 = sr0 * sr0;
-                float x = 1.f - fabsf(idotn);
-                float x2 = x * x;
-                float f = r0 + (1.f - r0) * (x2 * x2 * x);
-                refl = f > rand_unit(g);
+        // ---- phase 1: a pixel whose samples are all done is written out ---------------------------
+        if (state == ST_NEED_SAMPLE) {
+            if (shard.mode == 2)
+                while (sidx < spp && (sidx % shard.world) != shard.rank) sidx++;
+            if (sidx >= spp) {
+                if (shard.mode != 2) acc = scale(acc, 1.f / ((float)samples * (float)samples));
+                float* o3 = out + 3 * (size_t)pixel;
+                o3[0] = acc.x;
+                o3[1] = acc.y;
+                o3[2] = acc.z;
+                state = ST_NEED_PIXEL;
             }
-            if (refl) {
-                o = add(p, scale(n_corr, kSurfaceOffset));
-                d = reflect(d, n_corr);
-            } else {
-                o = add(p, scale(n_corr, -kSurfaceOffset));
-                d = refract(d, n_corr, eta);
-                ior_below = ior_top;
-                ior_top = eta_t;
-            }
-            stack[sp * stride] = (uint32_t)material;
-            sp++;
-        } else if (type == RTHIP_MAT_METAL) {
-            V3 i = reflect(d, n);
-            V3 r;
-            for (;;) {  // rand_unit_sphere_3f32, common_math.c:54-60: positive octant only
-                r.x = rand_unit(g);
-                r.y = rand_unit(g);
-                r.z = rand_unit(g);
-                if (dot(r, r) <= 1.f) break;
-            }
-            i = add(i, scale(r, mat->roughness));
-            o = add(p, scale(n, kSurfaceOffset));
-            d = normalize(i);
-        } else if (type == RTHIP_MAT_NORMAL) {  // rt_cpu_normal_to_radiance, :565-567
-            L = scale(add(n, mk(1.f, 1.f, 1.f)), 0.5f);
-            break;
-        } else {  // RTHIP_MAT_LIGHT
-            L = mk(mat->emissive[0], mat->emissive[1], mat->emissive[2]);
-            break;
         }
-        depth--;
-    }
-    while (sp > 0) {
-        sp--;
-        const rthip_material* mat = &S.mats[stack[sp * stride]];
-        const V3 e = mk(mat->emissive[0], mat->emissive[1], mat->emissive[2]);
-        if (mat->type == RTHIP_MAT_LAMBERTIAN)
-            L = add(mul(mk(mat->albedo[0], mat->albedo[1], mat->albedo[2]), L), e);  // :286-289
-        else
-            L = add(L, e);  // dielectric, :327
-    }
-    return L;
-}
 
-__device__ __forceinline__ void flush_counters(uint64_t* counters, const Counters& c, uint32_t rays) {
-    // one atomic per wave and counter
-    uint32_t v[4] = {rays, c.nodes, c.tris, c.insts};
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        uint32_t x = v[k];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
-        if ((threadIdx.x & 63) == 0 && x) atomicAdd((unsigned long long*)&counters[k], (unsigned long long)x);
+        // ---- phase 2: pixels for the lanes that have none ---------------------------------------------
+        // A wave owns one 8x8 tile at a time and hands its 64 positions to idle lanes with a ballot and
+        // an mbcnt-style prefix.  A new tile costs ONE atomic per wave.  The first `static_rounds` tiles
+        // of a wave are dealt round-robin without any atomic (wave w gets tiles w, w + W, ...); the rest
+        // of the image is shared out dynamically from 8 interleaved counters (counter s serves tiles
+        // dyn_first + 8k + s), so that waves with cheap tiles take over work from waves with expensive
+        // ones and no single word has to serve every wave.
+        uint64_t need = __ballot(state == ST_NEED_PIXEL);
+        while (need != 0 && !exhausted) {
+            if (tile_pos >= 64u) {  // the wave's tile is used up: next tile (wave-uniform)
+                if (static_left != 0) {
+                    tile_id = (uint64_t)wave_id + (uint64_t)(static_rounds - static_left) * n_waves;
+                    static_left--;
+                    tile_pos = 0;
+                } else {
+                    bool got = false;
+                    while (qtried < 8u) {
+                        uint32_t k = 0;
+                        if (lane == 0) k = atomicAdd(&work_counters[qslot * 32u], 1u);
+                        k = __shfl(k, 0);
+                        const uint64_t t = dyn_first + (uint64_t)k * 8u + qslot;
+                        if (t < n_tiles) {
+                            tile_id = t;
+                            tile_pos = 0;
+                            got = true;
+                            break;
+                        }
+                        qslot = (qslot + 1u) & 7u;
+                        qtried++;
+                    }
+                    if (!got) {
+                        exhausted = true;
+                        break;
+                    }
+                }
+            }
+            const uint32_t room = 64u - tile_pos;
+            const uint32_t rank_in_need = (uint32_t)__popcll(need & lt_mask);
+            const bool served = (state == ST_NEED_PIXEL) && ((need >> lane) & 1ull) && rank_in_need < room;
+            if (served) {
+                const uint32_t in = tile_pos + rank_in_need;
+                const uint32_t tile = (uint32_t)tile_id;
+                px = (tile % tiles_x) * 8u + (in & 7u);
+                py = (tile / tiles_x) * 8u + (in >> 3);
+                if (px < (uint32_t)width && py < (uint32_t)height) {
+                    pixel = py * (uint32_t)width + px;
+                    bool mine = true;
+                    if (shard.mode == 1) mine = (((py / 64u) * shard_tiles_x + (px / 64u)) % shard.world) == shard.rank;
+                    if (mine) {
+                        acc = mk(0.f, 0.f, 0.f);
+                        sidx = 0;
+                        if (shard.mode == 2)
+                            while (sidx < spp && (sidx % shard.world) != shard.rank) sidx++;
+                        state = ST_NEED_SAMPLE;
+                    } else {  // another rank's tile: this rank's share of the pixel is 0
+                        float* o3 = out + 3 * (size_t)pixel;
+                        o3[0] = 0.f;
+                        o3[1] = 0.f;
+                        o3[2] = 0.f;
+                    }
+                }
+                // positions outside the image (partial tiles) and foreign pixels: the lane asks again
+            }
+            const uint32_t n = (uint32_t)__popcll(need);
+            tile_pos += (n < room) ? n : room;
+            need = __ballot(state == ST_NEED_PIXEL && !served);
+        }
+        if (exhausted && state == ST_NEED_PIXEL) state = ST_DONE;
+        if (__ballot(state != ST_DONE) == 0) break;
+
+        // ---- phase 3: camera ray of the next sample ------------------------------------------------
+        if (state == ST_NEED_SAMPLE && sidx < spp) {
+            P.g = rng_make(seed, pixel, sidx);
+            V3 o, d;
+            camera_ray(c, width, height, (int)px, (int)py, (int)(sidx % (uint32_t)samples),
+                       (int)(sidx / (uint32_t)samples), true, P.g, o, d);
+            P.depth = S.max_bounces;
+            P.sp = 0;
+            P.ior_top = P.ior_below = c.ior;
+            if (P.depth == 0) {  // max_bounces == 0: every path is black (raytracer_cpu.c:247-249)
+                acc = add(acc, mk(0.f, 0.f, 0.f));
+                sidx++;
+            } else {
+                trav_begin(T, S, o, d);
+                rays++;
+                state = ST_TRAVERSE;
+            }
+        }
+
+        // ---- phase 4: traversal, until enough lanes have something else to do ------------------------
+        for (;;) {
+            const uint64_t walking = __ballot(state == ST_TRAVERSE);
+            if (walking == 0) break;
+            const uint64_t waiting = __ballot(state != ST_TRAVERSE && state != ST_DONE);
+            if ((uint32_t)__popcll(waiting) >= refill) break;
+            if (COUNT && (int)lane == __ffsll((long long)walking) - 1) cnt.wave_steps++;
+            if (state == ST_TRAVERSE) {
+                if (trav_step<COUNT>(T, S, cnt)) state = ST_SHADE;
+            }
+        }
+
+        // ---- phase 5: shading / bounce generation ----------------------------------------------------
+        if (state == ST_SHADE) {
+            V3 o = T.wo, d = T.wd;
+            V3 L;
+            if (path_bounce(S, P, T.h, o, d, L, stack, kBlock)) {
+                L = path_fold(S, P, L, stack, kBlock);
+                acc = add(acc, L);
+                sidx++;
+                state = ST_NEED_SAMPLE;
+            } else {
+                trav_begin(T, S, o, d);
+                rays++;
+                state = ST_TRAVERSE;
+            }
+        }
     }
+    if (COUNT) flush_counters(counters, cnt, rays);
 }
 
 // A wave covers an 8x8 pixel tile, a workgroup 16x16, so that the rays of a wave stay close.
@@ -490,16 +208,18 @@ __device__ __forceinline__ bool pixel_of_thread(int width, int height, int& x, i
     return x < width && y < height;
 }
 
-// rt_cpu_raygen, raytracer_cpu.c:179-242: one thread per pixel, samples in the reference's
-// order (y_sample outer, x_sample inner), sum then scale by 1/samples^2.
+// The same renderer with a fixed pixel per thread (wave = 8x8 tile) and no refill: less
+// bookkeeping per path, but a wave is as slow as its longest pixel.  Faster than the persistent
+// kernel when paths are short and neighbouring pixels behave alike.
 template <bool COUNT>
-__global__ __launch_bounds__(kBlock) void cast_kernel(DevScene S, rthip_cast_settings c, uint64_t seed,
-                                                      float* __restrict__ out, int width, int height,
-                                                      rthip_shard shard, uint64_t* counters) {
+__global__ __launch_bounds__(kBlock) void cast_static_kernel(DevScene S, rthip_cast_settings c, uint64_t seed,
+                                                             float* __restrict__ out, int width, int height,
+                                                             rthip_shard shard, uint64_t* counters) {
     extern __shared__ uint32_t bounce_stack[];
+    uint32_t* stack = bounce_stack + threadIdx.x;
     int x, y;
     const bool inside = pixel_of_thread(width, height, x, y);
-    Counters cnt = {0, 0, 0};
+    Counters cnt = {0, 0, 0, 0};
     uint32_t rays = 0;
     if (inside) {
         const int samples = (int)c.samples;
@@ -515,17 +235,30 @@ __global__ __launch_bounds__(kBlock) void cast_kernel(DevScene S, rthip_cast_set
                 for (int xs = 0; xs < samples; xs++) {
                     const uint32_t sidx = (uint32_t)(ys * samples + xs);
                     if (shard.mode == 2 && (sidx % shard.world) != shard.rank) continue;
-                    Rng g = rng_make(seed, pixel, sidx);
+                    PathState P;
+                    P.g = rng_make(seed, pixel, sidx);
                     V3 o, d;
-                    camera_ray(c, width, height, x, y, xs, ys, true, g, o, d);
-                    acc = add(acc, trace_path<COUNT>(S, o, d, c.ior, g, bounce_stack + threadIdx.x, kBlock, cnt, rays));
+                    camera_ray(c, width, height, x, y, xs, ys, true, P.g, o, d);
+                    P.depth = S.max_bounces;
+                    P.sp = 0;
+                    P.ior_top = P.ior_below = c.ior;
+                    V3 L = mk(0.f, 0.f, 0.f);
+                    if (P.depth != 0) {
+                        for (;;) {
+                            rays++;
+                            const Hit h = closest_hit_query<COUNT>(S, o, d, cnt);
+                            if (path_bounce(S, P, h, o, d, L, stack, kBlock)) break;
+                        }
+                        L = path_fold(S, P, L, stack, kBlock);
+                    }
+                    acc = add(acc, L);
                 }
             if (shard.mode != 2) acc = scale(acc, 1.f / ((float)samples * (float)samples));
         }
-        float* px = out + 3 * (size_t)pixel;
-        px[0] = acc.x;
-        px[1] = acc.y;
-        px[2] = acc.z;
+        float* o3 = out + 3 * (size_t)pixel;
+        o3[0] = acc.x;
+        o3[1] = acc.y;
+        o3[2] = acc.z;
     }
     if (COUNT) flush_counters(counters, cnt, rays);
 }
@@ -535,7 +268,7 @@ __global__ __launch_bounds__(kBlock) void primary_hits_kernel(DevScene S, rthip_
                                                               uint32_t* __restrict__ hits4, uint64_t* counters) {
     int x, y;
     const bool inside = pixel_of_thread(width, height, x, y);
-    Counters cnt = {0, 0, 0};
+    Counters cnt = {0, 0, 0, 0};
     uint32_t rays = 0;
     if (inside) {
         rthip_cast_settings c1 = c;
@@ -560,7 +293,7 @@ __global__ __launch_bounds__(kBlock) void trace_rays_kernel(DevScene S, const fl
                                                             uint32_t* __restrict__ hits4, float* __restrict__ uv,
                                                             float* __restrict__ normal, uint64_t* counters) {
     const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-    Counters cnt = {0, 0, 0};
+    Counters cnt = {0, 0, 0, 0};
     uint32_t rays = 0;
     if (i < n) {
         const V3 o = mk(ro[3 * i], ro[3 * i + 1], ro[3 * i + 2]);
@@ -617,12 +350,45 @@ int primary_hits_launch(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_
 
 int cast_launch(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_settings& cast, uint64_t seed, float* d_rgb,
                 int width, int height, rthip_shard shard, uint64_t* d_counters, hipStream_t stream) {
-    const uint32_t blocks = div_up(width, 16) * div_up(height, 16);
+    if (ctx->cast_mode == 2)
+        return cast_wavefront_launch(ctx, scene, cast, seed, d_rgb, width, height, shard, d_counters, stream);
+    const size_t lds_bytes = (size_t)(scene.max_bounces ? scene.max_bounces : 1) * kBlock * sizeof(uint32_t);
+    int mode = ctx->cast_mode;
+    if (mode == 3) {
+        // Paths through a small scene are short and alike, and the pixel-per-thread kernel has the least
+        // bookkeeping per ray; deep scenes (many instances, large meshes) have long-tailed walks that pay
+        // for the persistent kernel's lane refill.
+        mode = (ctx->n_inst >= 64u || ctx->total_tris >= (1ull << 20)) ? 0 : 1;
+    }
+    if (mode == 1) {
+        const uint32_t sblocks = div_up(width, 16) * div_up(height, 16);
+        if (d_counters)
+            cast_static_kernel<true><<<sblocks, kBlock, lds_bytes, stream>>>(scene, cast, seed, d_rgb, width, height, shard, d_counters);
+        else
+            cast_static_kernel<false><<<sblocks, kBlock, lds_bytes, stream>>>(scene, cast, seed, d_rgb, width, height, shard, nullptr);
+        RT_HIP(ctx, hipGetLastError());
+        return RTHIP_OK;
+    }
+    // persistent grid: as many workgroups as are resident at once (256 CUs x 5 at 96 VGPRs), never more than the work
+    const uint64_t total = (uint64_t)div_up(width, 8) * div_up(height, 8) * 64ull;
+    uint32_t blocks = div_up(total, kBlock);
+    if (blocks > ctx->persistent_blocks) blocks = ctx->persistent_blocks;
     const size_t lds = (size_t)(scene.max_bounces ? scene.max_bounces : 1) * kBlock * sizeof(uint32_t);
+    const uint32_t refill = ctx->refill_lanes;
+    // every launch gets its own zeroed set of 8 work counters (one 128-byte line each) out of a small
+    // ring, so that casts enqueued back to back (or on two streams) do not share them
+    uint32_t* work = (uint32_t*)ctx->work_ring.p + (size_t)(ctx->work_next++ % 16u) * 256u;
+    RT_HIP(ctx, hipMemsetAsync(work, 0, 1024, stream));
+    const uint64_t n_tiles = total / 64ull;
+    const uint64_t n_waves = (uint64_t)blocks * (kBlock / 64);
+    // share of the tiles that is dealt round-robin up front (the rest is pulled dynamically)
+    const uint32_t static_rounds = (uint32_t)((n_tiles * ctx->static_percent / 100ull) / n_waves);
     if (d_counters)
-        cast_kernel<true><<<blocks, kBlock, lds, stream>>>(scene, cast, seed, d_rgb, width, height, shard, d_counters);
+        cast_kernel<true><<<blocks, kBlock, lds, stream>>>(scene, cast, seed, d_rgb, width, height, shard, work,
+                                                           static_rounds, refill, d_counters);
     else
-        cast_kernel<false><<<blocks, kBlock, lds, stream>>>(scene, cast, seed, d_rgb, width, height, shard, nullptr);
+        cast_kernel<false><<<blocks, kBlock, lds, stream>>>(scene, cast, seed, d_rgb, width, height, shard, work,
+                                                            static_rounds, refill, nullptr);
     RT_HIP(ctx, hipGetLastError());
     return RTHIP_OK;
 }

@@ -176,5 +176,13 @@ def get_stats(tracer: RT_Tracer) -> dict:
     return {k: st[0][k].item() for k in abi.STATS.names}
 
 
+CAST_KERNELS = {"persistent": 0, "static": 1, "wavefront": 2, "auto": 3}
+
+
+def set_cast_kernel(tracer: RT_Tracer, kernel: str) -> None:
+    """Selects the renderer implementation (all produce the same bits); see include/rthip.h."""
+    tracer.check(tracer.lib.rthip_set_cast_kernel(tracer.h, CAST_KERNELS[kernel]), "rthip_set_cast_kernel")
+
+
 def set_counting(tracer: RT_Tracer, enabled: bool) -> None:
     tracer.check(tracer.lib.rthip_set_counting(tracer.h, 1 if enabled else 0), "rthip_set_counting")

@@ -192,6 +192,45 @@ def test_instanced_scene_and_counters(oracle, gpu_tracer):
     assert (bits(img) == bits(want)).all()
 
 
+@pytest.mark.parametrize("kernel", ["persistent", "static", "wavefront"])
+def test_every_cast_kernel_gives_the_same_bits(oracle, gpu_tracer, kernel):
+    """The three renderer implementations against the oracle: full frames, partial tiles, both shard
+    modes, a scene with refraction/metal (spheres) and one with instances."""
+    import torch
+
+    T.set_cast_kernel(gpu_tracer, kernel)
+    try:
+        verts, indices = scenes.bunny_class_mesh(3)
+        cases = [(scenes.cornell(), 8, (70, 50, 2, 6)), (scenes.spheres(), 8, (64, 40, 2, 3)),
+                 (scenes.instanced_grid(10, seed=2, verts=verts, indices=indices), 4, (90, 60, 1, 8))]
+        for (w, cam, sky), bounces, (wd, ht, smp, seed) in cases:
+            build(gpu_tracer, w, bounces, sky)
+            sc = oracle.Scene(world.flatten_world(w), bounces, sky)
+            c = cam(wd, ht, smp)
+            img = np.zeros((ht, wd, 3), dtype=np.float32)
+            T.rt_tracer_cast(gpu_tracer, c, img, wd, ht, seed=seed)
+            want, _ = sc.cast(c, seed, wd, ht, rng_mode=oracle.RNG_COUNTER, threads=8)
+            assert (bits(img) == bits(want)).all(), f"{kernel}: frame differs"
+            for shard in ((1, 1, 2), (2, 2, 3)):
+                buf = torch.full((ht, wd, 3), 7.0, dtype=torch.float32, device="cuda:0")
+                sh = np.zeros(1, dtype=abi.SHARD)
+                sh[0] = shard
+                rc = gpu_tracer.lib.rthip_cast_device(gpu_tracer.h, abi.ptr(c), seed, buf.data_ptr(), wd, ht, abi.ptr(sh),
+                                                      torch.cuda.current_stream().cuda_stream)
+                gpu_tracer.check(rc, "rthip_cast_device")
+                torch.cuda.synchronize()
+                want, _ = sc.cast(c, seed, wd, ht, rng_mode=oracle.RNG_COUNTER, shard=shard, threads=8)
+                assert (bits(buf.cpu().numpy()) == bits(want)).all(), f"{kernel}: shard {shard} differs"
+        # max_bounces 0: black frame (raytracer_cpu.c:247-249)
+        w, cam, sky = scenes.cornell()
+        build(gpu_tracer, w, 0, sky)
+        img = np.ones((16, 16, 3), dtype=np.float32)
+        T.rt_tracer_cast(gpu_tracer, cam(16, 16, 1), img, 16, 16, seed=1)
+        assert not img.any()
+    finally:
+        T.set_cast_kernel(gpu_tracer, "auto")
+
+
 def test_shards_sum_to_the_frame(oracle, gpu_tracer):
     import ctypes as C
 
