@@ -93,6 +93,19 @@ def build_times(tracer, torch, sizes):
     return out
 
 
+def recorded_traffic(workload: str, kernel_name: str):
+    """HBM bytes per launch of the cast kernel from the PMC passes kept under profiles/ (FETCH_SIZE and
+    WRITE_SIZE, separate rocprofv3 runs of this same command; tools/pmc_traffic.py writes the file).
+    None when no pass was recorded for this workload and kernel."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        table = json.load(f)
+    rec = table.get(workload, {}).get(kernel_name.split(" ")[0])
+    return None if rec is None else rec["hbm_bytes_per_launch"]
+
+
 def cpu_baseline(wl, cast, flat, budget_s=20.0):
     """The CPU path on this box's host cores: the unmodified reference when oracle/_ref travelled
     with the tree (kind 'reference'), otherwise the repo's CPU restatement (kind 'port')."""
@@ -120,6 +133,19 @@ def cpu_baseline(wl, cast, flat, budget_s=20.0):
                            "oracle run with the same glibc rand() stream")
     return dict(value=round(rays / port_s / 1e6, 3), unit="Mrays/s", cores=1, kind="port",
                 sample=f"the full {W}x{H} frame of the same workload, one pass of the CPU restatement")
+
+
+def cpu_port_parallel(wl, cast, flat, threads):
+    """The CPU restatement row-parallel over the host cores (the reference itself is single-threaded)."""
+    from oracle import oracle as O
+
+    W, H = wl["width"], wl["height"]
+    ora = O.Scene(flat, wl["bounces"], wl["sky"])
+    t0 = time.time()
+    _, cnt = ora.cast(cast, 1, W, H, rng_mode=O.RNG_COUNTER, threads=threads)
+    sec = time.time() - t0
+    return dict(value=round(cnt["rays"] / sec / 1e6, 3), unit="Mrays/s", cores=threads, kind="port",
+                sample=f"the full {W}x{H} frame, one pass, rows dealt to {threads} threads")
 
 
 def main():
@@ -157,19 +183,27 @@ def main():
     cast = wl["cam"](W, H, wl["samples"])
     flat = Wd.flatten_world(wl["world"])
 
-    fb = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+    # two framebuffers: the RCCL reduce of frame k overlaps the render of frame k + 1
+    pipe = rdist.FramePipeline([torch.zeros((H, W, 3), dtype=torch.float32, device="cuda") for _ in range(2)],
+                               "frames", wl["samples"], world, dst=0)
     stream = torch.cuda.current_stream()
     seed = 1 + rank
 
-    def step():
+    def step(events=None):
+        fb = pipe.acquire()
+        if events:
+            events[0].record(stream)
         rc = tr.lib.rthip_cast_device(tr.h, abi.ptr(cast), seed, fb.data_ptr(), W, H, None, stream.cuda_stream)
+        if events:
+            events[1].record(stream)
         tr.check(rc, "rthip_cast_device")
-        rdist.combine_framebuffer(fb, "frames", wl["samples"], world, dst=0)
+        pipe.submit(fb)
 
     # traversal counters of this rank's frame (untimed launch with counting on)
     T.set_counting(tr, True)
     T.get_stats(tr)
     step()
+    pipe.drain()
     torch.cuda.synchronize()
     st = T.get_stats(tr)
     T.set_counting(tr, False)
@@ -178,17 +212,15 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    pipe.drain()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for k in range(args.steps):
-        ev[k][0].record(stream)
-        rc = tr.lib.rthip_cast_device(tr.h, abi.ptr(cast), seed, fb.data_ptr(), W, H, None, stream.cuda_stream)
-        ev[k][1].record(stream)
-        tr.check(rc, "rthip_cast_device")
-        rdist.combine_framebuffer(fb, "frames", wl["samples"], world, dst=0)
+        step(ev[k])
+    pipe.drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -204,6 +236,9 @@ def main():
     elapsed = float(t_all.item())
     total_rays = float(r_all.item())
 
+    kernel_name = {0: "cast_kernel (persistent)", 1: "cast_static_kernel", 2: "wf_trace_kernel + wf_shade_kernel (wavefront)"}[
+        T.get_stats(tr)["last_cast_kernel"]]
+    traffic = recorded_traffic(args.workload, kernel_name)
     if rank == 0:
         value = total_rays * args.steps / elapsed / 1e6
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
@@ -223,7 +258,7 @@ def main():
             "config": {"workload": wl["label"], "rays_per_frame_per_gpu": int(rays), "sharding": "every rank renders the "
                        "frame with its own sample set; framebuffers summed onto rank 0 with RCCL" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "kernel": "cast_kernel",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "kernel": kernel_name,
                          "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": int(algo_bytes),
                          "per_ray": {"nodes": round(st["nodes_tested"] / max(rays, 1), 2),
                                      "triangles": round(st["tris_tested"] / max(rays, 1), 3),
@@ -237,6 +272,8 @@ def main():
             line["lbvh_build_ms_per_1M_triangles"] = line["lbvh_build"][big]["ms_per_1M"]
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(wl, cast, flat)
+            threads = min(16, os.cpu_count() or 1)  # the box's CPU share for one GPU
+            line["cpu_port_all_cores"] = cpu_port_parallel(wl, cast, flat, threads)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -128,6 +128,8 @@ typedef struct rthip_stats {
                                nodes_tested / (64 * wave_steps) = lane utilisation */
     float last_cast_ms;     /* device time of the last cast / trace kernel(s) */
     float last_build_ms;    /* device time of the last LBVH build             */
+    uint32_t last_cast_kernel; /* RTHIP_KERNEL_* the last cast ran (never AUTO)  */
+    uint32_t reserved;
 } rthip_stats;
 
 typedef struct rthip_ctx rthip_ctx;

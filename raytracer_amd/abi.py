@@ -40,11 +40,12 @@ SHARD = np.dtype([("mode", "<u4"), ("rank", "<u4"), ("world", "<u4")], align=Fal
 # rthip_stats
 STATS = np.dtype(
     [("rays", "<u8"), ("nodes_tested", "<u8"), ("tris_tested", "<u8"), ("inst_entered", "<u8"),
-     ("wave_steps", "<u8"), ("last_cast_ms", "<f4"), ("last_build_ms", "<f4")],
+     ("wave_steps", "<u8"), ("last_cast_ms", "<f4"), ("last_build_ms", "<f4"),
+     ("last_cast_kernel", "<u4"), ("reserved", "<u4")],
     align=False,
 )
 assert MATERIAL.itemsize == 40 and INSTANCE.itemsize == 68 and CAST.itemsize == 84
-assert NODE.itemsize == 32 and SHARD.itemsize == 12 and STATS.itemsize == 48
+assert NODE.itemsize == 32 and SHARD.itemsize == 12 and STATS.itemsize == 56
 
 MAT_LAMBERTIAN, MAT_DIELECTRIC, MAT_METAL, MAT_NORMAL, MAT_LIGHT = range(5)
 INST_SPHERE, INST_MESH = 0, 1

@@ -522,6 +522,8 @@ int rthip_get_stats(rthip_ctx* ctx, rthip_stats* out) {
     out->wave_steps = c[4];
     out->last_cast_ms = ctx->last_cast_ms;
     out->last_build_ms = ctx->last_build_ms;
+    out->last_cast_kernel = ctx->last_cast_kernel;
+    out->reserved = 0;
     return RTHIP_OK;
 }
 

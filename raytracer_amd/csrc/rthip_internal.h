@@ -135,6 +135,7 @@ struct rthip_ctx {
     uint32_t refill_lanes = 16;  // lanes with other work that end a traversal phase (RTHIP_REFILL overrides)
     DevBuf scratch_a, scratch_b, scratch_c, scratch_d, scratch_e;  // staging for host <-> device taps
     float last_cast_ms = 0.f, last_build_ms = 0.f;
+    uint32_t last_cast_kernel = 0;
 };
 
 // ---- helpers (rthip_api.hip) -------------------------------------------------

@@ -350,6 +350,7 @@ int primary_hits_launch(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_
 
 int cast_launch(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_settings& cast, uint64_t seed, float* d_rgb,
                 int width, int height, rthip_shard shard, uint64_t* d_counters, hipStream_t stream) {
+    ctx->last_cast_kernel = 2;
     if (ctx->cast_mode == 2)
         return cast_wavefront_launch(ctx, scene, cast, seed, d_rgb, width, height, shard, d_counters, stream);
     const size_t lds_bytes = (size_t)(scene.max_bounces ? scene.max_bounces : 1) * kBlock * sizeof(uint32_t);
@@ -360,6 +361,7 @@ int cast_launch(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_settings
         // for the persistent kernel's lane refill.
         mode = (ctx->n_inst >= 64u || ctx->total_tris >= (1ull << 20)) ? 0 : 1;
     }
+    ctx->last_cast_kernel = (uint32_t)mode;
     if (mode == 1) {
         const uint32_t sblocks = div_up(width, 16) * div_up(height, 16);
         if (d_counters)

@@ -38,3 +38,60 @@ def combine_framebuffer(fb, mode: str, samples: int, world: int, dst: int = 0):
             elif mode == "frames":
                 fb.mul_(1.0 / float(world))
     return fb
+
+
+class FramePipeline:
+    """Frames in flight: the collective of frame k runs while frame k + 1 is rendered.
+
+    `buffers` are framebuffer tensors of one shape (two are enough).  Per frame the caller does
+
+        fb = pipe.acquire()      # a buffer whose previous reduce has finished (stream-ordered on a GPU)
+        ... render into fb ...
+        pipe.submit(fb)          # starts the asynchronous SUM onto dst
+
+    and `drain()` at the end, which returns the last combined frame (meaningful on dst).  On the
+    "nccl" (RCCL) backend `wait()` only makes the current stream wait for the collective, so the host
+    keeps enqueueing; on "gloo" it blocks, which is all a CPU rehearsal needs.
+    """
+
+    def __init__(self, buffers, mode: str, samples: int, world: int, dst: int = 0):
+        assert len(buffers) >= 1
+        self.buffers = list(buffers)
+        self.pending = [None] * len(self.buffers)
+        self.mode, self.samples, self.world, self.dst = mode, samples, world, dst
+        self.next = 0
+        self.last = None
+
+    def _finish(self, k: int) -> None:
+        work = self.pending[k]
+        if work is None:
+            return
+        import torch.distributed as dist
+
+        work.wait()
+        self.pending[k] = None
+        if dist.get_rank() == self.dst:
+            if self.mode == "samples":
+                self.buffers[k].mul_(1.0 / float(self.samples * self.samples))
+            elif self.mode == "frames":
+                self.buffers[k].mul_(1.0 / float(self.world))
+
+    def acquire(self):
+        k = self.next
+        self._finish(k)
+        return self.buffers[k]
+
+    def submit(self, fb) -> None:
+        k = self.next
+        assert fb is self.buffers[k], "submit the buffer acquire() returned"
+        if self.world > 1:
+            import torch.distributed as dist
+
+            self.pending[k] = dist.reduce(fb, dst=self.dst, op=dist.ReduceOp.SUM, async_op=True)
+        self.last = k
+        self.next = (k + 1) % len(self.buffers)
+
+    def drain(self):
+        for k in range(len(self.buffers)):
+            self._finish(k)
+        return None if self.last is None else self.buffers[self.last]

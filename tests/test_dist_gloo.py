@@ -73,3 +73,32 @@ def test_frame_replicas_average(tmp_path):
     got = _run("frames", tmp_path)
     want = (_full(5).astype(np.float32) + _full(6).astype(np.float32)) * np.float32(0.5)
     assert np.allclose(got, want, rtol=1e-6, atol=1e-7)
+
+
+def _pipeline_worker(rank, world_size, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    bufs = [torch.zeros((8, 8, 3)), torch.zeros((8, 8, 3))]
+    pipe = rdist.FramePipeline(bufs, "frames", 1, world_size, dst=0)
+    seen = []
+    for frame in range(5):
+        fb = pipe.acquire()
+        if rank == 0 and frame >= 2:  # the buffer comes back holding the combined frame of two frames ago
+            seen.append(float(fb[0, 0, 0]))
+        fb.fill_(float(10 * frame + rank))  # what a render of this frame on this rank would have left
+        pipe.submit(fb)
+    last = pipe.drain()
+    if rank == 0:
+        seen.append(float(last[0, 0, 0]))
+        np.save(os.path.join(out_dir, "pipe.npy"), np.array(seen, dtype=np.float64))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_frame_pipeline_keeps_frames_apart(tmp_path):
+    port = _free_port()
+    mp.spawn(_pipeline_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    got = np.load(os.path.join(str(tmp_path), "pipe.npy"))
+    # mean over the two ranks of 10 * frame + rank = 10 * frame + 0.5, for frames 0, 1, 2 and the last one (4)
+    assert np.allclose(got, [0.5, 10.5, 20.5, 40.5])
