@@ -50,6 +50,17 @@ def make_workload(name: str):
         w, cam, sky = scenes.soup_world(10_000_000, seed=1)
         return dict(world=w, cam=cam, sky=sky, width=1920, height=1080, samples=1, bounces=4,
                     label="10M-triangle soup (1 BLAS), 1920x1080, samples=1, bounces=4, sky on")
+    if name == "soup-rays":
+        w, cam, sky = scenes.soup_world(10_000_000, seed=1)
+        return dict(world=w, cam=cam, sky=sky, width=4096, height=4096, samples=1, bounces=1, rays=1 << 24,
+                    label="10M-triangle soup (1 BLAS), 2^24 incoherent rays: origins uniform in the scene box, directions "
+                          "uniform on the sphere (closest-hit queries through rthip_trace_rays_device)")
+    if name == "instanced-rays":
+        verts, idx = scenes.bunny_class_mesh()
+        w, cam, sky = scenes.instanced_grid(100, seed=1, verts=verts, indices=idx)
+        return dict(world=w, cam=cam, sky=sky, width=4096, height=1024, samples=1, bounces=1, rays=1 << 22,
+                    ray_box=((-125.0, -1.0, -125.0), (125.0, 3.0, 125.0)),
+                    label="bunny-class mesh x 10000 instances, 2^22 incoherent rays through the grid's box")
     if name == "cornell":
         w, cam, sky = scenes.cornell()
         return dict(world=w, cam=cam, sky=sky, width=512, height=512, samples=2, bounces=8,
@@ -93,6 +104,52 @@ def build_times(tracer, torch, sizes):
     return out
 
 
+def camera_rays_torch(torch, cast, W, H):
+    """Pixel-centre camera rays as device tensors (same construction as rt_cpu_raygen with samples = 1)."""
+    c = cast[0]
+    f = lambda k: torch.tensor(np.asarray(c[k], dtype=np.float32), device="cuda")
+    xs = (torch.arange(W, device="cuda", dtype=torch.float32) + 0.5) / W
+    ys = (torch.arange(H, device="cuda", dtype=torch.float32) + 0.5) / H
+    ndc_x = (2 * xs - 1)[None, :].expand(H, W)
+    ndc_y = (1 - 2 * ys)[:, None].expand(H, W)
+    vp = f("viewport")
+    sample = (f("eye")[None, None, :] + f("right")[None, None, :] * (ndc_x * vp[0])[..., None]
+              + f("up")[None, None, :] * (ndc_y * vp[1])[..., None] + f("forward")[None, None, :] * vp[2])
+    origin = f("eye")[None, None, :].expand(H, W, 3)
+    d = sample - origin
+    d = d / d.norm(dim=2, keepdim=True)
+    return origin.reshape(-1, 3).contiguous(), d.reshape(-1, 3).contiguous()
+
+
+def shadow_ray_rate(tr, torch, cast, W, H, steps):
+    """Config 2's shadow rays: from every primary hit point towards a directional light, answered by the
+    any-hit kernel (rthip_occluded_device).  Reported beside the headline, never mixed into it."""
+    stream = torch.cuda.current_stream()
+    o, d = camera_rays_torch(torch, cast, W, H)
+    hits = torch.zeros((W * H, 4), dtype=torch.int32, device="cuda")
+    tr.check(tr.lib.rthip_trace_rays_device(tr.h, o.data_ptr(), d.data_ptr(), W * H, hits.data_ptr(), stream.cuda_stream), "trace")
+    torch.cuda.synchronize()
+    hit = hits[:, 0] != 0
+    t = hits[:, 2].view(torch.float32)
+    so = (o + d * (t[:, None] - 1e-3))[hit].contiguous()
+    light = torch.tensor([0.5, 1.0, 0.3], device="cuda")
+    sd = (light / light.norm())[None, :].expand(so.shape[0], 3).contiguous()
+    n = so.shape[0]
+    out = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for it in range(steps + 2):
+        if it == 2:
+            e0.record(stream)
+        tr.check(tr.lib.rthip_occluded_device(tr.h, so.data_ptr(), sd.data_ptr(), n, 3.402823466e+38, out.data_ptr(),
+                                              stream.cuda_stream), "rthip_occluded_device")
+    e1.record(stream)
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    return dict(rays=int(n), kernel_ms=round(ms, 4), value=round(n / ms / 1e3, 2), unit="Mrays/s",
+                occluded_fraction=round(float(out.float().mean().item()), 4),
+                what="any-hit occlusion rays from the primary hit points towards a directional light, occlusion_kernel")
+
+
 def recorded_traffic(workload: str, kernel_name: str):
     """HBM bytes per launch of the cast kernel from the PMC passes kept under profiles/ (FETCH_SIZE and
     WRITE_SIZE, separate rocprofv3 runs of this same command; tools/pmc_traffic.py writes the file).
@@ -133,6 +190,24 @@ def cpu_baseline(wl, cast, flat, budget_s=20.0):
                            "oracle run with the same glibc rand() stream")
     return dict(value=round(rays / port_s / 1e6, 3), unit="Mrays/s", cores=1, kind="port",
                 sample=f"the full {W}x{H} frame of the same workload, one pass of the CPU restatement")
+
+
+def cpu_baseline_rays(wl, flat, o, d, sample=1 << 16):
+    """Ray-stream workloads: the reference's TLAS query on the first `sample` rays, one core."""
+    from oracle import oracle as O
+
+    if O.have_ref("core"):
+        rs = O.RefScene(flat, wl["bounces"], wl["sky"])
+        sec = rs.trace(o[:sample], d[:sample], want_normal=False)[5]
+        kind = "reference"
+    else:
+        ora = O.Scene(flat, wl["bounces"], wl["sky"])
+        t0 = time.time()
+        ora.trace(o[:sample], d[:sample], want_normal=False)
+        sec = time.time() - t0
+        kind = "port"
+    return dict(value=round(sample / sec / 1e6, 4), unit="Mrays/s", cores=1, kind=kind,
+                sample=f"the first {sample} rays of the same ray stream, one pass")
 
 
 def cpu_port_parallel(wl, cast, flat, threads):
@@ -189,7 +264,27 @@ def main():
     stream = torch.cuda.current_stream()
     seed = 1 + rank
 
+    ray_o = ray_d = ray_hits = None
+    if "rays" in wl:  # a ray-stream workload: closest-hit queries for explicit rays instead of a frame
+        g = torch.Generator(device="cuda")
+        g.manual_seed(2 + rank)
+        lo, hi = wl.get("ray_box", ((0.0, 0.0, 0.0), (1.0, 1.0, 1.0)))
+        lo, hi = torch.tensor(lo, device="cuda"), torch.tensor(hi, device="cuda")
+        ray_o = (lo + torch.rand((wl["rays"], 3), device="cuda", generator=g) * (hi - lo)).contiguous()
+        v = torch.randn((wl["rays"], 3), device="cuda", generator=g)
+        ray_d = (v / v.norm(dim=1, keepdim=True)).contiguous()
+        ray_hits = torch.zeros((wl["rays"], 4), dtype=torch.int32, device="cuda")
+
     def step(events=None):
+        if ray_o is not None:
+            if events:
+                events[0].record(stream)
+            rc = tr.lib.rthip_trace_rays_device(tr.h, ray_o.data_ptr(), ray_d.data_ptr(), wl["rays"], ray_hits.data_ptr(),
+                                                stream.cuda_stream)
+            if events:
+                events[1].record(stream)
+            tr.check(rc, "rthip_trace_rays_device")
+            return
         fb = pipe.acquire()
         if events:
             events[0].record(stream)
@@ -238,6 +333,8 @@ def main():
 
     kernel_name = {0: "cast_kernel (persistent)", 1: "cast_static_kernel", 2: "wf_trace_kernel + wf_shade_kernel (wavefront)"}[
         T.get_stats(tr)["last_cast_kernel"]]
+    if ray_o is not None:
+        kernel_name = "trace_rays_kernel"
     traffic = recorded_traffic(args.workload, kernel_name)
     if rank == 0:
         value = total_rays * args.steps / elapsed / 1e6
@@ -270,7 +367,11 @@ def main():
             line["lbvh_build"] = build_times(tr, torch, [int(s) for s in args.build_sizes.split(",") if s])
             big = max(line["lbvh_build"], key=lambda k: int(k))
             line["lbvh_build_ms_per_1M_triangles"] = line["lbvh_build"][big]["ms_per_1M"]
-        if not args.no_cpu_baseline:
+        if args.workload == "bunny":
+            line["shadow_rays"] = shadow_ray_rate(tr, torch, cast, W, H, args.steps)
+        if not args.no_cpu_baseline and ray_o is not None:
+            line["cpu_baseline"] = cpu_baseline_rays(wl, flat, ray_o[: 1 << 16].cpu().numpy(), ray_d[: 1 << 16].cpu().numpy())
+        if not args.no_cpu_baseline and ray_o is None:
             line["cpu_baseline"] = cpu_baseline(wl, cast, flat)
             threads = min(16, os.cpu_count() or 1)  # the box's CPU share for one GPU
             line["cpu_port_all_cores"] = cpu_port_parallel(wl, cast, flat, threads)

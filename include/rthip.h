@@ -234,6 +234,15 @@ int rthip_trace_rays(rthip_ctx* ctx, const float* origins, const float* directio
 int rthip_trace_rays_device(rthip_ctx* ctx, const float* d_origins, const float* d_directions, uint64_t n,
                             uint32_t* d_hits, void* stream);
 
+/* Occlusion ("shadow") rays: out[i] = 1 when the TLAS query of rt_cpu_intersect
+ * (raytracer_cpu.c:402-407: lbvh_query_ray with rt_cpu_tlas_hit) run over the interval
+ * [EPSILON_F32, tmax] instead of [EPSILON_F32, MAX_F32] would report a hit, else 0.  The
+ * reference itself casts no shadow rays; this is that same query stopped at the first
+ * accepted primitive.  Directions need not be normalised (t is in units of |direction|). */
+int rthip_occluded(rthip_ctx* ctx, const float* origins, const float* directions, uint64_t n, float tmax, uint8_t* out);
+int rthip_occluded_device(rthip_ctx* ctx, const float* d_origins, const float* d_directions, uint64_t n, float tmax,
+                          uint8_t* d_out, void* stream);
+
 /* Reads (and clears) the traversal counters; blocks until the context's work is done. */
 int rthip_get_stats(rthip_ctx* ctx, rthip_stats* out);
 /* Turns traversal counting on or off (off by default: counting costs atomics). */

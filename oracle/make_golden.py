@@ -148,9 +148,52 @@ def write_bunny():
     print("bunny-class", int(out["ref_1080_hits"]), "hits at 1080p; ref trace seconds", float(out["ref_1080_trace_seconds"]))
 
 
+def shadow_rays(rs, cast, W, H, target=None, direction=None):
+    """Shadow rays from the reference's own primary hit points (offset along the shading normal)."""
+    o, d = O.primary_rays(cast, W, H)
+    inst, tri, t, uv, nrm, _ = rs.trace(o, d)
+    hit = inst > 0
+    p = (o[hit] + d[hit] * t[hit, None]).astype(np.float32)
+    n = nrm[hit]
+    n = np.where(((n * d[hit]).sum(axis=1) > 0)[:, None], -n, n).astype(np.float32)  # face the viewer
+    so = (p + n * np.float32(0.001)).astype(np.float32)
+    if target is not None:
+        sd = (np.asarray(target, dtype=np.float32)[None, :] - so).astype(np.float32)  # unnormalised: t = 1 at the target
+    else:
+        sd = np.tile(np.asarray(direction, dtype=np.float32), (so.shape[0], 1))
+    return so, sd
+
+
+def write_occlusion():
+    """Occlusion fixtures: the reference's TLAS query with the interval [EPSILON_F32, tmax] -> hit or not."""
+    out = {}
+    w, cam, sky = scenes.cornell()
+    rs = O.RefScene(world.flatten_world(w), 8, sky)
+    so, sd = shadow_rays(rs, cam(64, 64, 1), 64, 64, target=(0.0, 270.0, 0.0))
+    out.update(cornell_o=so, cornell_d=sd)
+    for k, tmax in enumerate((0.5, 1.0, 3.402823466e+38)):
+        out[f"cornell_tmax{k}"] = np.float32(tmax)
+        out[f"cornell_ref_occluded{k}"] = rs.occluded(so, sd, tmax)
+    verts, indices = scenes.bunny_class_mesh()
+    w, cam, sky = scenes.bunny(verts, indices)
+    rs = O.RefScene(world.flatten_world(w), 2, sky)
+    so, sd = shadow_rays(rs, cam(160, 90, 1), 160, 90, direction=(0.5, 1.0, 0.3))
+    out.update(bunny_o=so, bunny_d=sd)
+    for k, tmax in enumerate((0.002, 0.03, 3.402823466e+38)):
+        out[f"bunny_tmax{k}"] = np.float32(tmax)
+        out[f"bunny_ref_occluded{k}"] = rs.occluded(so, sd, tmax)
+    np.savez_compressed(os.path.join(OUT, "occlusion.npz"), **out)
+    print("occlusion:", {k: int(v.sum()) for k, v in out.items() if "ref_occluded" in k}, "of", out["cornell_o"].shape[0],
+          out["bunny_o"].shape[0])
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     assert O.have_ref("core"), "build oracle/_ref first: make -C oracle ref"
+    if len(sys.argv) > 1 and sys.argv[1] == "occlusion":
+        write_occlusion()
+        sys.exit(0)
     write_lbvh()
     write_demos()
     write_bunny()
+    write_occlusion()

@@ -86,6 +86,8 @@ def lib() -> C.CDLL:
         L.ora_scene_trace.restype = None
         L.ora_scene_trace.argtypes = [_P, _P, _P, C.c_uint64, _P, _P, _P, _P, _P, _P, C.c_int]
         L.ora_primary_rays.restype = None
+        L.ora_scene_occluded.restype = None
+        L.ora_scene_occluded.argtypes = [_P, _P, _P, C.c_uint64, C.c_float, _P]
         L.ora_primary_rays.argtypes = [_P, C.c_int, C.c_int, _P, _P]
         L.ora_scene_cast.restype = None
         L.ora_scene_cast.argtypes = [_P, _P, C.c_uint64, C.c_int, _P, C.c_int, C.c_int, _P, C.c_int, _P]
@@ -217,6 +219,13 @@ class Scene:
                               abi.ptr(nrm), abi.ptr(cnt), threads)
         return inst, tri, t, uv, nrm, {k: int(cnt[0][k]) for k in COUNTERS.names}
 
+    def occluded(self, o, d, tmax):
+        o = np.ascontiguousarray(o, dtype=np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(d, dtype=np.float32).reshape(-1, 3)
+        out = np.zeros(o.shape[0], dtype=np.uint8)
+        lib().ora_scene_occluded(self.h, abi.ptr(o), abi.ptr(d), o.shape[0], float(tmax), abi.ptr(out))
+        return out
+
     def cast(self, cast, seed, width, height, rng_mode=RNG_COUNTER, shard=None, threads=1):
         cast = np.ascontiguousarray(cast, dtype=abi.CAST).reshape(1)
         out = np.zeros((height, width, 3), dtype=np.float32)
@@ -274,6 +283,9 @@ def ref(name: str = "core") -> C.CDLL:
             L.ref_scene_cast.argtypes = [_P, _P, C.c_int, _P, C.c_int, C.c_int, C.c_char_p]
             L.ref_scene_trace.restype = C.c_double
             L.ref_scene_trace.argtypes = [_P, _P, _P, C.c_uint64, _P, _P, _P, _P, _P]
+            if hasattr(L, "ref_scene_occluded"):
+                L.ref_scene_occluded.restype = None
+                L.ref_scene_occluded.argtypes = [_P, _P, _P, C.c_uint64, C.c_float, _P]
             L.ref_scene_dump_tree.argtypes = [_P, C.c_int, _P, C.c_uint64, _P]
             L.ref_load_obj.argtypes = [C.c_char_p, C.c_uint32, _P, C.c_uint64, _P, _P, C.c_uint64, _P]
         else:
@@ -344,6 +356,13 @@ class RefScene:
         sec = self.L.ref_scene_trace(self.h, abi.ptr(o), abi.ptr(d), n, abi.ptr(inst), abi.ptr(tri), abi.ptr(t),
                                      abi.ptr(uv), abi.ptr(nrm))
         return inst, tri, t, uv, nrm, sec
+
+    def occluded(self, o, d, tmax):
+        o = np.ascontiguousarray(o, dtype=np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(d, dtype=np.float32).reshape(-1, 3)
+        out = np.zeros(o.shape[0], dtype=np.uint8)
+        self.L.ref_scene_occluded(self.h, abi.ptr(o), abi.ptr(d), o.shape[0], float(tmax), abi.ptr(out))
+        return out
 
     def cast(self, cast, seed, width, height, workdir=None):
         cast = np.ascontiguousarray(cast, dtype=abi.CAST).reshape(1)

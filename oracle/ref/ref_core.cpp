@@ -339,6 +339,22 @@ double ref_scene_cast(void* scene, const rthip_cast_settings* cast, int seed, fl
 
 // rt_cpu_intersect for caller-supplied rays, plus the TLAS-level record
 // (instance id, tri_idx, uv) that rt_cpu_intersect consumes internally.
+// lbvh_query_ray over the reference-built TLAS with the interval [EPSILON_F32, tmax]: hit or not
+void ref_scene_occluded(void* scene, const float* o3, const float* d3, uint64_t n, float tmax, uint8_t* out) {
+    RefScene* s = (RefScene*)scene;
+    RT_CPU_Tracer* tr = rt_cpu_handle_to_tracer(s->tracer);
+    for (uint64_t i = 0; i < n; i++) {
+        rng3_f32 ray;
+        ray.origin = make_3f32(o3[3 * i], o3[3 * i + 1], o3[3 * i + 2]);
+        ray.direction = make_3f32(d3[3 * i], d3[3 * i + 1], d3[3 * i + 2]);
+        rng_f32 iv = geo_make_pos_interval();
+        iv.max = tmax;
+        RT_CPU_TLASData data = {};
+        data.tlas = &tr->tlas;
+        out[i] = lbvh_query_ray(&tr->tlas.lbvh, &ray, &iv, &rt_cpu_tlas_hit, (void*)&data) != 0 ? 1 : 0;
+    }
+}
+
 double ref_scene_trace(void* scene, const float* o3, const float* d3, uint64_t n, uint32_t* out_inst,
                        uint32_t* out_tri, float* out_t, float* out_uv, float* out_normal) {
     RefScene* s = (RefScene*)scene;

@@ -545,8 +545,8 @@ static int blas_query(const ora_mesh* m, const ray_t* r, float tmin, float* tmax
     return any;
 }
 
-static void tlas_query(const ora_scene* s, const ray_t* r, tlas_hit* h, ora_counters* cnt) {
-    float tmin = ORA_EPS, tmax = ORA_MAXF; /* geo_make_pos_interval, geo.c:28-30 */
+static void tlas_query_interval(const ora_scene* s, const ray_t* r, float tmax, tlas_hit* h, ora_counters* cnt) {
+    float tmin = ORA_EPS; /* geo_make_pos_interval, geo.c:28-30, with a caller-chosen upper end */
     memset(h, 0, sizeof *h);
     cnt->rays++;
     uint64_t i = 0, end = s->n_tlas;
@@ -590,6 +590,10 @@ static void tlas_query(const ora_scene* s, const ray_t* r, tlas_hit* h, ora_coun
         }
     }
     h->t = tmax;
+}
+
+static void tlas_query(const ora_scene* s, const ray_t* r, tlas_hit* h, ora_counters* cnt) {
+    tlas_query_interval(s, r, ORA_MAXF, h, cnt);
 }
 
 typedef struct { v3 p, n; float t; int32_t material; } hit_record;
@@ -683,6 +687,20 @@ void ora_scene_trace(const ora_scene* s, const float* o3, const float* d3, uint6
         total.inst_entered += jobs[k].cnt.inst_entered;
     }
     if (counters) *counters = total;
+}
+
+/* Occlusion: does lbvh_query_ray (lbvh.c:163-165) over the TLAS with the interval
+ * [EPSILON_F32, tmax] report a hit?  The walk up to the first accepted primitive does not
+ * depend on what comes after it, so "some primitive is accepted" is what an any-hit walk
+ * that stops there computes. */
+void ora_scene_occluded(const ora_scene* s, const float* o3, const float* d3, uint64_t n, float tmax, uint8_t* out) {
+    ora_counters cnt = {0, 0, 0, 0};
+    for (uint64_t i = 0; i < n; i++) {
+        ray_t r = {V3(o3[3 * i], o3[3 * i + 1], o3[3 * i + 2]), V3(d3[3 * i], d3[3 * i + 1], d3[3 * i + 2])};
+        tlas_hit h;
+        tlas_query_interval(s, &r, tmax, &h, &cnt);
+        out[i] = h.hit ? 1 : 0;
+    }
 }
 
 /* ======================================================================== */

@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "librthip.so")
+LIB_PATH = os.environ.get("RTHIP_LIBRARY", os.path.join(HERE, "librthip.so"))  # override: a development build
 
 # rthip_material (RT_Material, src/raytracer/raytracer_core.h:74-84)
 MATERIAL = np.dtype(
@@ -71,6 +71,8 @@ SYMBOLS = [
     ("rthip_primary_hits", C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int]),
     ("rthip_trace_rays", C.c_int, [_P, _P, _P, C.c_uint64, _P, _P, _P, _P, _P]),
     ("rthip_trace_rays_device", C.c_int, [_P, _P, _P, C.c_uint64, _P, _P]),
+    ("rthip_occluded", C.c_int, [_P, _P, _P, C.c_uint64, C.c_float, _P]),
+    ("rthip_occluded_device", C.c_int, [_P, _P, _P, C.c_uint64, C.c_float, _P, _P]),
     ("rthip_get_stats", C.c_int, [_P, _P]),
     ("rthip_set_counting", C.c_int, [_P, C.c_int]),
     ("rthip_set_cast_kernel", C.c_int, [_P, C.c_int]),

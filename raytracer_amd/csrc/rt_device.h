@@ -76,27 +76,24 @@ struct Counters {
 
 // lbvh_aabb_query_ray, lbvh.c:127-149, with 1/d hoisted (the same correctly rounded
 // quotient every time, so hoisting does not change a bit).  Works on a copy of the
-// interval, as the reference does.
+// interval, as the reference does.  Written with selects instead of the reference's nested
+// ifs: `t0 < t1 ? (t0, t1) : (t1, t0)` picks the same candidates, the two strict comparisons
+// update the interval exactly when the reference's do (a NaN candidate, from 0 * inf, fails them
+// and changes nothing), and because the lower end only rises and the upper end only falls, one
+// `max < min` test after the third axis rejects exactly the boxes the reference rejects after
+// the first axis that empties the interval.
+__device__ __forceinline__ void slab_axis(float lo, float hi, float o, float inv, float& tmin, float& tmax) {
+    const float t0 = (lo - o) * inv, t1 = (hi - o) * inv;
+    const bool ordered = t0 < t1;
+    const float near = ordered ? t0 : t1, far = ordered ? t1 : t0;
+    tmin = (near > tmin) ? near : tmin;
+    tmax = (far < tmax) ? far : tmax;
+}
 __device__ __forceinline__ bool slab(float4 lo, float4 hi, V3 o, V3 inv, float tmin, float tmax) {
-    {
-        float t0 = (lo.x - o.x) * inv.x, t1 = (hi.x - o.x) * inv.x;
-        if (t0 < t1) { if (t0 > tmin) tmin = t0; if (t1 < tmax) tmax = t1; }
-        else         { if (t1 > tmin) tmin = t1; if (t0 < tmax) tmax = t0; }
-        if (tmax < tmin) return false;
-    }
-    {
-        float t0 = (lo.y - o.y) * inv.y, t1 = (hi.y - o.y) * inv.y;
-        if (t0 < t1) { if (t0 > tmin) tmin = t0; if (t1 < tmax) tmax = t1; }
-        else         { if (t1 > tmin) tmin = t1; if (t0 < tmax) tmax = t0; }
-        if (tmax < tmin) return false;
-    }
-    {
-        float t0 = (lo.z - o.z) * inv.z, t1 = (hi.z - o.z) * inv.z;
-        if (t0 < t1) { if (t0 > tmin) tmin = t0; if (t1 < tmax) tmax = t1; }
-        else         { if (t1 > tmin) tmin = t1; if (t0 < tmax) tmax = t0; }
-        if (tmax < tmin) return false;
-    }
-    return true;
+    slab_axis(lo.x, hi.x, o.x, inv.x, tmin, tmax);
+    slab_axis(lo.y, hi.y, o.y, inv.y, tmin, tmax);
+    slab_axis(lo.z, hi.z, o.z, inv.z, tmin, tmax);
+    return !(tmax < tmin);
 }
 
 // geo_intersect_tri, src/geo/geo.c:72-109
@@ -268,6 +265,23 @@ __device__ __forceinline__ Hit closest_hit_query(const DevScene& S, V3 wo, V3 wd
         if (trav_step<COUNT>(T, S, cnt)) break;
     }
     return T.h;
+}
+
+// Occlusion: whether the same query over the interval [EPSILON_F32, tmax] would report a hit.  The
+// walk up to the first accepted primitive does not depend on anything after it, so it stops there.
+template <bool COUNT>
+__device__ __forceinline__ bool any_hit_query(const DevScene& S, V3 wo, V3 wd, float tmax, Counters& cnt) {
+    Trav T;
+    trav_begin(T, S, wo, wd);
+    T.tmax = tmax;
+    for (;;) {
+        if (COUNT) {
+            const uint64_t walking = __ballot(1);
+            if ((int)(threadIdx.x & 63) == __ffsll((long long)walking) - 1) cnt.wave_steps++;
+        }
+        if (trav_step<COUNT>(T, S, cnt) || T.h.inst != 0) break;
+    }
+    return T.h.inst != 0;
 }
 
 // epilogue of rt_cpu_intersect, raytracer_cpu.c:411-454: position and shading normal

@@ -508,6 +508,37 @@ int rthip_trace_rays(rthip_ctx* ctx, const float* origins, const float* directio
     return RTHIP_OK;
 }
 
+int rthip_occluded_device(rthip_ctx* ctx, const float* d_origins, const float* d_directions, uint64_t n, float tmax,
+                          uint8_t* d_out, void* stream) {
+    RT_TRY(check_ready(ctx, "rthip_occluded_device"));
+    if (n && (!d_origins || !d_directions || !d_out)) return rthip_fail(ctx, RTHIP_E_INVALID, "NULL device pointer");
+    if (n > (1ull << 40)) return rthip_fail(ctx, RTHIP_E_LIMIT, "more than 2^40 rays in one call");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    return occlusion_launch(ctx, make_scene(ctx), d_origins, d_directions, n, tmax, d_out, counters_or_null(ctx),
+                            (hipStream_t)stream);
+}
+
+int rthip_occluded(rthip_ctx* ctx, const float* origins, const float* directions, uint64_t n, float tmax, uint8_t* out) {
+    RT_TRY(check_ready(ctx, "rthip_occluded"));
+    if (n == 0) return RTHIP_OK;
+    if (!origins || !directions || !out) return rthip_fail(ctx, RTHIP_E_INVALID, "ray or output arrays are NULL");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    RT_TRY(rthip_reserve(ctx, ctx->scratch_a, n));
+    RT_TRY(rthip_reserve(ctx, ctx->scratch_b, n * 12));
+    RT_TRY(rthip_reserve(ctx, ctx->scratch_c, n * 12));
+    RT_HIP(ctx, hipMemcpyAsync(ctx->scratch_b.p, origins, n * 12, hipMemcpyHostToDevice, s));
+    RT_HIP(ctx, hipMemcpyAsync(ctx->scratch_c.p, directions, n * 12, hipMemcpyHostToDevice, s));
+    RT_HIP(ctx, hipEventRecord(ctx->ev0, s));
+    RT_TRY(rthip_occluded_device(ctx, (const float*)ctx->scratch_b.p, (const float*)ctx->scratch_c.p, n, tmax,
+                                 (uint8_t*)ctx->scratch_a.p, s));
+    RT_HIP(ctx, hipEventRecord(ctx->ev1, s));
+    RT_HIP(ctx, hipMemcpyAsync(out, ctx->scratch_a.p, n, hipMemcpyDeviceToHost, s));
+    RT_HIP(ctx, hipStreamSynchronize(s));
+    RT_HIP(ctx, hipEventElapsedTime(&ctx->last_cast_ms, ctx->ev0, ctx->ev1));
+    return RTHIP_OK;
+}
+
 int rthip_get_stats(rthip_ctx* ctx, rthip_stats* out) {
     if (!ctx || !out) return RTHIP_E_INVALID;
     RT_HIP(ctx, hipSetDevice(ctx->device));

@@ -179,6 +179,8 @@ int instance_aabbs_device(rthip_ctx* ctx, const DevInstance* d_inst, uint32_t n,
 // ---- tracing (trace.hip) ----------------------------------------------------------
 int trace_rays_launch(rthip_ctx* ctx, const DevScene& scene, const float* d_o, const float* d_d, uint64_t n,
                       uint32_t* d_hits4, float* d_uv, float* d_normal, uint64_t* d_counters, hipStream_t stream);
+int occlusion_launch(rthip_ctx* ctx, const DevScene& scene, const float* d_o, const float* d_d, uint64_t n, float tmax,
+                     uint8_t* d_out, uint64_t* d_counters, hipStream_t stream);
 int primary_hits_launch(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_settings& cast, int width, int height,
                         uint32_t* d_hits4, uint64_t* d_counters, hipStream_t stream);
 int cast_wavefront_launch(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_settings& cast, uint64_t seed,

@@ -211,8 +211,11 @@ __device__ __forceinline__ bool pixel_of_thread(int width, int height, int& x, i
 // The same renderer with a fixed pixel per thread (wave = 8x8 tile) and no refill: less
 // bookkeeping per path, but a wave is as slow as its longest pixel.  Faster than the persistent
 // kernel when paths are short and neighbouring pixels behave alike.
+#ifndef RT_STATIC_WAVES
+#define RT_STATIC_WAVES 5
+#endif
 template <bool COUNT>
-__global__ __launch_bounds__(kBlock) void cast_static_kernel(DevScene S, rthip_cast_settings c, uint64_t seed,
+__global__ __launch_bounds__(kBlock, RT_STATIC_WAVES) void cast_static_kernel(DevScene S, rthip_cast_settings c, uint64_t seed,
                                                              float* __restrict__ out, int width, int height,
                                                              rthip_shard shard, uint64_t* counters) {
     extern __shared__ uint32_t bounce_stack[];
@@ -287,6 +290,29 @@ __global__ __launch_bounds__(kBlock) void primary_hits_kernel(DevScene S, rthip_
     if (COUNT) flush_counters(counters, cnt, rays);
 }
 
+// Result record of one explicit ray (the taps' output format).
+__device__ __forceinline__ void write_ray_result(const DevScene& S, uint64_t i, const Hit& h, V3 o, V3 d,
+                                                 uint32_t* __restrict__ hits4, float* __restrict__ uv,
+                                                 float* __restrict__ normal) {
+    uint32_t* r = hits4 + 4 * i;
+    r[0] = h.inst;
+    r[1] = h.inst ? h.tri : 0u;
+    r[2] = __float_as_uint(h.inst ? h.t : -1.0f);
+    r[3] = 0;
+    if (uv) {
+        uv[2 * i] = h.inst ? h.u : 0.f;
+        uv[2 * i + 1] = h.inst ? h.v : 0.f;
+    }
+    if (normal) {
+        V3 p, nn = mk(0.f, 0.f, 0.f);
+        int material;
+        if (h.inst) finish_hit(S, o, d, h, p, nn, material);
+        normal[3 * i] = nn.x;
+        normal[3 * i + 1] = nn.y;
+        normal[3 * i + 2] = nn.z;
+    }
+}
+
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void trace_rays_kernel(DevScene S, const float* __restrict__ ro,
                                                             const float* __restrict__ rd, uint64_t n,
@@ -300,23 +326,92 @@ __global__ __launch_bounds__(kBlock) void trace_rays_kernel(DevScene S, const fl
         const V3 d = mk(rd[3 * i], rd[3 * i + 1], rd[3 * i + 2]);
         rays = 1;
         const Hit h = closest_hit_query<COUNT>(S, o, d, cnt);
-        uint32_t* r = hits4 + 4 * i;
-        r[0] = h.inst;
-        r[1] = h.inst ? h.tri : 0u;
-        r[2] = __float_as_uint(h.inst ? h.t : -1.0f);
-        r[3] = 0;
-        if (uv) {
-            uv[2 * i] = h.inst ? h.u : 0.f;
-            uv[2 * i + 1] = h.inst ? h.v : 0.f;
+        write_ray_result(S, i, h, o, d, hits4, uv, normal);
+    }
+    if (COUNT) flush_counters(counters, cnt, rays);
+}
+
+// The same queries for long ray streams: resident waves, and a lane whose ray has ended takes the
+// next ray of the stream instead of idling until the longest ray of its wave is done.  A wave
+// reserves kRayGrab consecutive rays with one atomic and deals them to its idle lanes by ballot
+// and prefix count; it goes back for rays whenever `refill` lanes are idle.
+constexpr uint32_t kRayGrab = 1024;
+
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void trace_rays_persistent_kernel(DevScene S, const float* __restrict__ ro,
+                                                                       const float* __restrict__ rd, uint64_t n,
+                                                                       uint32_t* __restrict__ hits4,
+                                                                       float* __restrict__ uv, float* __restrict__ normal,
+                                                                       uint32_t* work_counter, uint32_t refill,
+                                                                       uint64_t* counters) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    Counters cnt = {0, 0, 0, 0};
+    uint32_t rays = 0;
+    uint64_t cur = 0, cur_end = 0;  // wave-uniform: the reserved rays not yet dealt
+    bool exhausted = false;         // wave-uniform: the stream has no rays left to reserve
+    bool active = false;
+    uint64_t ray = 0;
+    Trav T;
+    trav_begin(T, S, mk(0.f, 0.f, 0.f), mk(0.f, 0.f, 1.f));
+
+    for (;;) {
+        uint64_t idle = __ballot(!active);
+        while (idle != 0 && !exhausted) {
+            if (cur >= cur_end) {
+                uint32_t k = 0;
+                if (lane == 0) k = atomicAdd(work_counter, 1u);
+                k = __shfl(k, 0);
+                cur = (uint64_t)k * kRayGrab;
+                if (cur >= n) {
+                    exhausted = true;
+                    break;
+                }
+                cur_end = cur + kRayGrab < n ? cur + kRayGrab : n;
+            }
+            const uint64_t room = cur_end - cur;
+            const uint32_t n_idle = (uint32_t)__popcll(idle);
+            const uint32_t take = room < (uint64_t)n_idle ? (uint32_t)room : n_idle;
+            const uint32_t my_rank = (uint32_t)__popcll(idle & lt_mask);
+            if (!active && my_rank < take) {
+                ray = cur + my_rank;
+                trav_begin(T, S, mk(ro[3 * ray], ro[3 * ray + 1], ro[3 * ray + 2]),
+                           mk(rd[3 * ray], rd[3 * ray + 1], rd[3 * ray + 2]));
+                active = true;
+                rays++;
+            }
+            cur += take;
+            idle = __ballot(!active);
         }
-        if (normal) {
-            V3 p, nn = mk(0.f, 0.f, 0.f);
-            int material;
-            if (h.inst) finish_hit(S, o, d, h, p, nn, material);
-            normal[3 * i] = nn.x;
-            normal[3 * i + 1] = nn.y;
-            normal[3 * i + 2] = nn.z;
+        if (__ballot(active) == 0) break;  // nothing in flight and nothing left to reserve
+        for (;;) {
+            if (COUNT) {
+                const uint64_t walking = __ballot(active);
+                if ((int)lane == __ffsll((long long)walking) - 1) cnt.wave_steps++;
+            }
+            if (active && trav_step<COUNT>(T, S, cnt)) {
+                write_ray_result(S, ray, T.h, T.wo, T.wd, hits4, uv, normal);
+                active = false;
+            }
+            const uint32_t n_idle = (uint32_t)__popcll(__ballot(!active));
+            if (n_idle == 64u || (!exhausted && n_idle >= refill)) break;
         }
+    }
+    if (COUNT) flush_counters(counters, cnt, rays);
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void occlusion_kernel(DevScene S, const float* __restrict__ ro,
+                                                           const float* __restrict__ rd, uint64_t n, float tmax,
+                                                           uint8_t* __restrict__ out, uint64_t* counters) {
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    Counters cnt = {0, 0, 0, 0};
+    uint32_t rays = 0;
+    if (i < n) {
+        const V3 o = mk(ro[3 * i], ro[3 * i + 1], ro[3 * i + 2]);
+        const V3 d = mk(rd[3 * i], rd[3 * i + 1], rd[3 * i + 2]);
+        rays = 1;
+        out[i] = any_hit_query<COUNT>(S, o, d, tmax, cnt) ? 1 : 0;
     }
     if (COUNT) flush_counters(counters, cnt, rays);
 }
@@ -328,11 +423,42 @@ inline uint32_t div_up(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) /
 int trace_rays_launch(rthip_ctx* ctx, const DevScene& scene, const float* d_o, const float* d_d, uint64_t n,
                       uint32_t* d_hits4, float* d_uv, float* d_normal, uint64_t* d_counters, hipStream_t stream) {
     if (n == 0) return RTHIP_OK;
+    // Long streams over a scene that the caches can hold: resident waves with lane refill.  Once the
+    // scene is larger than the Infinity Cache the walk is bound by HBM line fetches, not by idle lanes,
+    // and the plain kernel (fewer registers, more waves) is the faster one.
+    const uint64_t scene_bytes = ctx->total_blas_nodes * 32ull + ctx->total_tris * 48ull;
+    const bool resident = ctx->cast_mode == 0 || (ctx->cast_mode != 1 && scene_bytes <= (256ull << 20));
+    if (n >= (1ull << 18) && n < (1ull << 32) * kRayGrab && resident) {
+        uint32_t blocks = div_up(n, kBlock);
+        if (blocks > ctx->persistent_blocks) blocks = ctx->persistent_blocks;
+        uint32_t* work = (uint32_t*)ctx->work_ring.p + (size_t)(ctx->work_next++ % 16u) * 256u;
+        RT_HIP(ctx, hipMemsetAsync(work, 0, 1024, stream));
+        if (d_counters)
+            trace_rays_persistent_kernel<true><<<blocks, kBlock, 0, stream>>>(scene, d_o, d_d, n, d_hits4, d_uv, d_normal,
+                                                                             work, ctx->refill_lanes, d_counters);
+        else
+            trace_rays_persistent_kernel<false><<<blocks, kBlock, 0, stream>>>(scene, d_o, d_d, n, d_hits4, d_uv, d_normal,
+                                                                              work, ctx->refill_lanes, nullptr);
+        RT_HIP(ctx, hipGetLastError());
+        return RTHIP_OK;
+    }
     const uint32_t blocks = div_up(n, kBlock);
     if (d_counters)
         trace_rays_kernel<true><<<blocks, kBlock, 0, stream>>>(scene, d_o, d_d, n, d_hits4, d_uv, d_normal, d_counters);
     else
         trace_rays_kernel<false><<<blocks, kBlock, 0, stream>>>(scene, d_o, d_d, n, d_hits4, d_uv, d_normal, nullptr);
+    RT_HIP(ctx, hipGetLastError());
+    return RTHIP_OK;
+}
+
+int occlusion_launch(rthip_ctx* ctx, const DevScene& scene, const float* d_o, const float* d_d, uint64_t n, float tmax,
+                     uint8_t* d_out, uint64_t* d_counters, hipStream_t stream) {
+    if (n == 0) return RTHIP_OK;
+    const uint32_t blocks = div_up(n, kBlock);
+    if (d_counters)
+        occlusion_kernel<true><<<blocks, kBlock, 0, stream>>>(scene, d_o, d_d, n, tmax, d_out, d_counters);
+    else
+        occlusion_kernel<false><<<blocks, kBlock, 0, stream>>>(scene, d_o, d_d, n, tmax, d_out, nullptr);
     RT_HIP(ctx, hipGetLastError());
     return RTHIP_OK;
 }

@@ -176,6 +176,16 @@ def get_stats(tracer: RT_Tracer) -> dict:
     return {k: st[0][k].item() for k in abi.STATS.names}
 
 
+def occluded(tracer: RT_Tracer, origins, directions, tmax: float = 3.402823466e+38) -> np.ndarray:
+    """1 per ray whose TLAS query over [EPSILON_F32, tmax] reports a hit (any-hit walk), else 0."""
+    o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
+    d = np.ascontiguousarray(directions, dtype=np.float32).reshape(-1, 3)
+    out = np.zeros(o.shape[0], dtype=np.uint8)
+    tracer.check(tracer.lib.rthip_occluded(tracer.h, abi.ptr(o), abi.ptr(d), o.shape[0], float(tmax), abi.ptr(out)),
+                 "rthip_occluded")
+    return out
+
+
 CAST_KERNELS = {"persistent": 0, "static": 1, "wavefront": 2, "auto": 3}
 
 

@@ -231,6 +231,52 @@ def test_every_cast_kernel_gives_the_same_bits(oracle, gpu_tracer, kernel):
         T.set_cast_kernel(gpu_tracer, "auto")
 
 
+def test_long_ray_stream(oracle, gpu_tracer):
+    """Ray streams of 2^18 rays and more go through the resident-wave kernel with lane refill: same
+    answers and the same traversal counters as the oracle, with a ragged tail."""
+    verts, indices = scenes.bunny_class_mesh(3)
+    w, cam, sky = scenes.instanced_grid(12, seed=1, verts=verts, indices=indices)
+    build(gpu_tracer, w, 4, sky)
+    sc = oracle.Scene(world.flatten_world(w), 4, sky)
+    n = (1 << 18) + 1234
+    o, d = scenes.random_rays(n, seed=9, lo=(-15, -2, -15), hi=(15, 3, 15))
+    T.set_counting(gpu_tracer, True)
+    T.get_stats(gpu_tracer)
+    inst, tri, t, uv, nrm = T.trace_rays(gpu_tracer, o, d)
+    st = T.get_stats(gpu_tracer)
+    T.set_counting(gpu_tracer, False)
+    oi, ot, ott, ouv, onrm, cnt = sc.trace(o, d, threads=8)
+    assert (inst == oi).all() and (tri == ot).all() and (bits(t) == bits(ott)).all()
+    assert (bits(uv) == bits(ouv)).all() and (bits(nrm) == bits(onrm)).all()
+    for k in ("rays", "nodes_tested", "tris_tested", "inst_entered"):
+        assert st[k] == cnt[k], f"traversal counter {k}: {st[k]} vs {cnt[k]}"
+    inst2 = T.trace_rays(gpu_tracer, o, d)[0]  # counting off: the other template instance
+    assert (inst2 == oi).all()
+
+
+def test_occlusion_rays(oracle, gpu_tracer):
+    """Shadow rays (any-hit walk) against the reference's interval-limited query, and against the
+    oracle on an instanced scene with random rays and several tmax."""
+    g = golden("occlusion")
+    verts, indices = scenes.bunny_class_mesh()
+    for name, (w, cam, sky), bounces in (("cornell", scenes.cornell(), 8), ("bunny", scenes.bunny(verts, indices), 2)):
+        build(gpu_tracer, w, bounces, sky)
+        for k in range(3):
+            got = T.occluded(gpu_tracer, g[f"{name}_o"], g[f"{name}_d"], float(g[f"{name}_tmax{k}"]))
+            assert (got == g[f"{name}_ref_occluded{k}"]).all(), f"{name} tmax {k}"
+    verts, indices = scenes.bunny_class_mesh(3)
+    w, cam, sky = scenes.instanced_grid(12, seed=1, verts=verts, indices=indices)
+    build(gpu_tracer, w, 4, sky)
+    sc = oracle.Scene(world.flatten_world(w), 4, sky)
+    o, d = scenes.random_rays(30_000, seed=5, lo=(-15, -2, -15), hi=(15, 3, 15))
+    for tmax in (0.5, 3.0, 40.0, 3.402823466e+38):
+        got = T.occluded(gpu_tracer, o, d, tmax)
+        want = sc.occluded(o, d, tmax)
+        assert (got == want).all(), f"instanced tmax {tmax}: {(got != want).sum()} rays differ"
+    assert 0 < int(T.occluded(gpu_tracer, o, d, 3.0).sum()) < int(T.occluded(gpu_tracer, o, d, 40.0).sum())
+    assert T.occluded(gpu_tracer, np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32)).size == 0
+
+
 def test_shards_sum_to_the_frame(oracle, gpu_tracer):
     import ctypes as C
 

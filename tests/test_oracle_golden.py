@@ -126,3 +126,22 @@ def test_counter_modes_agree_statistically(oracle):
     assert rmse(img, a) <= 1.25 * rmse(a, b)
     lum = lambda x: float(x.astype(np.float64).mean())
     assert abs(lum(img) - lum(a)) <= 0.01 * lum(a) + 2.0 * abs(lum(a) - lum(b))
+
+
+def _occlusion_scenes():
+    verts, indices = scenes.bunny_class_mesh()
+    return {"cornell": (scenes.cornell(), 8), "bunny": (scenes.bunny(verts, indices), 2)}
+
+
+def test_occlusion_matches_reference(oracle):
+    """The interval-limited TLAS query (shadow rays) against the reference's own answers."""
+    g = golden("occlusion")
+    for name, ((w, cam, sky), bounces) in _occlusion_scenes().items():
+        sc = oracle.Scene(world.flatten_world(w), bounces, sky)
+        o, d = g[f"{name}_o"], g[f"{name}_d"]
+        for k in range(3):
+            got = sc.occluded(o, d, float(g[f"{name}_tmax{k}"]))
+            assert (got == g[f"{name}_ref_occluded{k}"]).all(), f"{name} tmax {k}"
+        # with the full interval, occlusion is "the closest-hit query found something"
+        inst = sc.trace(o, d, want_normal=False)[0]
+        assert ((inst > 0).astype(np.uint8) == g[f"{name}_ref_occluded2"]).all()
