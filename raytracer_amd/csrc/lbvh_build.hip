@@ -415,21 +415,25 @@ __global__ __launch_bounds__(kBlock) void gap_priority_kernel(const uint64_t* __
 }
 
 // ---- K5 + K6: hierarchy emission with box refit ------------------------------------------
-// lbvh_create_subtree, lbvh.c:44-72, bottom-up.  A child publishes its record in its
-// parent's slot and bumps the parent's arrival counter; the second child to arrive
-// reads its sibling's record, merges (merge_rng3_f32(left, right), lbvh.c:58), records the
-// finished node and walks on.
+// lbvh_create_subtree, lbvh.c:44-72, bottom-up.  A child leaves its record in its parent's
+// slot and bumps the parent's arrival counter; the second child to arrive reads its
+// sibling's record, merges (merge_rng3_f32(left, right), lbvh.c:58), records the finished node
+// and walks on.  Nobody ever waits for anybody.
 //
-// A workgroup owns kChunk consecutive sorted leaves.  A gap whose node lies entirely inside
-// the chunk (it is bounded on both sides, inside the chunk, by gaps of smaller priority) is
-// "local": both of its children are produced by this workgroup, so their hand-off goes
-// through LDS.  Only the few nodes on the chunk's two boundary staircases leave the chunk;
-// their hand-off goes through HBM between workgroups: the record is written with
-// device-scope (write-through) stores, the wave drains them (s_waitcnt vmcnt(0)) before its
-// device-scope counter add, and the sibling is read with device-scope loads only after the
-// add has returned.  FENCE = true replaces that with plain accesses bracketed by
-// __threadfence() (diagnostic switch RTHIP_REFIT_FENCE=1).
-constexpr int kChunk = 512;  // sorted leaves per workgroup (2 per thread)
+// Two kernels.  hierarchy_local_kernel: a workgroup owns kChunk consecutive sorted leaves, one
+// per thread.  A gap whose node lies entirely inside the chunk (it is bounded on both sides,
+// inside the chunk, by gaps of smaller priority) is "local": both of its children are produced
+// by this workgroup, so their hand-off goes through LDS.  A thread that reaches a parent that
+// is not local stores its record in HBM, counts itself at the parent (+1) and is done.
+// hierarchy_upper_kernel finishes the nodes that span chunks (a few per cent of all): one
+// thread per gap; the gaps whose two children both arrived in the first kernel start climbing,
+// with the hand-off through HBM: the record is written with device-scope (write-through)
+// stores, the wave drains them (s_waitcnt vmcnt(0)) before its device-scope counter add (+16,
+// so the starting condition "two arrivals from the first kernel" stays readable), and the
+// sibling is read with device-scope loads only after the add has returned.  FENCE = true
+// replaces that with plain accesses bracketed by __threadfence() (diagnostic switch
+// RTHIP_REFIT_FENCE=1).
+constexpr int kChunk = 512;  // sorted leaves per workgroup, one per thread
 
 struct alignas(16) NodeInfo {  // a finished inner node, indexed by its gap
     float box[6];
@@ -478,37 +482,58 @@ __device__ __forceinline__ void child_load(const ChildRec* slot, float* box, uin
     *dl = (uint32_t)(w3 >> 32);
 }
 
-template <bool FENCE>
-__global__ __launch_bounds__(kBlock) void hierarchy_kernel(uint32_t n, const uint8_t* __restrict__ prio,
-                                                           const uint32_t* __restrict__ sorted_idx,
-                                                           const float* __restrict__ aabb6, ChildRec* child,
-                                                           uint32_t* flags, uint32_t* __restrict__ cnt_l,
-                                                           NodeInfo* __restrict__ node_info,
-                                                           uint8_t* __restrict__ node_dl,
-                                                           LeafRec* __restrict__ leaf_sorted) {
+// merge with a sibling: the LEFT child's box is the first argument of every Min / Max (lbvh.c:58)
+__device__ __forceinline__ void merge_sibling(float* box, const float* sbox, bool sibling_is_right) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        box[k] = sibling_is_right ? ref_min(box[k], sbox[k]) : ref_min(sbox[k], box[k]);
+        box[k + 3] = sibling_is_right ? ref_max(box[k + 3], sbox[k + 3]) : ref_max(sbox[k + 3], box[k + 3]);
+    }
+}
+
+__device__ __forceinline__ void node_store(NodeInfo* node_info, uint8_t* node_dl, uint32_t gap, const float* box,
+                                           uint32_t l, uint32_t r, uint32_t dl) {
+    NodeInfo ni;
+#pragma unroll
+    for (int k = 0; k < 6; k++) ni.box[k] = box[k];
+    ni.l = l;
+    ni.r = r;
+    node_info[gap] = ni;
+    node_dl[gap] = (uint8_t)dl;
+}
+
+__global__ __launch_bounds__(kChunk) void hierarchy_local_kernel(uint32_t n, const uint8_t* __restrict__ prio,
+                                                                 const uint32_t* __restrict__ sorted_idx,
+                                                                 const float* __restrict__ aabb6,
+                                                                 ChildRec* __restrict__ child, uint32_t* flags,
+                                                                 uint32_t* __restrict__ cnt_l,
+                                                                 NodeInfo* __restrict__ node_info,
+                                                                 uint8_t* __restrict__ node_dl,
+                                                                 LeafRec* __restrict__ leaf_sorted) {
     // window of gap priorities: entry k is gap c0 - 1 + k, k = 0 .. kChunk; bit 7 marks a local gap.
     // Gaps that do not exist (-1, >= n-1) read as 0, below every real priority (>= 1).
     __shared__ uint8_t win[kChunk + 8];
     __shared__ uint32_t lflag[kChunk];
     __shared__ ChildRec lrec[2 * kChunk];
-    __shared__ uint32_t wmin_l[kBlock / 64], wmin_r[kBlock / 64];
+    __shared__ uint32_t wmin_l[kChunk / 64], wmin_r[kChunk / 64];
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const uint32_t c0 = blockIdx.x * (uint32_t)kChunk;
 
-    for (int k = tid; k <= kChunk; k += kBlock) {
-        int64_t g = (int64_t)c0 - 1 + k;
-        win[k] = (g >= 0 && g + 1 < (int64_t)n) ? prio[g] : (uint8_t)0;
+    {
+        const int64_t g = (int64_t)c0 - 1 + tid;
+        win[tid] = (g >= 0 && g + 1 < (int64_t)n) ? prio[g] : (uint8_t)0;
+        if (tid == 0) {
+            const int64_t ge = (int64_t)c0 - 1 + kChunk;
+            win[kChunk] = (ge + 1 < (int64_t)n) ? prio[ge] : (uint8_t)0;
+        }
     }
     lflag[tid] = 0;
-    lflag[tid + kBlock] = 0;
     __syncthreads();
 
-    {   // local[k] <=> win[k] > min(win[0..k-1]) and win[k] > min(win[k+1..kChunk]), k = 1 .. kChunk-1
-        // thread t owns entries 2t and 2t+1 (entry kChunk is folded into the suffix minima)
-        const uint32_t e0 = win[2 * tid], e1 = win[2 * tid + 1];
-        const uint32_t m = e0 < e1 ? e0 : e1;
-        uint32_t pre = m, suf = m;  // inclusive over threads
+    {   // local[k] <=> win[k] > min(win[0..k-1]) and win[k] > min(win[k+1..kChunk]), k = 1 .. kChunk-1; thread t owns entry t
+        const uint32_t e = win[tid];
+        uint32_t pre = e, suf = e;  // inclusive over the wave
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             uint32_t a = __shfl_up(pre, o), b = __shfl_down(suf, o);
@@ -518,114 +543,137 @@ __global__ __launch_bounds__(kBlock) void hierarchy_kernel(uint32_t n, const uin
         if (lane == 63) wmin_l[wave] = pre;
         if (lane == 0) wmin_r[wave] = suf;
         __syncthreads();
-        uint32_t before = 0xffu, after = win[kChunk];  // minima over the threads before / after this one
-        for (int w = 0; w < kBlock / 64; w++) {
+        uint32_t before = 0xffu, after = win[kChunk];  // minima over the entries before / after this one
+        for (int w = 0; w < kChunk / 64; w++) {
             if (w < wave) before = wmin_l[w] < before ? wmin_l[w] : before;
             if (w > wave) after = wmin_r[w] < after ? wmin_r[w] : after;
         }
-        uint32_t pl = __shfl_up(pre, 1), sr = __shfl_down(suf, 1);
+        const uint32_t pl = __shfl_up(pre, 1), sr = __shfl_down(suf, 1);
         if (lane > 0) before = pl < before ? pl : before;
         if (lane < 63) after = sr < after ? sr : after;
-        // entry 2t: left = before, right = min(e1, after); entry 2t+1: left = min(before, e0), right = after
-        const uint32_t r0 = e1 < after ? e1 : after, l1 = before < e0 ? before : e0;
-        const bool loc0 = (2 * tid >= 1) && e0 > before && e0 > r0;
-        const bool loc1 = e1 > l1 && e1 > after;
+        const bool loc = tid >= 1 && e > before && e > after;
         __syncthreads();
-        win[2 * tid] = (uint8_t)(e0 | (loc0 ? 0x80u : 0u));
-        win[2 * tid + 1] = (uint8_t)(e1 | (loc1 ? 0x80u : 0u));
+        win[tid] = (uint8_t)(e | (loc ? 0x80u : 0u));
     }
     __syncthreads();
 
-    for (int half = 0; half < 2; half++) {
-        const uint32_t i = c0 + (uint32_t)half * kBlock + (uint32_t)tid;
-        if (i >= n) continue;
-        uint32_t l = i, r = i, dl = 0;
-        float box[6];
-        {
-            const uint32_t prim = sorted_idx[i];
-            const float* b = aabb6 + 6 * (uint64_t)prim;  // node->aabb = in_aabbs[id - 1], lbvh.c:53
+    const uint32_t i = c0 + (uint32_t)tid;
+    if (i >= n) return;
+    uint32_t l = i, r = i, dl = 0;
+    float box[6];
+    {
+        const uint32_t prim = sorted_idx[i];
+        const float* b = aabb6 + 6 * (uint64_t)prim;  // node->aabb = in_aabbs[id - 1], lbvh.c:53
 #pragma unroll
-            for (int k = 0; k < 6; k++) box[k] = b[k];
-            LeafRec lr;
+        for (int k = 0; k < 6; k++) box[k] = b[k];
+        LeafRec lr;
 #pragma unroll
-            for (int k = 0; k < 6; k++) lr.box[k] = box[k];
-            lr.id = prim + 1;  // id = idx + 1, lbvh.c:116
-            lr.pad = 0;
-            leaf_sorted[i] = lr;
+        for (int k = 0; k < 6; k++) lr.box[k] = box[k];
+        lr.id = prim + 1;  // id = idx + 1, lbvh.c:116
+        lr.pad = 0;
+        leaf_sorted[i] = lr;
+    }
+    for (;;) {
+        if (l == 0 && r == n - 1) {  // the root: top of the left spine that starts at leaf 0
+            cnt_l[0] = dl;
+            break;
         }
-        for (;;) {
-            if (l == 0 && r == n - 1) {  // the root: top of the left spine that starts at leaf 0
-                cnt_l[0] = dl;
-                break;
-            }
-            // priorities of the two gaps that bound [l, r]; the parent is the one with the larger priority
-            uint32_t pr_r = 0, pr_l = 0;
-            if (r != n - 1) {
-                const uint32_t k = r + 1 - c0;  // window index of gap r (unsigned wrap when r + 1 < c0)
-                pr_r = (k <= (uint32_t)kChunk) ? (uint32_t)win[k] : (uint32_t)prio[r];
-            }
-            if (l != 0) {
-                const uint32_t k = l - c0;  // window index of gap l - 1
-                pr_l = (k <= (uint32_t)kChunk) ? (uint32_t)win[k] : (uint32_t)prio[l - 1];
-            }
-            const bool parent_right = (l == 0) || (r != n - 1 && (pr_r & 0x7fu) > (pr_l & 0x7fu));
-            const uint32_t parent = parent_right ? r : l - 1;
-            const uint32_t side = parent_right ? 0u : 1u;  // 0: this node is the LEFT child
-            const bool local = ((parent_right ? pr_r : pr_l) & 0x80u) != 0;
-            if (side == 1) cnt_l[l] = dl;  // a right child tops the left spine that starts at l
-            float sbox[6];
-            uint32_t s_far, s_dl;
-            if (local) {
-                const uint32_t slot = parent - c0;
-                ChildRec mine;
+        // Priorities of the two gaps that bound [l, r]; the parent is the one with the larger priority.
+        // While the node is inside the chunk both gaps are inside the window.
+        const uint32_t pr_r = (r != n - 1) ? (uint32_t)win[r + 1 - c0] : 0u;
+        const uint32_t pr_l = (l != 0) ? (uint32_t)win[l - c0] : 0u;
+        const bool parent_right = (l == 0) || (r != n - 1 && (pr_r & 0x7fu) > (pr_l & 0x7fu));
+        const uint32_t parent = parent_right ? r : l - 1;
+        const uint32_t side = parent_right ? 0u : 1u;  // 0: this node is the LEFT child
+        const bool local = ((parent_right ? pr_r : pr_l) & 0x80u) != 0;
+        if (side == 1) cnt_l[l] = dl;  // a right child tops the left spine that starts at l
+        if (!local) {  // the parent spans chunks: leave the record for hierarchy_upper_kernel
+            ChildRec mine;
 #pragma unroll
-                for (int k = 0; k < 6; k++) mine.box[k] = box[k];
-                mine.far_end = parent_right ? l : r;
-                mine.dl = dl;
-                lrec[2 * slot + side] = mine;
-                __threadfence_block();
-                const uint32_t old = atomicAdd(&lflag[slot], 1u);
-                if (old == 0) break;
-                __threadfence_block();
-                const ChildRec sib = lrec[2 * slot + (1u - side)];
-#pragma unroll
-                for (int k = 0; k < 6; k++) sbox[k] = sib.box[k];
-                s_far = sib.far_end;
-                s_dl = sib.dl;
-            } else {
-                child_store<FENCE>(&child[2 * (uint64_t)parent + side], box, parent_right ? l : r, dl);
-                if (FENCE) __threadfence();
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                const uint32_t old = atomicAdd(&flags[parent], 1u);
-                if (old == 0) break;  // first to arrive: the sibling's subtree carries on from here
-                if (FENCE) __threadfence();
-                child_load<FENCE>(&child[2 * (uint64_t)parent + (1u - side)], sbox, &s_far, &s_dl);
-            }
-            if (side == 0) {  // sibling is the right child
-#pragma unroll
-                for (int k = 0; k < 3; k++) {
-                    box[k] = ref_min(box[k], sbox[k]);
-                    box[k + 3] = ref_max(box[k + 3], sbox[k + 3]);
-                }
-                r = s_far;
-                dl = dl + 1;
-            } else {  // sibling is the left child
-#pragma unroll
-                for (int k = 0; k < 3; k++) {
-                    box[k] = ref_min(sbox[k], box[k]);
-                    box[k + 3] = ref_max(sbox[k + 3], box[k + 3]);
-                }
-                l = s_far;
-                dl = s_dl + 1;
-            }
-            NodeInfo ni;
-#pragma unroll
-            for (int k = 0; k < 6; k++) ni.box[k] = box[k];
-            ni.l = l;
-            ni.r = r;
-            node_info[parent] = ni;
-            node_dl[parent] = (uint8_t)dl;
+            for (int k = 0; k < 6; k++) mine.box[k] = box[k];
+            mine.far_end = parent_right ? l : r;
+            mine.dl = dl;
+            child[2 * (uint64_t)parent + side] = mine;
+            atomicAdd(&flags[parent], 1u);
+            break;
         }
+        const uint32_t slot = parent - c0;
+        ChildRec mine;
+#pragma unroll
+        for (int k = 0; k < 6; k++) mine.box[k] = box[k];
+        mine.far_end = parent_right ? l : r;
+        mine.dl = dl;
+        lrec[2 * slot + side] = mine;
+        __threadfence_block();
+        const uint32_t old = atomicAdd(&lflag[slot], 1u);
+        if (old == 0) break;  // first to arrive: the sibling's thread carries on from here
+        __threadfence_block();
+        const ChildRec sib = lrec[2 * slot + (1u - side)];
+        merge_sibling(box, sib.box, side == 0);
+        if (side == 0) {
+            r = sib.far_end;
+            dl = dl + 1;
+        } else {
+            l = sib.far_end;
+            dl = sib.dl + 1;
+        }
+        node_store(node_info, node_dl, parent, box, l, r, dl);
+    }
+}
+
+template <bool FENCE>
+__global__ __launch_bounds__(kBlock) void hierarchy_upper_kernel(uint32_t n, const uint8_t* __restrict__ prio,
+                                                                 ChildRec* child, uint32_t* flags,
+                                                                 uint32_t* __restrict__ cnt_l,
+                                                                 NodeInfo* __restrict__ node_info,
+                                                                 uint8_t* __restrict__ node_dl) {
+    const uint64_t g0 = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (g0 + 1 >= n) return;
+    // start where both children were delivered by hierarchy_local_kernel (its arrivals count 1, the
+    // arrivals of this kernel 16, so the test reads the same whatever this kernel has done so far)
+    if ((__hip_atomic_load(&flags[g0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 15u) != 2u) return;
+    uint32_t parent = (uint32_t)g0;
+    uint32_t l, r, dl;
+    float box[6];
+    {
+        const ChildRec a = child[2 * (uint64_t)parent], b = child[2 * (uint64_t)parent + 1];  // left, right
+#pragma unroll
+        for (int k = 0; k < 6; k++) box[k] = a.box[k];
+        merge_sibling(box, b.box, true);
+        l = a.far_end;
+        r = b.far_end;
+        dl = a.dl + 1;
+        node_store(node_info, node_dl, parent, box, l, r, dl);
+    }
+    for (;;) {
+        if (l == 0 && r == n - 1) {
+            cnt_l[0] = dl;
+            break;
+        }
+        const uint32_t pr_r = (r != n - 1) ? (uint32_t)prio[r] : 0u;
+        const uint32_t pr_l = (l != 0) ? (uint32_t)prio[l - 1] : 0u;
+        const bool parent_right = (l == 0) || (r != n - 1 && pr_r > pr_l);
+        parent = parent_right ? r : l - 1;
+        const uint32_t side = parent_right ? 0u : 1u;
+        if (side == 1) cnt_l[l] = dl;
+        child_store<FENCE>(&child[2 * (uint64_t)parent + side], box, parent_right ? l : r, dl);
+        if (FENCE) __threadfence();
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t old = atomicAdd(&flags[parent], 16u);
+        if ((old & 15u) + (old >> 4) == 0u) break;  // first to arrive: the sibling carries on from here
+        if (FENCE) __threadfence();
+        float sbox[6];
+        uint32_t s_far, s_dl;
+        child_load<FENCE>(&child[2 * (uint64_t)parent + (1u - side)], sbox, &s_far, &s_dl);
+        merge_sibling(box, sbox, side == 0);
+        if (side == 0) {
+            r = s_far;
+            dl = dl + 1;
+        } else {
+            l = s_far;
+            dl = s_dl + 1;
+        }
+        node_store(node_info, node_dl, parent, box, l, r, dl);
     }
 }
 
@@ -825,17 +873,21 @@ int lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, float4* 
         RT_HIP(ctx, hipMemsetAsync(w.flags.p, 0, (n - 1) * 4, s));
     }
     const uint32_t chunks = div_up(n, kChunk);
-    if (ctx->refit_fence)
-        hierarchy_kernel<true><<<chunks, kBlock, 0, s>>>(n32, (const uint8_t*)w.prio.p, vals[cur], d_aabb6,
-                                                         (ChildRec*)w.child.p, (uint32_t*)w.flags.p, (uint32_t*)w.cnt_l.p,
-                                                         (NodeInfo*)w.node_info.p, (uint8_t*)w.node_dl.p,
-                                                         (LeafRec*)w.leaf_sorted.p);
-    else
-        hierarchy_kernel<false><<<chunks, kBlock, 0, s>>>(n32, (const uint8_t*)w.prio.p, vals[cur], d_aabb6,
-                                                          (ChildRec*)w.child.p, (uint32_t*)w.flags.p, (uint32_t*)w.cnt_l.p,
-                                                          (NodeInfo*)w.node_info.p, (uint8_t*)w.node_dl.p,
-                                                          (LeafRec*)w.leaf_sorted.p);
+    hierarchy_local_kernel<<<chunks, kChunk, 0, s>>>(n32, (const uint8_t*)w.prio.p, vals[cur], d_aabb6, (ChildRec*)w.child.p,
+                                                     (uint32_t*)w.flags.p, (uint32_t*)w.cnt_l.p, (NodeInfo*)w.node_info.p,
+                                                     (uint8_t*)w.node_dl.p, (LeafRec*)w.leaf_sorted.p);
     RT_HIP(ctx, hipGetLastError());
+    if (n > 1) {
+        if (ctx->refit_fence)
+            hierarchy_upper_kernel<true><<<div_up(n - 1, kBlock), kBlock, 0, s>>>(
+                n32, (const uint8_t*)w.prio.p, (ChildRec*)w.child.p, (uint32_t*)w.flags.p, (uint32_t*)w.cnt_l.p,
+                (NodeInfo*)w.node_info.p, (uint8_t*)w.node_dl.p);
+        else
+            hierarchy_upper_kernel<false><<<div_up(n - 1, kBlock), kBlock, 0, s>>>(
+                n32, (const uint8_t*)w.prio.p, (ChildRec*)w.child.p, (uint32_t*)w.flags.p, (uint32_t*)w.cnt_l.p,
+                (NodeInfo*)w.node_info.p, (uint8_t*)w.node_dl.p);
+        RT_HIP(ctx, hipGetLastError());
+    }
     RT_TRY((scan_u32<true>(ctx, (uint32_t*)w.cnt_l.p, n, scan_tmp + scan_tmp_elems(hist_elems), s)));
     emit_kernel<<<div_up(n, kBlock), kBlock, 0, s>>>(n32, (const LeafRec*)w.leaf_sorted.p, (const NodeInfo*)w.node_info.p,
                                                     (const uint8_t*)w.node_dl.p, (const uint32_t*)w.cnt_l.p, d_nodes);

@@ -146,7 +146,7 @@ struct Trav {
     V3 o, d, inv;       // ray of the level being walked (model space inside an instance)
     float tmax;         // interval.max; interval.min stays EPSILON_F32 (geo_make_pos_interval, geo.c:28-30)
     uint32_t idx, end;  // next node and node count of the array being walked
-    uint32_t base;      // first float4 of that array inside S.blas (unused in the TLAS)
+    const float4* nodes;  // the array being walked (TLAS, or one mesh's part of the BLAS array)
     uint32_t resume;    // TLAS index to continue from when the current BLAS walk ends
     uint32_t cur_inst;  // TLAS id of the instance being walked (0: in the TLAS)
     uint32_t tri_base;
@@ -163,7 +163,7 @@ __device__ __forceinline__ void trav_begin(Trav& T, const DevScene& S, V3 o, V3 
     T.tmax = kMaxF;
     T.idx = 0;
     T.end = S.n_tlas;
-    T.base = 0;
+    T.nodes = S.tlas;
     T.resume = 0;
     T.cur_inst = 0;
     T.tri_base = 0;
@@ -184,6 +184,7 @@ __device__ __forceinline__ bool trav_step(Trav& T, const DevScene& S, Counters& 
         }
         // leave the instance: back to the TLAS walk with the world-space ray
         T.cur_inst = 0;
+        T.nodes = S.tlas;
         T.idx = T.resume;
         T.end = S.n_tlas;
         T.o = T.wo;
@@ -191,8 +192,7 @@ __device__ __forceinline__ bool trav_step(Trav& T, const DevScene& S, Counters& 
         T.inv = T.winv;
         return false;
     }
-    const float4* nodes = (T.cur_inst != 0) ? (S.blas + T.base) : S.tlas;
-    const float4 lo = nodes[2 * (size_t)T.idx], hi = nodes[2 * (size_t)T.idx + 1];
+    const float4 lo = T.nodes[2 * (size_t)T.idx], hi = T.nodes[2 * (size_t)T.idx + 1];
     if (COUNT) cnt.nodes++;
     const uint32_t id = __float_as_uint(hi.w);
     uint32_t skip = __float_as_uint(lo.w);
@@ -247,7 +247,7 @@ __device__ __forceinline__ bool trav_step(Trav& T, const DevScene& S, Counters& 
     T.resume = skip;
     T.cur_inst = id;
     T.tri_base = it->tri_base;
-    T.base = 2u * it->node_base;
+    T.nodes = S.blas + 2 * (size_t)it->node_base;
     T.idx = 0;
     T.end = it->n_nodes;
     return false;
