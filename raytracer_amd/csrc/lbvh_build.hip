@@ -64,46 +64,82 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// order-preserving reduction of per-thread centroid bounds into bounds[0..5] (6 atomics per workgroup)
+__device__ __forceinline__ void block_bounds_reduce(const float* mn, const float* mx, uint32_t* __restrict__ bounds) {
+    __shared__ float red[6][kBlock / 64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        float a = wave_min(mn[k]), b = wave_max(mx[k]);
+        if (lane == 0) {
+            red[k][wave] = a;
+            red[k + 3][wave] = b;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int k = threadIdx.x;
+        float v = red[k][0];
+        for (int w = 1; w < kBlock / 64; w++) v = (k < 3) ? fminf(v, red[k][w]) : fmaxf(v, red[k][w]);
+        if (k < 3) atomicMin(&bounds[k], f2ord(v));
+        else atomicMax(&bounds[k], f2ord(v));
+    }
+}
+
 // ---- K1: triangle boxes + per-triangle vertex records ----------------------------
-// rt_cpu_aabb_from_tri and its loops, src/raytracer/cpu/raytracer_cpu.c:54-87.
+// rt_cpu_aabb_from_tri and its loops, src/raytracer/cpu/raytracer_cpu.c:54-87, fused with the
+// centroid bounds of lbvh_make's first loop (lbvh.c:95-105) so the boxes are not read again
+// for them.  Grid-stride, so that the bounds cost 6 atomics per workgroup of a bounded grid.
 __global__ __launch_bounds__(kBlock) void tri_prepare_kernel(const float* __restrict__ px, const float* __restrict__ py,
                                                              const float* __restrict__ pz, const float* __restrict__ nx,
                                                              const float* __restrict__ ny, const float* __restrict__ nz,
                                                              const uint32_t* __restrict__ indices, uint64_t n_tris,
                                                              float* __restrict__ aabb6, float4* __restrict__ tri_v,
-                                                             float4* __restrict__ tri_n) {
-    uint64_t t = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (t >= n_tris) return;
-    uint32_t i0, i1, i2;
-    if (indices) {
-        i0 = indices[3 * t];
-        i1 = indices[3 * t + 1];
-        i2 = indices[3 * t + 2];
-    } else {
-        i0 = (uint32_t)(3 * t);
-        i1 = i0 + 1;
-        i2 = i0 + 2;
+                                                             float4* __restrict__ tri_n, uint32_t* __restrict__ bounds) {
+    float mn[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f};
+    float mx[3] = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
+    for (uint64_t t = (uint64_t)blockIdx.x * kBlock + threadIdx.x; t < n_tris; t += (uint64_t)gridDim.x * kBlock) {
+        uint32_t i0, i1, i2;
+        if (indices) {
+            i0 = indices[3 * t];
+            i1 = indices[3 * t + 1];
+            i2 = indices[3 * t + 2];
+        } else {
+            i0 = (uint32_t)(3 * t);
+            i1 = i0 + 1;
+            i2 = i0 + 2;
+        }
+        float ax = px[i0], ay = py[i0], az = pz[i0];
+        float bx = px[i1], by = py[i1], bz = pz[i1];
+        float cx = px[i2], cy = py[i2], cz = pz[i2];
+        float b[6];
+        b[0] = ref_min(ref_min(ax, bx), cx);
+        b[1] = ref_min(ref_min(ay, by), cy);
+        b[2] = ref_min(ref_min(az, bz), cz);
+        b[3] = ref_max(ref_max(ax, bx), cx);
+        b[4] = ref_max(ref_max(ay, by), cy);
+        b[5] = ref_max(ref_max(az, bz), cz);
+        float* o = aabb6 + 6 * t;
+#pragma unroll
+        for (int k = 0; k < 6; k++) o[k] = b[k];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const float c = (b[k] + b[k + 3]) * 0.5f;  // mul_3f32(add_3f32(min, max), 0.5f), lbvh.c:98
+            mn[k] = ref_min(mn[k], c);
+            mx[k] = ref_max(mx[k], c);
+        }
+        if (tri_v) {
+            tri_v[3 * t + 0] = make_float4(ax, ay, az, 0.f);
+            tri_v[3 * t + 1] = make_float4(bx, by, bz, 0.f);
+            tri_v[3 * t + 2] = make_float4(cx, cy, cz, 0.f);
+        }
+        if (tri_n && nx) {
+            tri_n[3 * t + 0] = make_float4(nx[i0], ny[i0], nz[i0], 0.f);
+            tri_n[3 * t + 1] = make_float4(nx[i1], ny[i1], nz[i1], 0.f);
+            tri_n[3 * t + 2] = make_float4(nx[i2], ny[i2], nz[i2], 0.f);
+        }
     }
-    float ax = px[i0], ay = py[i0], az = pz[i0];
-    float bx = px[i1], by = py[i1], bz = pz[i1];
-    float cx = px[i2], cy = py[i2], cz = pz[i2];
-    float* o = aabb6 + 6 * t;
-    o[0] = ref_min(ref_min(ax, bx), cx);
-    o[1] = ref_min(ref_min(ay, by), cy);
-    o[2] = ref_min(ref_min(az, bz), cz);
-    o[3] = ref_max(ref_max(ax, bx), cx);
-    o[4] = ref_max(ref_max(ay, by), cy);
-    o[5] = ref_max(ref_max(az, bz), cz);
-    if (tri_v) {
-        tri_v[3 * t + 0] = make_float4(ax, ay, az, 0.f);
-        tri_v[3 * t + 1] = make_float4(bx, by, bz, 0.f);
-        tri_v[3 * t + 2] = make_float4(cx, cy, cz, 0.f);
-    }
-    if (tri_n && nx) {
-        tri_n[3 * t + 0] = make_float4(nx[i0], ny[i0], nz[i0], 0.f);
-        tri_n[3 * t + 1] = make_float4(nx[i1], ny[i1], nz[i1], 0.f);
-        tri_n[3 * t + 2] = make_float4(nx[i2], ny[i2], nz[i2], 0.f);
-    }
+    block_bounds_reduce(mn, mx, bounds);
 }
 
 __global__ __launch_bounds__(kBlock) void deinterleave_kernel(const uint8_t* __restrict__ src, uint32_t count,
@@ -126,7 +162,6 @@ __global__ void bounds_init_kernel(uint32_t* bounds) {
 
 __global__ __launch_bounds__(kBlock) void bounds_kernel(const float* __restrict__ aabb6, uint64_t n,
                                                         uint32_t* __restrict__ bounds) {
-    __shared__ float red[6][kBlock / 64];
     float mn[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f};
     float mx[3] = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
     for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
@@ -138,23 +173,7 @@ __global__ __launch_bounds__(kBlock) void bounds_kernel(const float* __restrict_
             mx[k] = ref_max(mx[k], c);
         }
     }
-    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        float a = wave_min(mn[k]), b = wave_max(mx[k]);
-        if (lane == 0) {
-            red[k][wave] = a;
-            red[k + 3][wave] = b;
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x < 6) {
-        int k = threadIdx.x;
-        float v = red[k][0];
-        for (int w = 1; w < kBlock / 64; w++) v = (k < 3) ? fminf(v, red[k][w]) : fmaxf(v, red[k][w]);
-        if (k < 3) atomicMin(&bounds[k], f2ord(v));
-        else atomicMax(&bounds[k], f2ord(v));
-    }
+    block_bounds_reduce(mn, mx, bounds);
 }
 
 // ---- K2: lbvh_c_to_morton_code, lbvh.c:74-90 ----------------------------------------
@@ -219,6 +238,47 @@ __global__ __launch_bounds__(kBlock) void radix_hist_kernel(const uint64_t* __re
     block_hist[(uint64_t)threadIdx.x * tiles + blockIdx.x] = hist[threadIdx.x];
 }
 
+// Workgroup d turns row d of the digit-major tile histogram into exclusive prefix sums over the tiles
+// and leaves the row's total behind the table; the scatter kernel adds the digit bases itself.
+__global__ __launch_bounds__(kBlock) void radix_offsets_kernel(uint32_t* __restrict__ block_hist, uint32_t tiles) {
+    __shared__ uint32_t wave_tot[kBlock / 64];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    uint32_t* row = block_hist + (uint64_t)blockIdx.x * tiles;
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < tiles; base += kScanTile) {
+        const uint32_t first = base + (uint32_t)tid * kScanItems;
+        uint32_t v[kScanItems];
+        uint32_t run = 0;
+#pragma unroll
+        for (int j = 0; j < kScanItems; j++) {
+            v[j] = (first + j < tiles) ? row[first + j] : 0u;
+            run += v[j];
+        }
+        uint32_t incl = run;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            uint32_t up = __shfl_up(incl, o);
+            if (lane >= o) incl += up;
+        }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        uint32_t wsum = 0, total = 0;
+        for (int w = 0; w < kBlock / 64; w++) {
+            if (w < wave) wsum += wave_tot[w];
+            total += wave_tot[w];
+        }
+        uint32_t acc = carry + wsum + incl - run;
+#pragma unroll
+        for (int j = 0; j < kScanItems; j++) {
+            if (first + j < tiles) row[first + j] = acc;
+            acc += v[j];
+        }
+        carry += total;
+        __syncthreads();  // wave_tot is reused by the next round
+    }
+    if (tid == 0) block_hist[256ull * tiles + blockIdx.x] = carry;
+}
+
 // Each workgroup ranks its 4096 keys by the current digit (wave-level match-any on
 // ballots, wave-private LDS counters), sorts the tile in LDS and writes every digit
 // bucket to its place in the output with consecutive lanes on consecutive addresses.
@@ -227,7 +287,9 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(const uint64_t* _
                                                                uint64_t* __restrict__ keys_out,
                                                                uint32_t* __restrict__ vals_out, uint64_t n, int shift,
                                                                const uint32_t* __restrict__ gbase, uint32_t tiles) {
+    // gbase[d * tiles + t]: keys with digit d in the tiles before t; gbase[256 * tiles + d]: keys with digit d
     __shared__ uint32_t wave_cnt[kBlock / 64][256];
+    __shared__ uint32_t dig_tot[kBlock / 64];
     __shared__ uint32_t bin_start[256];
     __shared__ uint32_t out_base[256];
     __shared__ uint32_t wave_tot[kBlock / 64];
@@ -292,7 +354,19 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(const uint64_t* _
         for (int w = 0; w < wave; w++) wsum += wave_tot[w];
         uint32_t start = wsum + incl - run;
         bin_start[tid] = start;
-        out_base[tid] = gbase[(uint64_t)tid * tiles + blockIdx.x] - start;
+        // first output position of digit d = keys with a smaller digit (exclusive scan of the digit totals)
+        const uint32_t total = gbase[256ull * tiles + tid];
+        uint32_t dincl = total;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            uint32_t up = __shfl_up(dincl, o);
+            if (lane >= o) dincl += up;
+        }
+        if (lane == 63) dig_tot[wave] = dincl;
+        __syncthreads();
+        uint32_t dsum = 0;
+        for (int w = 0; w < wave; w++) dsum += dig_tot[w];
+        out_base[tid] = (dsum + dincl - total) + gbase[(uint64_t)tid * tiles + blockIdx.x] - start;
     }
     __syncthreads();
 
@@ -799,9 +873,19 @@ int mesh_prepare_device(rthip_ctx* ctx, const float* px, const float* py, const 
                         const float* ny, const float* nz, const uint32_t* indices, uint64_t n_tris,
                         float* d_aabb6, float4* d_tri_v, float4* d_tri_n, hipStream_t stream) {
     if (n_tris == 0) return RTHIP_OK;
-    tri_prepare_kernel<<<div_up(n_tris, kBlock), kBlock, 0, stream>>>(px, py, pz, nx, ny, nz, indices, n_tris,
-                                                                       d_aabb6, d_tri_v, d_tri_n);
+    RT_TRY(rthip_reserve(ctx, ctx->ws.bounds, 64));
+    uint32_t* bounds = (uint32_t*)ctx->ws.bounds.p;
+    bounds_init_kernel<<<1, 64, 0, stream>>>(bounds);
+    uint32_t blocks = div_up(n_tris, kBlock);
+    if (blocks > 4096) blocks = 4096;
+    tri_prepare_kernel<<<blocks, kBlock, 0, stream>>>(px, py, pz, nx, ny, nz, indices, n_tris, d_aabb6, d_tri_v, d_tri_n,
+                                                      bounds);
     RT_HIP(ctx, hipGetLastError());
+    // the centroid bounds of exactly these boxes are now in the workspace: the build that follows on this
+    // stream for this array can skip its own pass over them
+    ctx->bounds_of = d_aabb6;
+    ctx->bounds_n = n_tris;
+    ctx->bounds_stream = stream;
     return RTHIP_OK;
 }
 
@@ -825,7 +909,7 @@ int lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, float4* 
     RT_TRY(rthip_reserve(ctx, w.keys[1], n * 8));
     RT_TRY(rthip_reserve(ctx, w.vals[0], n * 4));
     RT_TRY(rthip_reserve(ctx, w.vals[1], n * 4));
-    RT_TRY(rthip_reserve(ctx, w.block_hist, hist_elems * 4));
+    RT_TRY(rthip_reserve(ctx, w.block_hist, (hist_elems + 256) * 4));
     RT_TRY(rthip_reserve(ctx, w.scan_tmp, (scan_tmp_elems(hist_elems) + scan_tmp_elems(n)) * 4));
     RT_TRY(rthip_reserve(ctx, w.prio, n));
     RT_TRY(rthip_reserve(ctx, w.child, 2 * n * sizeof(ChildRec)));
@@ -841,10 +925,13 @@ int lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, float4* 
     uint32_t* vals[2] = {(uint32_t*)w.vals[0].p, (uint32_t*)w.vals[1].p};
     uint32_t* scan_tmp = (uint32_t*)w.scan_tmp.p;
 
-    bounds_init_kernel<<<1, 64, 0, s>>>(bounds);
-    uint32_t bblocks = div_up(n, kBlock);
-    if (bblocks > 2048) bblocks = 2048;
-    bounds_kernel<<<bblocks, kBlock, 0, s>>>(d_aabb6, n, bounds);
+    if (!(ctx->bounds_of == d_aabb6 && ctx->bounds_n == n && ctx->bounds_stream == s)) {
+        bounds_init_kernel<<<1, 64, 0, s>>>(bounds);
+        uint32_t bblocks = div_up(n, kBlock);
+        if (bblocks > 2048) bblocks = 2048;
+        bounds_kernel<<<bblocks, kBlock, 0, s>>>(d_aabb6, n, bounds);
+    }
+    ctx->bounds_of = nullptr;
     morton_kernel<<<div_up(n, kBlock), kBlock, 0, s>>>(d_aabb6, n, bounds, keys[0], vals[0]);
     RT_HIP(ctx, hipGetLastError());
     if (d_codes_unsorted)
@@ -856,7 +943,7 @@ int lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, float4* 
             int shift = pass * 8;
             radix_hist_kernel<<<tiles, kBlock, 0, s>>>(keys[cur], n, shift, (uint32_t*)w.block_hist.p, tiles);
             RT_HIP(ctx, hipGetLastError());
-            RT_TRY((scan_u32<false>(ctx, (uint32_t*)w.block_hist.p, hist_elems, scan_tmp, s)));
+            radix_offsets_kernel<<<256, kBlock, 0, s>>>((uint32_t*)w.block_hist.p, tiles);
             radix_scatter_kernel<<<tiles, kBlock, 0, s>>>(keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, shift,
                                                           (const uint32_t*)w.block_hist.p, tiles);
             RT_HIP(ctx, hipGetLastError());

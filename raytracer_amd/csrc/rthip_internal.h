@@ -134,6 +134,10 @@ struct rthip_ctx {
     uint32_t static_percent = 0;   // share of the tiles dealt round-robin up front (RTHIP_STATIC overrides)
     uint32_t refill_lanes = 16;  // lanes with other work that end a traversal phase (RTHIP_REFILL overrides)
     DevBuf scratch_a, scratch_b, scratch_c, scratch_d, scratch_e;  // staging for host <-> device taps
+    // set by mesh_prepare_device: the workspace holds the centroid bounds of this box array (consumed by the next build)
+    const float* bounds_of = nullptr;
+    uint64_t bounds_n = 0;
+    hipStream_t bounds_stream = nullptr;
     float last_cast_ms = 0.f, last_build_ms = 0.f;
     uint32_t last_cast_kernel = 0;
 };
