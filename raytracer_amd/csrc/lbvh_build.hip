@@ -28,8 +28,9 @@
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kSortItems = 16;                  // keys per thread in the radix kernels
-constexpr int kSortTile = kBlock * kSortItems;  // 4096 keys per workgroup
+constexpr int kSortBlock = 1024;                    // threads per workgroup in the radix kernels
+constexpr int kSortItems = 4;                       // keys per thread
+constexpr int kSortTile = kSortBlock * kSortItems;  // 4096 keys per workgroup
 constexpr int kScanItems = 8;
 constexpr int kScanTile = kBlock * kScanItems;  // 2048 values per workgroup
 
@@ -223,19 +224,19 @@ __global__ __launch_bounds__(kBlock) void morton_kernel(const float* __restrict_
 // ---- K3: LSD radix sort, 8 bits per pass, stable ---------------------------------------
 // Replaces radsort(...) at lbvh.c:120.  Equal codes keep ascending primitive index.
 
-__global__ __launch_bounds__(kBlock) void radix_hist_kernel(const uint64_t* __restrict__ keys, uint64_t n, int shift,
-                                                            uint32_t* __restrict__ block_hist, uint32_t tiles) {
+__global__ __launch_bounds__(kSortBlock) void radix_hist_kernel(const uint64_t* __restrict__ keys, uint64_t n, int shift,
+                                                                uint32_t* __restrict__ block_hist, uint32_t tiles) {
     __shared__ uint32_t hist[256];
-    hist[threadIdx.x] = 0;
+    if (threadIdx.x < 256) hist[threadIdx.x] = 0;
     __syncthreads();
     uint64_t base = (uint64_t)blockIdx.x * kSortTile;
 #pragma unroll
     for (int j = 0; j < kSortItems; j++) {
-        uint64_t i = base + (uint64_t)j * kBlock + threadIdx.x;
+        uint64_t i = base + (uint64_t)j * kSortBlock + threadIdx.x;
         if (i < n) atomicAdd(&hist[(uint32_t)(keys[i] >> shift) & 255u], 1u);
     }
     __syncthreads();
-    block_hist[(uint64_t)threadIdx.x * tiles + blockIdx.x] = hist[threadIdx.x];
+    if (threadIdx.x < 256) block_hist[(uint64_t)threadIdx.x * tiles + blockIdx.x] = hist[threadIdx.x];
 }
 
 // Workgroup d turns row d of the digit-major tile histogram into exclusive prefix sums over the tiles
@@ -282,17 +283,17 @@ __global__ __launch_bounds__(kBlock) void radix_offsets_kernel(uint32_t* __restr
 // Each workgroup ranks its 4096 keys by the current digit (wave-level match-any on
 // ballots, wave-private LDS counters), sorts the tile in LDS and writes every digit
 // bucket to its place in the output with consecutive lanes on consecutive addresses.
-__global__ __launch_bounds__(kBlock) void radix_scatter_kernel(const uint64_t* __restrict__ keys_in,
-                                                               const uint32_t* __restrict__ vals_in,
-                                                               uint64_t* __restrict__ keys_out,
-                                                               uint32_t* __restrict__ vals_out, uint64_t n, int shift,
-                                                               const uint32_t* __restrict__ gbase, uint32_t tiles) {
+__global__ __launch_bounds__(kSortBlock) void radix_scatter_kernel(const uint64_t* __restrict__ keys_in,
+                                                                   const uint32_t* __restrict__ vals_in,
+                                                                   uint64_t* __restrict__ keys_out,
+                                                                   uint32_t* __restrict__ vals_out, uint64_t n, int shift,
+                                                                   const uint32_t* __restrict__ gbase, uint32_t tiles) {
     // gbase[d * tiles + t]: keys with digit d in the tiles before t; gbase[256 * tiles + d]: keys with digit d
-    __shared__ uint32_t wave_cnt[kBlock / 64][256];
-    __shared__ uint32_t dig_tot[kBlock / 64];
+    constexpr int kWaves = kSortBlock / 64;
+    __shared__ uint32_t wave_cnt[kWaves][256];
     __shared__ uint32_t bin_start[256];
     __shared__ uint32_t out_base[256];
-    __shared__ uint32_t wave_tot[kBlock / 64];
+    __shared__ uint32_t wave_tot[4], dig_tot[4];  // the 256 digits live on the first four waves
     __shared__ uint64_t skeys[kSortTile];
     __shared__ uint32_t svals[kSortTile];
 
@@ -300,8 +301,7 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(const uint64_t* _
     const uint64_t base = (uint64_t)blockIdx.x * kSortTile;
     const uint64_t wbase = base + (uint64_t)wave * (64 * kSortItems);
 
-#pragma unroll
-    for (int w = 0; w < kBlock / 64; w++) wave_cnt[w][tid] = 0;
+    for (int k = tid; k < kWaves * 256; k += kSortBlock) (&wave_cnt[0][0])[k] = 0;
 
     uint64_t key[kSortItems];
 #pragma unroll
@@ -334,39 +334,43 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(const uint64_t* _
     }
     __syncthreads();
 
-    {   // thread d: offsets of each wave inside digit d, digit totals, exclusive scan of the totals
+    {   // thread d < 256: offsets of each wave inside digit d, digit totals, exclusive scans over the digits
+        const bool owner = tid < 256;
         uint32_t run = 0;
+        if (owner) {
 #pragma unroll
-        for (int w = 0; w < kBlock / 64; w++) {
-            uint32_t c = wave_cnt[w][tid];
-            wave_cnt[w][tid] = run;
-            run += c;
+            for (int w = 0; w < kWaves; w++) {
+                uint32_t c = wave_cnt[w][tid];
+                wave_cnt[w][tid] = run;
+                run += c;
+            }
         }
-        uint32_t incl = run;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            uint32_t up = __shfl_up(incl, o);
-            if (lane >= o) incl += up;
-        }
-        if (lane == 63) wave_tot[wave] = incl;
-        __syncthreads();
-        uint32_t wsum = 0;
-        for (int w = 0; w < wave; w++) wsum += wave_tot[w];
-        uint32_t start = wsum + incl - run;
-        bin_start[tid] = start;
-        // first output position of digit d = keys with a smaller digit (exclusive scan of the digit totals)
-        const uint32_t total = gbase[256ull * tiles + tid];
-        uint32_t dincl = total;
+        const uint32_t total = owner ? gbase[256ull * tiles + tid] : 0u;
+        uint32_t incl = run, dincl = total;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
-            uint32_t up = __shfl_up(dincl, o);
-            if (lane >= o) dincl += up;
+            uint32_t up = __shfl_up(incl, o), dup = __shfl_up(dincl, o);
+            if (lane >= o) {
+                incl += up;
+                dincl += dup;
+            }
         }
-        if (lane == 63) dig_tot[wave] = dincl;
+        if (owner && lane == 63) {
+            wave_tot[wave] = incl;
+            dig_tot[wave] = dincl;
+        }
         __syncthreads();
-        uint32_t dsum = 0;
-        for (int w = 0; w < wave; w++) dsum += dig_tot[w];
-        out_base[tid] = (dsum + dincl - total) + gbase[(uint64_t)tid * tiles + blockIdx.x] - start;
+        if (owner) {
+            uint32_t wsum = 0, dsum = 0;
+            for (int w = 0; w < wave; w++) {
+                wsum += wave_tot[w];
+                dsum += dig_tot[w];
+            }
+            const uint32_t start = wsum + incl - run;
+            bin_start[tid] = start;
+            // first output position of digit d = keys with a smaller digit + keys with digit d in earlier tiles
+            out_base[tid] = (dsum + dincl - total) + gbase[(uint64_t)tid * tiles + blockIdx.x] - start;
+        }
     }
     __syncthreads();
 
@@ -384,7 +388,7 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(const uint64_t* _
     uint32_t valid = left < (uint64_t)kSortTile ? (uint32_t)left : (uint32_t)kSortTile;
 #pragma unroll
     for (int j = 0; j < kSortItems; j++) {
-        uint32_t p = (uint32_t)j * kBlock + tid;
+        uint32_t p = (uint32_t)j * kSortBlock + tid;
         if (p < valid) {
             uint64_t k = skeys[p];
             uint32_t d = (uint32_t)(k >> shift) & 255u;
@@ -941,10 +945,10 @@ int lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, float4* 
     if (n > 1) {
         for (int pass = 0; pass < 8; pass++) {
             int shift = pass * 8;
-            radix_hist_kernel<<<tiles, kBlock, 0, s>>>(keys[cur], n, shift, (uint32_t*)w.block_hist.p, tiles);
+            radix_hist_kernel<<<tiles, kSortBlock, 0, s>>>(keys[cur], n, shift, (uint32_t*)w.block_hist.p, tiles);
             RT_HIP(ctx, hipGetLastError());
             radix_offsets_kernel<<<256, kBlock, 0, s>>>((uint32_t*)w.block_hist.p, tiles);
-            radix_scatter_kernel<<<tiles, kBlock, 0, s>>>(keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, shift,
+            radix_scatter_kernel<<<tiles, kSortBlock, 0, s>>>(keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, shift,
                                                           (const uint32_t*)w.block_hist.p, tiles);
             RT_HIP(ctx, hipGetLastError());
             cur ^= 1;
