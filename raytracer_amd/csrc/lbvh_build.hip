@@ -682,10 +682,12 @@ __global__ __launch_bounds__(kChunk) void hierarchy_local_kernel(uint32_t n, con
         mine.far_end = parent_right ? l : r;
         mine.dl = dl;
         lrec[2 * slot + side] = mine;
-        __threadfence_block();
+        // order the LDS record before the LDS counter and the counter before the sibling's record; LDS only:
+        // a fence that also covered global memory would make every level wait for the node stores below it
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
         const uint32_t old = atomicAdd(&lflag[slot], 1u);
         if (old == 0) break;  // first to arrive: the sibling's thread carries on from here
-        __threadfence_block();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
         const ChildRec sib = lrec[2 * slot + (1u - side)];
         merge_sibling(box, sib.box, side == 0);
         if (side == 0) {
