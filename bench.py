@@ -61,6 +61,11 @@ def make_workload(name: str):
         return dict(world=w, cam=cam, sky=sky, width=4096, height=1024, samples=1, bounces=1, rays=1 << 22,
                     ray_box=((-125.0, -1.0, -125.0), (125.0, 3.0, 125.0)),
                     label="bunny-class mesh x 10000 instances, 2^22 incoherent rays through the grid's box")
+    if name == "cornell-mesh":
+        verts, idx = scenes.bunny_class_mesh()
+        w, cam, sky = scenes.cornell(extra_mesh=(verts, idx))
+        return dict(world=w, cam=cam, sky=sky, width=3840, height=2160, samples=4, bounces=8,
+                    label="Cornell box + bunny-class mesh (metal, x80) on the short box, 3840x2160, bounces=8")
     if name == "cornell":
         w, cam, sky = scenes.cornell()
         return dict(world=w, cam=cam, sky=sky, width=512, height=512, samples=2, bounces=8,
@@ -229,6 +234,10 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="bunny")
+    ap.add_argument("--samples", type=int, default=0, help="samples per pixel axis (spp = samples^2); 0 = the workload's own")
+    ap.add_argument("--shard", default="frames", choices=["frames", "tiles", "samples"],
+                    help="N > 1: every rank renders its own frame (weak scaling), or the ranks split one frame by "
+                         "64x64 tiles or by sample index (strong scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--build-sizes", default="81920,1000000,10000000")
     args = ap.parse_args()
@@ -250,6 +259,9 @@ def main():
     from raytracer_amd import abi, dist as rdist, tracer as T, world as Wd
 
     wl = make_workload(args.workload)
+    if args.samples > 0:
+        wl["samples"] = args.samples
+    wl["label"] += f", samples={wl['samples']}" if "samples=" not in wl["label"] else ""
     W, H = wl["width"], wl["height"]
     tr = T.rt_make_tracer(T.RT_TracerSettings(max_bounces=wl["bounces"], sky=wl["sky"]), device_id=local_rank)
     T.rt_tracer_build_blas(tr, wl["world"])
@@ -260,9 +272,10 @@ def main():
 
     # two framebuffers: the RCCL reduce of frame k overlaps the render of frame k + 1
     pipe = rdist.FramePipeline([torch.zeros((H, W, 3), dtype=torch.float32, device="cuda") for _ in range(2)],
-                               "frames", wl["samples"], world, dst=0)
+                               args.shard, wl["samples"], world, dst=0)
     stream = torch.cuda.current_stream()
-    seed = 1 + rank
+    seed = 1 + (rank if args.shard == "frames" else 0)
+    shard = rdist.shard_record(args.shard, rank, world)
 
     ray_o = ray_d = ray_hits = None
     if "rays" in wl:  # a ray-stream workload: closest-hit queries for explicit rays instead of a frame
@@ -288,7 +301,7 @@ def main():
         fb = pipe.acquire()
         if events:
             events[0].record(stream)
-        rc = tr.lib.rthip_cast_device(tr.h, abi.ptr(cast), seed, fb.data_ptr(), W, H, None, stream.cuda_stream)
+        rc = tr.lib.rthip_cast_device(tr.h, abi.ptr(cast), seed, fb.data_ptr(), W, H, abi.ptr(shard), stream.cuda_stream)
         if events:
             events[1].record(stream)
         tr.check(rc, "rthip_cast_device")
@@ -331,8 +344,9 @@ def main():
     elapsed = float(t_all.item())
     total_rays = float(r_all.item())
 
-    kernel_name = {0: "cast_kernel (persistent)", 1: "cast_static_kernel", 2: "wf_trace_kernel + wf_shade_kernel (wavefront)"}[
-        T.get_stats(tr)["last_cast_kernel"]]
+    last = T.get_stats(tr)
+    kernel_name = {0: f"cast_kernel (persistent, refill {last['last_cast_refill']})", 1: "cast_static_kernel",
+                   2: "wf_trace_kernel + wf_shade_kernel (wavefront)"}[last["last_cast_kernel"]]
     if ray_o is not None:
         kernel_name = "trace_rays_kernel"
     traffic = recorded_traffic(args.workload, kernel_name)
@@ -348,12 +362,14 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "weak" if args.shard == "frames" else "strong",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": wl["label"], "rays_per_frame_per_gpu": int(rays), "sharding": "every rank renders the "
-                       "frame with its own sample set; framebuffers summed onto rank 0 with RCCL" if world > 1 else "none"},
+            "config": {"workload": wl["label"], "rays_per_frame_per_gpu": int(rays), "sharding": "none" if world == 1 else {
+                           "frames": "every rank renders the frame with its own sample set; framebuffers summed onto rank 0 with RCCL",
+                           "tiles": "ranks render interleaved 64x64 tiles of one frame; shares summed onto rank 0 with RCCL",
+                           "samples": "ranks render sample indices s % N == rank of one frame; sums added onto rank 0 with RCCL"}[args.shard]},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "kernel": kernel_name,
                          "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": int(algo_bytes),

@@ -129,7 +129,7 @@ typedef struct rthip_stats {
     float last_cast_ms;     /* device time of the last cast / trace kernel(s) */
     float last_build_ms;    /* device time of the last LBVH build             */
     uint32_t last_cast_kernel; /* RTHIP_KERNEL_* the last cast ran (never AUTO)  */
-    uint32_t reserved;
+    uint32_t last_cast_refill; /* persistent kernel: idle lanes that end a traversal phase; else 0 */
 } rthip_stats;
 
 typedef struct rthip_ctx rthip_ctx;
@@ -250,7 +250,11 @@ int rthip_set_counting(rthip_ctx* ctx, int enabled);
 
 /* Which kernel rthip_cast / rthip_cast_device run.  All of them produce the same bits.  No
  * counterpart in the reference (its renderer is one loop, raytracer_cpu.c:179-242).
- *   RTHIP_KERNEL_AUTO        static for small scenes, persistent for deep ones (default)
+ *   RTHIP_KERNEL_AUTO        default.  Frames of 2^26 paths and more: the candidates (static, persistent with
+ *                            three refill thresholds) first render a sparse sample of tiles and the fastest is
+ *                            kept for this scene and frame geometry (the first such call waits on the stream;
+ *                            skipped under stream capture).  Smaller frames: static for small scenes,
+ *                            persistent for deep ones
  *   RTHIP_KERNEL_PERSISTENT  resident waves, lanes take a new path as soon as theirs ends
  *   RTHIP_KERNEL_STATIC      one pixel per thread
  *   RTHIP_KERNEL_WAVEFRONT   ray generation, traversal, shading and resolve as separate kernels

@@ -41,7 +41,7 @@ SHARD = np.dtype([("mode", "<u4"), ("rank", "<u4"), ("world", "<u4")], align=Fal
 STATS = np.dtype(
     [("rays", "<u8"), ("nodes_tested", "<u8"), ("tris_tested", "<u8"), ("inst_entered", "<u8"),
      ("wave_steps", "<u8"), ("last_cast_ms", "<f4"), ("last_build_ms", "<f4"),
-     ("last_cast_kernel", "<u4"), ("reserved", "<u4")],
+     ("last_cast_kernel", "<u4"), ("last_cast_refill", "<u4")],
     align=False,
 )
 assert MATERIAL.itemsize == 40 and INSTANCE.itemsize == 68 and CAST.itemsize == 84

@@ -146,6 +146,8 @@ void rthip_destroy(rthip_ctx* ctx) {
     for (DevBuf& b : ctx->wf) rthip_release(b);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->tune_ev0) (void)hipEventDestroy(ctx->tune_ev0);
+    if (ctx->tune_ev1) (void)hipEventDestroy(ctx->tune_ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -156,6 +158,7 @@ int rthip_set_tracer(rthip_ctx* ctx, uint32_t max_bounces, int sky) {
         return rthip_fail(ctx, RTHIP_E_LIMIT, "max_bounces must be < 64, got %u", max_bounces);
     ctx->max_bounces = max_bounces;
     ctx->sky = sky ? 1 : 0;
+    ctx->scene_generation++;
     return RTHIP_OK;
 }
 
@@ -286,6 +289,7 @@ int rthip_blas_commit(rthip_ctx* ctx) {
     }
     ctx->last_build_ms = total_ms;
     ctx->blas_committed = true;
+    ctx->scene_generation++;
     return RTHIP_OK;
 }
 
@@ -333,6 +337,7 @@ int rthip_tlas_build(rthip_ctx* ctx, const rthip_instance* instances, uint32_t n
     RT_HIP(ctx, hipDeviceSynchronize());  // the previous structure may still be in use by an enqueued cast
     ctx->tlas_built = false;
     ctx->n_inst = n_instances;
+    ctx->scene_generation++;
     ctx->n_mats = n_materials;
     RT_TRY(rthip_reserve(ctx, ctx->inst, (size_t)n_instances * sizeof(DevInstance)));
     RT_TRY(rthip_reserve(ctx, ctx->mats, (size_t)n_materials * sizeof(rthip_material)));
@@ -554,7 +559,7 @@ int rthip_get_stats(rthip_ctx* ctx, rthip_stats* out) {
     out->last_cast_ms = ctx->last_cast_ms;
     out->last_build_ms = ctx->last_build_ms;
     out->last_cast_kernel = ctx->last_cast_kernel;
-    out->reserved = 0;
+    out->last_cast_refill = ctx->last_cast_refill;
     return RTHIP_OK;
 }
 

@@ -139,7 +139,15 @@ struct rthip_ctx {
     uint64_t bounds_n = 0;
     hipStream_t bounds_stream = nullptr;
     float last_cast_ms = 0.f, last_build_ms = 0.f;
-    uint32_t last_cast_kernel = 0;
+    uint32_t last_cast_kernel = 0, last_cast_refill = 0;
+    // measured kernel choice of RTHIP_KERNEL_AUTO for big frames (see tune_cast); scene_generation changes with every
+    // build and tracer setting
+    uint64_t scene_generation = 0;
+    hipEvent_t tune_ev0 = nullptr, tune_ev1 = nullptr;
+    bool tuned = false;
+    uint64_t tuned_key[4] = {0, 0, 0, 0};
+    int tuned_kernel = 1;
+    uint32_t tuned_refill = 16;
 };
 
 // ---- helpers (rthip_api.hip) -------------------------------------------------

@@ -2,6 +2,8 @@
 // per-lane refill, the fixed pixel-per-thread kernel, and the parity taps (primary hits, caller
 // supplied rays).  Device-side building blocks live in rt_device.h.
 
+#include <cstring>
+
 #include "rt_device.h"
 
 namespace {
@@ -474,35 +476,27 @@ int primary_hits_launch(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_
     return RTHIP_OK;
 }
 
-int cast_launch(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_settings& cast, uint64_t seed, float* d_rgb,
-                int width, int height, rthip_shard shard, uint64_t* d_counters, hipStream_t stream) {
-    ctx->last_cast_kernel = 2;
-    if (ctx->cast_mode == 2)
-        return cast_wavefront_launch(ctx, scene, cast, seed, d_rgb, width, height, shard, d_counters, stream);
-    const size_t lds_bytes = (size_t)(scene.max_bounces ? scene.max_bounces : 1) * kBlock * sizeof(uint32_t);
-    int mode = ctx->cast_mode;
-    if (mode == 3) {
-        // Paths through a small scene are short and alike, and the pixel-per-thread kernel has the least
-        // bookkeeping per ray; deep scenes (many instances, large meshes) have long-tailed walks that pay
-        // for the persistent kernel's lane refill.
-        mode = (ctx->n_inst >= 64u || ctx->total_tris >= (1ull << 20)) ? 0 : 1;
-    }
-    ctx->last_cast_kernel = (uint32_t)mode;
-    if (mode == 1) {
-        const uint32_t sblocks = div_up(width, 16) * div_up(height, 16);
-        if (d_counters)
-            cast_static_kernel<true><<<sblocks, kBlock, lds_bytes, stream>>>(scene, cast, seed, d_rgb, width, height, shard, d_counters);
-        else
-            cast_static_kernel<false><<<sblocks, kBlock, lds_bytes, stream>>>(scene, cast, seed, d_rgb, width, height, shard, nullptr);
-        RT_HIP(ctx, hipGetLastError());
-        return RTHIP_OK;
-    }
-    // persistent grid: as many workgroups as are resident at once (256 CUs x 5 at 96 VGPRs), never more than the work
+namespace {
+
+int launch_static(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_settings& cast, uint64_t seed, float* d_rgb,
+                  int width, int height, rthip_shard shard, uint64_t* d_counters, hipStream_t stream) {
+    const size_t lds = (size_t)(scene.max_bounces ? scene.max_bounces : 1) * kBlock * sizeof(uint32_t);
+    const uint32_t blocks = div_up(width, 16) * div_up(height, 16);
+    if (d_counters)
+        cast_static_kernel<true><<<blocks, kBlock, lds, stream>>>(scene, cast, seed, d_rgb, width, height, shard, d_counters);
+    else
+        cast_static_kernel<false><<<blocks, kBlock, lds, stream>>>(scene, cast, seed, d_rgb, width, height, shard, nullptr);
+    RT_HIP(ctx, hipGetLastError());
+    return RTHIP_OK;
+}
+
+int launch_persistent(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_settings& cast, uint64_t seed, float* d_rgb,
+                      int width, int height, rthip_shard shard, uint32_t refill, uint64_t* d_counters, hipStream_t stream) {
+    // persistent grid: as many workgroups as are resident at once (CUs x 5 at 96 VGPRs), never more than the work
     const uint64_t total = (uint64_t)div_up(width, 8) * div_up(height, 8) * 64ull;
     uint32_t blocks = div_up(total, kBlock);
     if (blocks > ctx->persistent_blocks) blocks = ctx->persistent_blocks;
     const size_t lds = (size_t)(scene.max_bounces ? scene.max_bounces : 1) * kBlock * sizeof(uint32_t);
-    const uint32_t refill = ctx->refill_lanes;
     // every launch gets its own zeroed set of 8 work counters (one 128-byte line each) out of a small
     // ring, so that casts enqueued back to back (or on two streams) do not share them
     uint32_t* work = (uint32_t*)ctx->work_ring.p + (size_t)(ctx->work_next++ % 16u) * 256u;
@@ -519,4 +513,95 @@ int cast_launch(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_settings
                                                             static_rounds, refill, nullptr);
     RT_HIP(ctx, hipGetLastError());
     return RTHIP_OK;
+}
+
+struct Candidate {
+    int kernel;       // RTHIP_KERNEL_STATIC or RTHIP_KERNEL_PERSISTENT
+    uint32_t refill;  // persistent only
+};
+
+// Which renderer suits this scene and camera is a property of how long and how unequal the paths are,
+// which nothing but running them tells.  For a big frame the choice is therefore measured: every
+// candidate renders the same sparse sample of 64x64 tiles (1 tile in `stride`, about 2M paths) into the caller's
+// framebuffer, which the real render overwrites afterwards; the fastest one is kept until the scene,
+// the tracer settings or the frame geometry change.  The probe waits on the stream, so it is skipped
+// while the stream is being captured.
+int tune_cast(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_settings& cast, uint64_t seed, float* d_rgb, int width,
+              int height, rthip_shard shard, hipStream_t stream, Candidate* best) {
+    static const Candidate candidates[] = {{1, 0}, {0, 16}, {0, 32}, {0, 48}};
+    // a probe run: about 2M paths (several per resident lane), at most 2x2 samples per pixel
+    rthip_cast_settings pc = cast;
+    if (pc.samples > 2) pc.samples = 2;
+    const uint64_t probe_pixels = (2ull << 20) / ((uint64_t)pc.samples * pc.samples);
+    const uint32_t tiles64 = div_up(width, 64) * div_up(height, 64);
+    uint32_t stride = (uint32_t)((uint64_t)tiles64 * 4096ull / probe_pixels);
+    if (stride < 1) stride = 1;
+    rthip_shard probe = {1u, 0u, stride};
+    if (shard.mode == 1) {  // stay inside this rank's own tiles
+        probe.world = shard.world * stride;
+        probe.rank = shard.rank;
+    }
+    if (!ctx->tune_ev0) {  // events of the tuner's own: the callers time their casts with the context's pair
+        RT_HIP(ctx, hipEventCreate(&ctx->tune_ev0));
+        RT_HIP(ctx, hipEventCreate(&ctx->tune_ev1));
+    }
+    float best_ms = 0.f;
+    bool warm[2] = {false, false};  // the first launch of a kernel also pays for loading its code
+    for (size_t k = 0; k < sizeof(candidates) / sizeof(candidates[0]); k++) {
+        float ms = 0.f;
+        for (int rep = warm[candidates[k].kernel] ? 1 : 0; rep < 2; rep++) {
+            RT_HIP(ctx, hipEventRecord(ctx->tune_ev0, stream));
+            if (candidates[k].kernel == 1)
+                RT_TRY(launch_static(ctx, scene, pc, seed, d_rgb, width, height, probe, nullptr, stream));
+            else
+                RT_TRY(launch_persistent(ctx, scene, pc, seed, d_rgb, width, height, probe, candidates[k].refill, nullptr,
+                                         stream));
+            RT_HIP(ctx, hipEventRecord(ctx->tune_ev1, stream));
+            RT_HIP(ctx, hipEventSynchronize(ctx->tune_ev1));
+            RT_HIP(ctx, hipEventElapsedTime(&ms, ctx->tune_ev0, ctx->tune_ev1));
+        }
+        warm[candidates[k].kernel] = true;
+        if (k == 0 || ms < best_ms) {
+            best_ms = ms;
+            *best = candidates[k];
+        }
+    }
+    return RTHIP_OK;
+}
+
+}  // namespace
+
+int cast_launch(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_settings& cast, uint64_t seed, float* d_rgb,
+                int width, int height, rthip_shard shard, uint64_t* d_counters, hipStream_t stream) {
+    ctx->last_cast_kernel = 2;
+    if (ctx->cast_mode == 2)
+        return cast_wavefront_launch(ctx, scene, cast, seed, d_rgb, width, height, shard, d_counters, stream);
+    Candidate choice = {ctx->cast_mode, ctx->refill_lanes};
+    if (ctx->cast_mode == 3) {
+        const uint64_t spp = (uint64_t)cast.samples * cast.samples;
+        const uint64_t paths = (uint64_t)width * (uint64_t)height * spp;
+        const uint64_t key[4] = {ctx->scene_generation, ((uint64_t)(uint32_t)width << 32) | (uint32_t)height, spp,
+                                 ((uint64_t)shard.mode << 32) | shard.world};
+        hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+        if (stream) (void)hipStreamIsCapturing(stream, &capturing);
+        if (ctx->tuned && memcmp(key, ctx->tuned_key, sizeof key) == 0) {
+            choice = {ctx->tuned_kernel, ctx->tuned_refill};
+        } else if (paths >= (1ull << 26) && capturing == hipStreamCaptureStatusNone) {
+            RT_TRY(tune_cast(ctx, scene, cast, seed, d_rgb, width, height, shard, stream, &choice));
+            ctx->tuned = true;
+            memcpy(ctx->tuned_key, key, sizeof key);
+            ctx->tuned_kernel = choice.kernel;
+            ctx->tuned_refill = choice.refill;
+        } else {
+            // Small frames are not worth a probe.  Paths through a small scene are short and alike, and the
+            // pixel-per-thread kernel has the least bookkeeping per ray; deep scenes (many instances, large
+            // meshes) have long-tailed walks that pay for the persistent kernel's lane refill.
+            choice.kernel = (ctx->n_inst >= 64u || ctx->total_tris >= (1ull << 20)) ? 0 : 1;
+            choice.refill = ctx->refill_lanes;
+        }
+    }
+    ctx->last_cast_kernel = (uint32_t)choice.kernel;
+    ctx->last_cast_refill = choice.kernel == 0 ? choice.refill : 0u;
+    if (choice.kernel == 1) return launch_static(ctx, scene, cast, seed, d_rgb, width, height, shard, d_counters, stream);
+    return launch_persistent(ctx, scene, cast, seed, d_rgb, width, height, shard, choice.refill, d_counters, stream);
 }

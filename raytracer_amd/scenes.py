@@ -148,8 +148,12 @@ def _set_mesh(m, verts, indices, attrs):
     m.attrs = attrs
 
 
-def cornell():
-    """src/demos/cornell/main.c:79-226.  Returns (world, camera(width, height, samples), sky)."""
+def cornell(extra_mesh=None):
+    """src/demos/cornell/main.c:79-226.  Returns (world, camera(width, height, samples), sky).
+
+    extra_mesh = (verts, indices) of a PN mesh centred near (-0.3, 1.2, 0) with radius about 1 (the
+    bunny-class mesh) adds one instance of it, scaled by 80, standing on the short box: the 4K
+    multi-GPU configuration.  Without it the scene is exactly the demo's."""
     world = rt_make_world()
     box_v = np.array([[-1, -1, -1, 0], [1, -1, -1, 0], [1, 1, -1, 0], [1, -1, 1, 0], [1, 1, 1, 0], [-1, 1, -1, 0],
                       [-1, 1, 1, 0], [-1, -1, 1, 0]], dtype=np.float32)
@@ -203,6 +207,18 @@ def cornell():
     e3 = (ext, ext, ext)
     add_box(white, elmul3(sub3(v3(130, 0, 65), e3), flip), elmul3(sub3(v3(295, 165, 230), e3), flip))
     add_box(white, elmul3(sub3(v3(265, 0, 295), e3), flip), elmul3(sub3(v3(430, 330, 460), e3), flip))
+
+    if extra_mesh is not None:
+        verts, indices = extra_mesh
+        mesh = rt_world_add_mesh(world)
+        _set_mesh(mesh, verts, indices, GEO_P | GEO_N)
+        it = rt_world_add_instance(world)
+        it.type, it.material, it.mesh = abi.INST_MESH, metal, mesh
+        s80 = f32(80)
+        # the mesh's centre (-0.3, 1.2, 0) goes to (65, -112.5 + 85, 130): above the middle of the short box's top face
+        it.translation = (f32(65) + f32(0.3) * s80, f32(-27.5) - f32(1.2) * s80, f32(130))
+        it.rotation = IDENTITY_QUAT
+        it.scale = (s80, s80, s80)
 
     def camera(width, height, samples):
         return get_rt_cast_settings(width, height, samples, (z, z, f32(2.4) * ext), (0, 0, 0), vfov=degrees_to_rad(40))

@@ -231,6 +231,64 @@ def test_every_cast_kernel_gives_the_same_bits(oracle, gpu_tracer, kernel):
         T.set_cast_kernel(gpu_tracer, "auto")
 
 
+def test_cornell_with_mesh_scene(oracle, gpu_tracer):
+    """The multi-GPU configuration's scene (Cornell box + a metal PN mesh): trees, radiance and a tile shard."""
+    verts, indices = scenes.bunny_class_mesh(3)
+    w, cam, sky = scenes.cornell(extra_mesh=(verts, indices))
+    build(gpu_tracer, w, 8, sky)
+    flat = world.flatten_world(w)
+    sc = oracle.Scene(flat, 8, sky)
+    assert_same_tree(T.get_tree(gpu_tracer, -1), sc.tree(-1), "TLAS")
+    for k in range(len(flat.meshes)):
+        assert_same_tree(T.get_tree(gpu_tracer, k), sc.tree(k), f"BLAS {k}")
+    wd, ht, smp = 96, 54, 2
+    c = cam(wd, ht, smp)
+    img = np.zeros((ht, wd, 3), dtype=np.float32)
+    T.rt_tracer_cast(gpu_tracer, c, img, wd, ht, seed=11)
+    want, _ = sc.cast(c, 11, wd, ht, rng_mode=oracle.RNG_COUNTER, threads=8)
+    assert (bits(img) == bits(want)).all()
+    assert float(img.mean()) > 0.01  # the light is seen
+
+
+def test_auto_kernel_choice_changes_no_bit(gpu_tracer):
+    """A frame of 2^26 paths makes RTHIP_KERNEL_AUTO time its candidates on a sparse sample of tiles first
+    (into the same framebuffer); the frame must come out exactly as from a fixed kernel, also from the
+    cached choice, and also under a tile shard."""
+    import torch
+
+    verts, indices = scenes.bunny_class_mesh(3)
+    w, cam, sky = scenes.cornell(extra_mesh=(verts, indices))
+    build(gpu_tracer, w, 8, sky)
+    wd = ht = 2048
+    c = cam(wd, ht, 4)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def render(shard=None):
+        buf = torch.full((ht, wd, 3), 3.0, dtype=torch.float32, device="cuda:0")
+        sh = None
+        if shard:
+            sh = np.zeros(1, dtype=abi.SHARD)
+            sh[0] = shard
+        gpu_tracer.check(gpu_tracer.lib.rthip_cast_device(gpu_tracer.h, abi.ptr(c), 21, buf.data_ptr(), wd, ht,
+                                                          abi.ptr(sh) if shard else None, stream), "rthip_cast_device")
+        torch.cuda.synchronize()
+        return buf
+
+    try:
+        T.set_cast_kernel(gpu_tracer, "static")
+        want = render()
+        want_shard = render((1, 1, 3))
+        T.set_cast_kernel(gpu_tracer, "auto")
+        first = render()
+        st = T.get_stats(gpu_tracer)
+        assert st["last_cast_kernel"] in (0, 1)
+        assert torch.equal(first.view(torch.int32), want.view(torch.int32)), "frame after the probe differs"
+        assert torch.equal(render().view(torch.int32), want.view(torch.int32)), "frame from the cached choice differs"
+        assert torch.equal(render((1, 1, 3)).view(torch.int32), want_shard.view(torch.int32)), "tile shard differs"
+    finally:
+        T.set_cast_kernel(gpu_tracer, "auto")
+
+
 def test_long_ray_stream(oracle, gpu_tracer):
     """Ray streams of 2^18 rays and more go through the resident-wave kernel with lane refill: same
     answers and the same traversal counters as the oracle, with a ragged tail."""
