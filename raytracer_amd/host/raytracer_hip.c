@@ -24,6 +24,35 @@ static void rt_hip_check(RT_HIP_Tracer* tracer, int rc, const char* what) {
     AssertAlways(rc == RTHIP_OK);
 }
 
+// The reference's tree dump (lbvh_dump_tree, src/lbvh/extra/dump.c:1-23, read by extra/blender.py): the
+// pointer tree in depth-first order, per node a 1-byte sentinel 1, the u64 id, min, max, and a sentinel 0
+// for every NULL child.  The GPU tree is already stored in that order (left child = next record), and a
+// node is a leaf exactly when its id is not 0, so the file is one pass over the node array.
+static void rt_hip_dump_tree(RT_HIP_Tracer* tracer, int which, const char* path) {
+    u64 count = 0;
+    rt_hip_check(tracer, rthip_get_tree(tracer->ctx, which, NULL, &count), "rthip_get_tree");
+    FILE* f = fopen(path, "w");
+    if (!f) return;
+    {DeferResource(Temp scratch = scratch_begin(NULL, 0), scratch_end(scratch)) {
+        rthip_node* nodes = push_array(scratch.arena, rthip_node, count + 1);
+        if (count) rt_hip_check(tracer, rthip_get_tree(tracer->ctx, which, nodes, &count), "rthip_get_tree");
+        if (count == 0) {
+            u8 none = 0;
+            fwrite(&none, 1, 1, f);
+        }
+        for (u64 i = 0; i < count; i++) {
+            u8 one = 1, none[2] = {0, 0};
+            u64 id = nodes[i].id;
+            fwrite(&one, 1, 1, f);
+            fwrite(&id, sizeof(id), 1, f);
+            fwrite(nodes[i].aabb_min, sizeof(f32), 3, f);
+            fwrite(nodes[i].aabb_max, sizeof(f32), 3, f);
+            if (id != 0) fwrite(none, 1, 2, f);
+        }
+    }}
+    fclose(f);
+}
+
 // rt_make_tracer: one GPU context per tracer.  The device is GPU 0 unless RT_HIP_DEVICE says otherwise.
 //
 // Random numbers: the CPU backend consumes the process-wide rand() stream that the demo seeded with
@@ -76,6 +105,19 @@ rt_hook void rt_tracer_build_blas(RT_Handle handle, RT_World* world) {
         idx++;
     }
     rt_hip_check(tracer, rthip_blas_commit(tracer->ctx), "rthip_blas_commit");
+
+#if BUILD_DEBUG
+    // "<mesh name>.bvh" per named mesh, as the CPU backend writes them (raytracer_cpu.c:92-97)
+    {DeferResource(Temp scratch = scratch_begin(NULL, 0), scratch_end(scratch)) {
+        for EachList(node, RT_MeshNode, meshes->first) {
+            RT_Mesh* mesh = &node->v;
+            if (mesh->name.length > 0) {
+                NTString8 path = ntstr8_concatenate(scratch.arena, mesh->name, ntstr8_lit(".bvh"));
+                rt_hip_dump_tree(tracer, (int)mesh->blas_id, path.cstr);
+            }
+        }
+    }}
+#endif
 }
 
 // rt_tracer_build_tlas: instances and materials in list order.  Instances refer to materials by the
@@ -155,6 +197,15 @@ rt_hook void rt_tracer_build_tlas(RT_Handle handle, RT_World* world) {
         }
         rt_hip_check(tracer, rthip_tlas_build(tracer->ctx, insts, inst_count, mats, mat_count), "rthip_tlas_build");
     }}
+
+    // The CPU backend writes the TLAS to "out.bvh" in every build flavour (its guard is `#ifdef BUILD_DEBUG`,
+    // and the macro is always defined, raytracer_cpu.c:171-173).  Same here; RT_HIP_NO_DUMP=1 turns it off.
+    #ifdef BUILD_DEBUG
+    {
+        const char* off = getenv("RT_HIP_NO_DUMP");
+        if (!(off && off[0] == '1')) rt_hip_dump_tree(tracer, -1, "out.bvh");
+    }
+    #endif
 }
 
 rt_hook void rt_tracer_cleanup(RT_Handle handle) {

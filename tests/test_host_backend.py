@@ -56,3 +56,8 @@ def test_reference_demo_binary_renders_through_the_backend(gpu_tracer, tmp_path,
     want = np.zeros((ht, wd, 3), dtype=np.float32)
     T.rt_tracer_cast(gpu_tracer, cam(wd, ht, samples), want, wd, ht, seed=first)
     assert (got.view(np.uint32) == want.view(np.uint32)).all()
+    # like the CPU backend, the hook leaves the TLAS in the reference's dump format in ./out.bvh
+    from conftest import golden
+
+    dump = (tmp_path / "out.bvh").read_bytes()
+    assert dump == golden("demo_" + demo)["ref_tlas_dump"].tobytes(), "out.bvh differs from the reference's"
