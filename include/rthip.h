@@ -250,9 +250,10 @@ int rthip_set_counting(rthip_ctx* ctx, int enabled);
 
 /* Which kernel rthip_cast / rthip_cast_device run.  All of them produce the same bits.  No
  * counterpart in the reference (its renderer is one loop, raytracer_cpu.c:179-242).
- *   RTHIP_KERNEL_AUTO        default.  Frames of 2^26 paths and more: the candidates (static, persistent with
- *                            three refill thresholds) first render a sparse sample of tiles and the fastest is
- *                            kept for this scene and frame geometry (the first such call waits on the stream;
+ *   RTHIP_KERNEL_AUTO        default.  Frames of 2^20 paths and more: a probe first renders a sparse sample of
+ *                            tiles with traversal counters on (into the same framebuffer) and the kernel
+ *                            follows from the measured lane utilisation and walk length; the choice is kept
+ *                            for this scene and frame geometry (the first such call waits on the stream;
  *                            skipped under stream capture).  Smaller frames: static for small scenes,
  *                            persistent for deep ones
  *   RTHIP_KERNEL_PERSISTENT  resident waves, lanes take a new path as soon as theirs ends

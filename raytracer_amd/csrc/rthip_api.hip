@@ -146,8 +146,7 @@ void rthip_destroy(rthip_ctx* ctx) {
     for (DevBuf& b : ctx->wf) rthip_release(b);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
-    if (ctx->tune_ev0) (void)hipEventDestroy(ctx->tune_ev0);
-    if (ctx->tune_ev1) (void)hipEventDestroy(ctx->tune_ev1);
+    rthip_release(ctx->tune_counters);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

@@ -143,7 +143,7 @@ struct rthip_ctx {
     // measured kernel choice of RTHIP_KERNEL_AUTO for big frames (see tune_cast); scene_generation changes with every
     // build and tracer setting
     uint64_t scene_generation = 0;
-    hipEvent_t tune_ev0 = nullptr, tune_ev1 = nullptr;
+    DevBuf tune_counters;
     bool tuned = false;
     uint64_t tuned_key[4] = {0, 0, 0, 0};
     int tuned_kernel = 1;

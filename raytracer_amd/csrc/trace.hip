@@ -2,6 +2,8 @@
 // per-lane refill, the fixed pixel-per-thread kernel, and the parity taps (primary hits, caller
 // supplied rays).  Device-side building blocks live in rt_device.h.
 
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "rt_device.h"
@@ -520,52 +522,53 @@ struct Candidate {
     uint32_t refill;  // persistent only
 };
 
-// Which renderer suits this scene and camera is a property of how long and how unequal the paths are,
-// which nothing but running them tells.  For a big frame the choice is therefore measured: every
-// candidate renders the same sparse sample of 64x64 tiles (1 tile in `stride`, about 2M paths) into the caller's
-// framebuffer, which the real render overwrites afterwards; the fastest one is kept until the scene,
-// the tracer settings or the frame geometry change.  The probe waits on the stream, so it is skipped
-// while the stream is being captured.
+// Which renderer suits a scene and camera depends on how long and how unequal the paths of one wave
+// are, which only running some of them tells.  So before the first frame of a scene (per frame
+// geometry) a probe renders a sparse sample of 64x64 tiles (1 in `stride`, one sample per pixel) with
+// the pixel-per-thread kernel and its traversal counters on, into the caller's framebuffer, which the
+// real render overwrites afterwards.  Two numbers decide:
+//   lane utilisation = box tests / (64 x wave steps): below 0.31 most lanes of a wave wait for its
+//     longest path, and the persistent kernel's refill pays for its bookkeeping;
+//   box tests per ray: short walks want more lanes gathered before shading (refill 32), long ones
+//     want idle lanes back in the walk quickly (refill 16).
+// The thresholds sit between the measured workloads (Cornell 0.33 / 18 keeps the static kernel; 10M-triangle
+// soup 0.30 / 145, 10k instances 0.24 / 146, Cornell + mesh at 4K 0.16 / 22 are 25-45 % faster on the
+// persistent one).  The counters are deterministic, so the choice is the same on every run.  The probe
+// waits on the stream, so it is skipped while the stream is being captured.
 int tune_cast(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_settings& cast, uint64_t seed, float* d_rgb, int width,
               int height, rthip_shard shard, hipStream_t stream, Candidate* best) {
-    static const Candidate candidates[] = {{1, 0}, {0, 16}, {0, 32}, {0, 48}};
-    // a probe run: about 2M paths (several per resident lane), at most 2x2 samples per pixel
     rthip_cast_settings pc = cast;
-    if (pc.samples > 2) pc.samples = 2;
-    const uint64_t probe_pixels = (2ull << 20) / ((uint64_t)pc.samples * pc.samples);
+    pc.samples = 1;
     const uint32_t tiles64 = div_up(width, 64) * div_up(height, 64);
-    uint32_t stride = (uint32_t)((uint64_t)tiles64 * 4096ull / probe_pixels);
+    uint32_t stride = tiles64 / 32u;  // about 32 tiles = 131k paths
     if (stride < 1) stride = 1;
     rthip_shard probe = {1u, 0u, stride};
     if (shard.mode == 1) {  // stay inside this rank's own tiles
         probe.world = shard.world * stride;
         probe.rank = shard.rank;
     }
-    if (!ctx->tune_ev0) {  // events of the tuner's own: the callers time their casts with the context's pair
-        RT_HIP(ctx, hipEventCreate(&ctx->tune_ev0));
-        RT_HIP(ctx, hipEventCreate(&ctx->tune_ev1));
+    RT_TRY(rthip_reserve(ctx, ctx->tune_counters, 64));
+    uint64_t* d_cnt = (uint64_t*)ctx->tune_counters.p;
+    uint64_t h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    RT_HIP(ctx, hipMemsetAsync(d_cnt, 0, 64, stream));
+    RT_TRY(launch_static(ctx, scene, pc, seed, d_rgb, width, height, probe, d_cnt, stream));
+    RT_HIP(ctx, hipMemcpyAsync(h, d_cnt, 64, hipMemcpyDeviceToHost, stream));
+    RT_HIP(ctx, hipStreamSynchronize(stream));
+    const double rays = (double)h[0], nodes = (double)h[1], steps = (double)h[4];
+    const double util = steps > 0 ? nodes / (64.0 * steps) : 1.0;
+    const double nodes_per_ray = rays > 0 ? nodes / rays : 0.0;
+    // deep scenes sit further from the border: their walks are long-tailed even where the sample looks even
+    const bool deep = ctx->n_inst >= 64u || ctx->total_tris >= (1ull << 20);
+    if (util < (deep ? 0.45 : 0.31)) {
+        best->kernel = 0;
+        best->refill = nodes_per_ray < 64.0 ? 32u : 16u;
+    } else {
+        best->kernel = 1;
+        best->refill = 0;
     }
-    float best_ms = 0.f;
-    bool warm[2] = {false, false};  // the first launch of a kernel also pays for loading its code
-    for (size_t k = 0; k < sizeof(candidates) / sizeof(candidates[0]); k++) {
-        float ms = 0.f;
-        for (int rep = warm[candidates[k].kernel] ? 1 : 0; rep < 2; rep++) {
-            RT_HIP(ctx, hipEventRecord(ctx->tune_ev0, stream));
-            if (candidates[k].kernel == 1)
-                RT_TRY(launch_static(ctx, scene, pc, seed, d_rgb, width, height, probe, nullptr, stream));
-            else
-                RT_TRY(launch_persistent(ctx, scene, pc, seed, d_rgb, width, height, probe, candidates[k].refill, nullptr,
-                                         stream));
-            RT_HIP(ctx, hipEventRecord(ctx->tune_ev1, stream));
-            RT_HIP(ctx, hipEventSynchronize(ctx->tune_ev1));
-            RT_HIP(ctx, hipEventElapsedTime(&ms, ctx->tune_ev0, ctx->tune_ev1));
-        }
-        warm[candidates[k].kernel] = true;
-        if (k == 0 || ms < best_ms) {
-            best_ms = ms;
-            *best = candidates[k];
-        }
-    }
+    if (getenv("RTHIP_TUNE_LOG"))
+        fprintf(stderr, "rthip tune: 1 tile in %u, %.0f rays, %.1f box tests per ray, lane utilisation %.3f -> kernel %d refill %u\n",
+                stride, rays, nodes_per_ray, util, best->kernel, best->refill);
     return RTHIP_OK;
 }
 
@@ -586,7 +589,7 @@ int cast_launch(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_settings
         if (stream) (void)hipStreamIsCapturing(stream, &capturing);
         if (ctx->tuned && memcmp(key, ctx->tuned_key, sizeof key) == 0) {
             choice = {ctx->tuned_kernel, ctx->tuned_refill};
-        } else if (paths >= (1ull << 26) && capturing == hipStreamCaptureStatusNone) {
+        } else if (paths >= (1ull << 20) && capturing == hipStreamCaptureStatusNone) {
             RT_TRY(tune_cast(ctx, scene, cast, seed, d_rgb, width, height, shard, stream, &choice));
             ctx->tuned = true;
             memcpy(ctx->tuned_key, key, sizeof key);

@@ -251,7 +251,7 @@ def test_cornell_with_mesh_scene(oracle, gpu_tracer):
 
 
 def test_auto_kernel_choice_changes_no_bit(gpu_tracer):
-    """A frame of 2^26 paths makes RTHIP_KERNEL_AUTO time its candidates on a sparse sample of tiles first
+    """A big frame makes RTHIP_KERNEL_AUTO render a counted probe on a sparse sample of tiles first
     (into the same framebuffer); the frame must come out exactly as from a fixed kernel, also from the
     cached choice, and also under a tile shard."""
     import torch
