@@ -5,7 +5,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/pmc_traffic
 mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
-for W in ${@:-bunny instanced soup cornell}; do
+for W in ${@:-bunny instanced soup cornell soup-rays}; do
   SIZES=""
   [ "$W" = "bunny" ] && SIZES="10000000"
   for C in FETCH_SIZE WRITE_SIZE; do
