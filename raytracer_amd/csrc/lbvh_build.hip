@@ -587,16 +587,19 @@ __global__ __launch_bounds__(kChunk) void hierarchy_local_kernel(uint32_t n, con
                                                                  uint32_t* __restrict__ cnt_l,
                                                                  NodeInfo* __restrict__ node_info,
                                                                  uint8_t* __restrict__ node_dl,
-                                                                 LeafRec* __restrict__ leaf_sorted) {
+                                                                 LeafRec* __restrict__ leaf_sorted,
+                                                                 uint32_t* __restrict__ starters, uint32_t* start_count) {
     // window of gap priorities: entry k is gap c0 - 1 + k, k = 0 .. kChunk; bit 7 marks a local gap.
     // Gaps that do not exist (-1, >= n-1) read as 0, below every real priority (>= 1).
     __shared__ uint8_t win[kChunk + 8];
     __shared__ uint32_t lflag[kChunk];
     __shared__ ChildRec lrec[2 * kChunk];
     __shared__ uint32_t wmin_l[kChunk / 64], wmin_r[kChunk / 64];
+    __shared__ uint32_t n_start, base_start;  // gaps that this workgroup found complete for the upper kernel
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const uint32_t c0 = blockIdx.x * (uint32_t)kChunk;
+    if (tid == 0) n_start = 0;
 
     {
         const int64_t g = (int64_t)c0 - 1 + tid;
@@ -636,7 +639,8 @@ __global__ __launch_bounds__(kChunk) void hierarchy_local_kernel(uint32_t n, con
     __syncthreads();
 
     const uint32_t i = c0 + (uint32_t)tid;
-    if (i >= n) return;
+    uint32_t my_start = 0xffffffffu, my_slot = 0;
+    if (i < n) {
     uint32_t l = i, r = i, dl = 0;
     float box[6];
     {
@@ -672,7 +676,8 @@ __global__ __launch_bounds__(kChunk) void hierarchy_local_kernel(uint32_t n, con
             mine.far_end = parent_right ? l : r;
             mine.dl = dl;
             child[2 * (uint64_t)parent + side] = mine;
-            atomicAdd(&flags[parent], 1u);
+            // the second child to be counted knows that the parent is complete: it goes on the upper kernel's list
+            if (atomicAdd(&flags[parent], 1u) == 1u) my_start = parent;
             break;
         }
         const uint32_t slot = parent - c0;
@@ -699,6 +704,13 @@ __global__ __launch_bounds__(kChunk) void hierarchy_local_kernel(uint32_t n, con
         }
         node_store(node_info, node_dl, parent, box, l, r, dl);
     }
+    }
+    // hand the complete gaps to the upper kernel: one device-wide atomic per workgroup
+    if (my_start != 0xffffffffu) my_slot = atomicAdd(&n_start, 1u);
+    __syncthreads();
+    if (tid == 0 && n_start != 0) base_start = atomicAdd(start_count, n_start);
+    __syncthreads();
+    if (my_start != 0xffffffffu) starters[base_start + my_slot] = my_start;
 }
 
 template <bool FENCE>
@@ -706,13 +718,14 @@ __global__ __launch_bounds__(kBlock) void hierarchy_upper_kernel(uint32_t n, con
                                                                  ChildRec* child, uint32_t* flags,
                                                                  uint32_t* __restrict__ cnt_l,
                                                                  NodeInfo* __restrict__ node_info,
-                                                                 uint8_t* __restrict__ node_dl) {
-    const uint64_t g0 = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (g0 + 1 >= n) return;
-    // start where both children were delivered by hierarchy_local_kernel (its arrivals count 1, the
-    // arrivals of this kernel 16, so the test reads the same whatever this kernel has done so far)
-    if ((__hip_atomic_load(&flags[g0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 15u) != 2u) return;
-    uint32_t parent = (uint32_t)g0;
+                                                                 uint8_t* __restrict__ node_dl,
+                                                                 const uint32_t* __restrict__ starters,
+                                                                 const uint32_t* __restrict__ start_count) {
+    // one thread per gap whose two children were both delivered by hierarchy_local_kernel (its arrivals
+    // count 1 in flags, the arrivals of this kernel 16)
+    const uint32_t count = *start_count;
+    for (uint32_t t = blockIdx.x * kBlock + threadIdx.x; t < count; t += gridDim.x * kBlock) {
+    uint32_t parent = starters[t];
     uint32_t l, r, dl;
     float box[6];
     {
@@ -754,6 +767,7 @@ __global__ __launch_bounds__(kBlock) void hierarchy_upper_kernel(uint32_t n, con
             dl = s_dl + 1;
         }
         node_store(node_info, node_dl, parent, box, l, r, dl);
+    }
     }
 }
 
@@ -923,6 +937,7 @@ int lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, float4* 
     RT_TRY(rthip_reserve(ctx, w.node_dl, n));
     RT_TRY(rthip_reserve(ctx, w.leaf_sorted, n * sizeof(LeafRec)));
     RT_TRY(rthip_reserve(ctx, w.flags, n * 4));
+    RT_TRY(rthip_reserve(ctx, w.starters, n * 4));
     RT_TRY(rthip_reserve(ctx, w.cnt_l, n * 4));
     RT_TRY(rthip_reserve(ctx, w.bounds, 64));
 
@@ -963,22 +978,27 @@ int lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, float4* 
     if (n > 1) {
         gap_priority_kernel<<<div_up(n - 1, kBlock), kBlock, 0, s>>>(keys[cur], n, (uint8_t*)w.prio.p);
         RT_HIP(ctx, hipGetLastError());
-        RT_HIP(ctx, hipMemsetAsync(w.flags.p, 0, (n - 1) * 4, s));
+        RT_HIP(ctx, hipMemsetAsync(w.flags.p, 0, n * 4, s));  // arrival counters of the n - 1 gaps + the starter count
     }
     const uint32_t chunks = div_up(n, kChunk);
     hierarchy_local_kernel<<<chunks, kChunk, 0, s>>>(n32, (const uint8_t*)w.prio.p, vals[cur], d_aabb6, (ChildRec*)w.child.p,
                                                      (uint32_t*)w.flags.p, (uint32_t*)w.cnt_l.p, (NodeInfo*)w.node_info.p,
-                                                     (uint8_t*)w.node_dl.p, (LeafRec*)w.leaf_sorted.p);
+                                                     (uint8_t*)w.node_dl.p, (LeafRec*)w.leaf_sorted.p, (uint32_t*)w.starters.p,
+                                                     (uint32_t*)w.flags.p + (n - 1));
     RT_HIP(ctx, hipGetLastError());
     if (n > 1) {
+        uint32_t ublocks = div_up(n - 1, kBlock);
+        if (ublocks > 2048) ublocks = 2048;
         if (ctx->refit_fence)
-            hierarchy_upper_kernel<true><<<div_up(n - 1, kBlock), kBlock, 0, s>>>(
+            hierarchy_upper_kernel<true><<<ublocks, kBlock, 0, s>>>(
                 n32, (const uint8_t*)w.prio.p, (ChildRec*)w.child.p, (uint32_t*)w.flags.p, (uint32_t*)w.cnt_l.p,
-                (NodeInfo*)w.node_info.p, (uint8_t*)w.node_dl.p);
+                (NodeInfo*)w.node_info.p, (uint8_t*)w.node_dl.p, (const uint32_t*)w.starters.p,
+                (const uint32_t*)w.flags.p + (n - 1));
         else
-            hierarchy_upper_kernel<false><<<div_up(n - 1, kBlock), kBlock, 0, s>>>(
+            hierarchy_upper_kernel<false><<<ublocks, kBlock, 0, s>>>(
                 n32, (const uint8_t*)w.prio.p, (ChildRec*)w.child.p, (uint32_t*)w.flags.p, (uint32_t*)w.cnt_l.p,
-                (NodeInfo*)w.node_info.p, (uint8_t*)w.node_dl.p);
+                (NodeInfo*)w.node_info.p, (uint8_t*)w.node_dl.p, (const uint32_t*)w.starters.p,
+                (const uint32_t*)w.flags.p + (n - 1));
         RT_HIP(ctx, hipGetLastError());
     }
     RT_TRY((scan_u32<true>(ctx, (uint32_t*)w.cnt_l.p, n, scan_tmp + scan_tmp_elems(hist_elems), s)));

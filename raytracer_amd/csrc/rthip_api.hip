@@ -139,7 +139,7 @@ void rthip_destroy(rthip_ctx* ctx) {
     for (auto& m : ctx->meshes) release_mesh(m);
     LbvhWorkspace& w = ctx->ws;
     DevBuf* all[] = {&w.aabb, &w.keys[0], &w.keys[1], &w.vals[0], &w.vals[1], &w.block_hist, &w.scan_tmp, &w.prio,
-                     &w.child, &w.flags, &w.node_info, &w.node_dl, &w.leaf_sorted, &w.cnt_l, &w.bounds, &ctx->blas_nodes, &ctx->tri_v, &ctx->tri_n,
+                     &w.child, &w.flags, &w.starters, &w.node_info, &w.node_dl, &w.leaf_sorted, &w.cnt_l, &w.bounds, &ctx->blas_nodes, &ctx->tri_v, &ctx->tri_n,
                      &ctx->tlas_nodes, &ctx->inst, &ctx->mats, &ctx->inst_aabb, &ctx->counters, &ctx->work_ring, &ctx->scratch_a,
                      &ctx->scratch_b, &ctx->scratch_c, &ctx->scratch_d, &ctx->scratch_e};
     for (DevBuf* b : all) rthip_release(*b);

@@ -32,6 +32,7 @@ struct LbvhWorkspace {
     DevBuf prio;        // uint8[n-1]  split priority of every gap
     DevBuf child;       // ChildInfo[2(n-1)]
     DevBuf flags;       // uint32[n-1] arrival counters
+    DevBuf starters;     // gaps whose two children both arrived in the chunk-local kernel (start list of the upper kernel)
     DevBuf node_info;   // NodeInfo[n-1] finished inner nodes by gap
     DevBuf node_dl;     // uint8[n-1]  left-spine length of every inner node
     DevBuf leaf_sorted; // LeafRec[n]  leaves in sorted order
