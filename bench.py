@@ -238,6 +238,9 @@ def main():
     ap.add_argument("--shard", default="frames", choices=["frames", "tiles", "samples"],
                     help="N > 1: every rank renders its own frame (weak scaling), or the ranks split one frame by "
                          "64x64 tiles or by sample index (strong scaling)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for N > 1: nccl = RCCL over xGMI (the product path); gloo = rehearsal "
+                         "of the N > 1 code on a box whose ranks share one GPU (framebuffers staged through the host)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--build-sizes", default="81920,1000000,10000000")
     args = ap.parse_args()
@@ -251,10 +254,14 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N")
-    torch.cuda.set_device(local_rank)
+    device_index = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(device_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend="gloo")
 
     from raytracer_amd import abi, dist as rdist, tracer as T, world as Wd
 
@@ -263,7 +270,7 @@ def main():
         wl["samples"] = args.samples
     wl["label"] += f", samples={wl['samples']}" if "samples=" not in wl["label"] else ""
     W, H = wl["width"], wl["height"]
-    tr = T.rt_make_tracer(T.RT_TracerSettings(max_bounces=wl["bounces"], sky=wl["sky"]), device_id=local_rank)
+    tr = T.rt_make_tracer(T.RT_TracerSettings(max_bounces=wl["bounces"], sky=wl["sky"]), device_id=device_index)
     T.rt_tracer_build_blas(tr, wl["world"])
     blas_ms = T.get_stats(tr)["last_build_ms"]
     T.rt_tracer_build_tlas(tr, wl["world"])

@@ -527,7 +527,7 @@ struct Candidate {
 // geometry) a probe renders a sparse sample of 64x64 tiles (1 in `stride`, one sample per pixel) with
 // the pixel-per-thread kernel and its traversal counters on, into the caller's framebuffer, which the
 // real render overwrites afterwards.  Two numbers decide:
-//   lane utilisation = box tests / (64 x wave steps): below 0.31 most lanes of a wave wait for its
+//   lane utilisation = box tests / (64 x wave steps): below 0.28 most lanes of a wave wait for its
 //     longest path, and the persistent kernel's refill pays for its bookkeeping;
 //   box tests per ray: short walks want more lanes gathered before shading (refill 32), long ones
 //     want idle lanes back in the walk quickly (refill 16).
@@ -559,7 +559,7 @@ int tune_cast(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_settings& 
     const double nodes_per_ray = rays > 0 ? nodes / rays : 0.0;
     // deep scenes sit further from the border: their walks are long-tailed even where the sample looks even
     const bool deep = ctx->n_inst >= 64u || ctx->total_tris >= (1ull << 20);
-    if (util < (deep ? 0.45 : 0.31)) {
+    if (util < (deep ? 0.45 : 0.28)) {
         best->kernel = 0;
         best->refill = nodes_per_ray < 64.0 ? 32u : 16u;
     } else {

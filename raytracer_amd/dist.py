@@ -40,6 +40,13 @@ def combine_framebuffer(fb, mode: str, samples: int, world: int, dst: int = 0):
     return fb
 
 
+class _Done:
+    """A finished collective (the synchronous rehearsal path)."""
+
+    def wait(self):
+        return True
+
+
 class FramePipeline:
     """Frames in flight: the collective of frame k runs while frame k + 1 is rendered.
 
@@ -87,7 +94,15 @@ class FramePipeline:
         if self.world > 1:
             import torch.distributed as dist
 
-            self.pending[k] = dist.reduce(fb, dst=self.dst, op=dist.ReduceOp.SUM, async_op=True)
+            if fb.is_cuda and dist.get_backend() == "gloo":
+                # rehearsal on a box without RCCL peers: gloo has no GPU reduce, so stage through the host
+                host = fb.cpu()
+                dist.reduce(host, dst=self.dst, op=dist.ReduceOp.SUM)
+                if dist.get_rank() == self.dst:
+                    fb.copy_(host)
+                self.pending[k] = _Done()
+            else:
+                self.pending[k] = dist.reduce(fb, dst=self.dst, op=dist.ReduceOp.SUM, async_op=True)
         self.last = k
         self.next = (k + 1) % len(self.buffers)
 
