@@ -187,13 +187,30 @@ def write_occlusion():
           out["bunny_o"].shape[0])
 
 
+def write_edges():
+    out = {}
+    o, d = scenes.edge_rays()
+    for name, w in (("edge", scenes.edge_scene()), ("cornell", scenes.cornell()[0])):
+        oo = o if name == "edge" else (o * np.float32(60.0)).astype(np.float32)
+        rs = O.RefScene(world.flatten_world(w), 4, True)
+        inst, tri, t, uv, nrm, _ = rs.trace(oo, d)
+        out.update({f"{name}_o": oo, f"{name}_d": d, f"{name}_ref_inst": inst, f"{name}_ref_tri": tri, f"{name}_ref_t": t,
+                    f"{name}_ref_uv": uv, f"{name}_ref_normal": nrm})
+        print("edges", name, int((inst > 0).sum()), "hits of", o.shape[0])
+    np.savez_compressed(os.path.join(OUT, "edge_rays.npz"), **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     assert O.have_ref("core"), "build oracle/_ref first: make -C oracle ref"
     if len(sys.argv) > 1 and sys.argv[1] == "occlusion":
         write_occlusion()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "edges":
+        write_edges()
+        sys.exit(0)
     write_lbvh()
     write_demos()
     write_bunny()
     write_occlusion()
+    write_edges()

@@ -563,6 +563,9 @@ static void tlas_query_interval(const ora_scene* s, const ray_t* r, float tmax, 
                                 it->sphere_radius, tmin, &tmax)) {
                     h->hit = 1;
                     h->inst = nd->id;
+                    h->tri_idx = 0; /* a sphere hit has no triangle or barycentrics */
+                    h->u = 0.f;
+                    h->v = 0.f;
                 }
             } else {
                 /* rt_cpu_inv_transform_ray, raytracer_cpu.c:572-580,607-612; the local

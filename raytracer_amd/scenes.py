@@ -472,3 +472,57 @@ def random_rays(n: int, seed: int, lo=(0.0, 0.0, 0.0), hi=(1.0, 1.0, 1.0)):
     d64 = d.astype(np.float64)
     d = (d64 / np.sqrt((d64 * d64).sum(axis=1))[:, None]).astype(np.float32)
     return o.astype(np.float32), d
+
+
+# ---- awkward inputs for the parity tests -----------------------------------------------------
+
+
+def edge_scene():
+    """A small world with awkward geometry: a degenerate (zero-area) triangle, two coincident triangles,
+    a sliver, a triangle in an axis plane, auto-indexed and indexed meshes, a scaled + rotated instance and
+    a sphere."""
+    w = rt_make_world()
+    v = np.array([[0, 0, 0, 0], [1, 0, 0, 0], [0, 1, 0, 0],      # plain triangle in the z = 0 plane
+                  [0, 0, 0, 0], [1, 0, 0, 0], [0, 1, 0, 0],      # the same triangle again (coincident)
+                  [2, 2, 2, 0], [2, 2, 2, 0], [2, 2, 2, 0],      # a point (zero area)
+                  [0, 0, 1, 0], [3, 0, 1, 0], [1.5, 1e-6, 1, 0],  # a sliver
+                  [0, 0, -1, 0], [0, 2, -1, 0], [0, 0, -3, 0]],   # in the x = 0 plane
+                 dtype=np.float32)
+    m0 = rt_world_add_mesh(w)
+    _set_mesh(m0, v, None, GEO_P)  # auto-indexed
+    quad_v = np.array([[-1, 0, -1, 0], [1, 0, -1, 0], [1, 0, 1, 0], [-1, 0, 1, 0]], dtype=np.float32)
+    m1 = rt_world_add_mesh(w)
+    _set_mesh(m1, quad_v, np.array([0, 1, 2, 0, 2, 3], dtype=np.uint32), GEO_P)
+    mat = rt_world_add_material(w)
+    mat.type, mat.albedo = abi.MAT_LAMBERTIAN, v3(0.5, 0.5, 0.5)
+    it = rt_world_add_instance(w)
+    it.type, it.material, it.mesh = abi.INST_MESH, mat, m0
+    it.translation, it.rotation, it.scale = v3(0, 0, 0), IDENTITY_QUAT, v3(1, 1, 1)
+    it = rt_world_add_instance(w)
+    it.type, it.material, it.mesh = abi.INST_MESH, mat, m1
+    it.translation = v3(0.5, -0.5, 0.25)
+    it.rotation = make_a_to_b_quat(v3(0, 1, 0), v3(1, 1, 0))
+    it.scale = v3(2, 1, 0.5)
+    it = rt_world_add_instance(w)
+    it.type, it.material = abi.INST_SPHERE, mat
+    it.sphere_center, it.sphere_radius = v3(-2, 0, 0), np.float32(0.75)
+    return w
+
+
+def edge_rays():
+    """Rays with exact zeros in their directions (1/0 = inf, 0 * inf = NaN in the slab test), origins exactly
+    on box planes and on triangle edges / vertices, and a few generic ones."""
+    o, d = [], []
+    axes = [(1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1), (1, 1, 0), (0, 1, 1), (1, 0, -1)]
+    pts = [(0, 0, 0), (0.25, 0.25, 5), (0.25, 0.25, -5), (1, 0, 5), (0, 1, 5), (0.5, 0.5, 5), (0.5, 0, 5), (5, 0.25, 0.25),
+           (-5, 0, 0), (-2, 5, 0), (-2, 0.75, 5), (0, 5, -2), (2, 2, 5), (1.5, 5e-7, 5), (0.5, -0.5, 5), (0.5, 5, 0.25),
+           (3, 0, 1), (-1.25, 0, 0), (0, 0, 1), (0.3, 0.3, 0.3)]
+    for p in pts:
+        for a in axes:
+            o.append(p)
+            d.append(a)
+    rng = np.random.default_rng(5)
+    o += list(rng.uniform(-4, 4, (400, 3)))
+    dd = rng.normal(size=(400, 3))
+    d += list(dd / np.linalg.norm(dd, axis=1, keepdims=True))
+    return np.asarray(o, dtype=np.float32), np.asarray(d, dtype=np.float32)

@@ -289,6 +289,31 @@ def test_auto_kernel_choice_changes_no_bit(gpu_tracer):
         T.set_cast_kernel(gpu_tracer, "auto")
 
 
+def test_edge_case_rays(oracle, gpu_tracer):
+    """Axis-parallel rays (1/0, 0 * inf), origins on box planes / edges / vertices, degenerate, coincident and
+    sliver triangles, an empty TLAS: the reference's answers, bit for bit."""
+    g = golden("edge_rays")
+    for name, w in (("edge", scenes.edge_scene()), ("cornell", scenes.cornell()[0])):
+        build(gpu_tracer, w, 4, True)
+        inst, tri, t, uv, nrm = T.trace_rays(gpu_tracer, g[f"{name}_o"], g[f"{name}_d"])
+        assert (inst == g[f"{name}_ref_inst"]).all() and (tri == g[f"{name}_ref_tri"]).all(), name
+        assert (bits(t) == bits(g[f"{name}_ref_t"])).all() and (bits(uv) == bits(g[f"{name}_ref_uv"])).all(), name
+        assert (bits(nrm) == bits(g[f"{name}_ref_normal"])).all(), name
+        occ = T.occluded(gpu_tracer, g[f"{name}_o"], g[f"{name}_d"])
+        assert (occ == (g[f"{name}_ref_inst"] > 0)).all(), name
+    # a world with meshes but no instance: everything misses, the frame is the sky
+    w = scenes.edge_scene()
+    w.instances.clear()
+    build(gpu_tracer, w, 4, True)
+    inst, tri, t, uv, nrm = T.trace_rays(gpu_tracer, g["edge_o"], g["edge_d"])
+    assert not inst.any() and (t == -1.0).all()
+    c = scenes.get_rt_cast_settings(32, 24, 2, (0, 0, 5), (0, 0, 0), vfov=scenes.degrees_to_rad(40))
+    img = np.zeros((24, 32, 3), dtype=np.float32)
+    T.rt_tracer_cast(gpu_tracer, c, img, 32, 24, seed=1)
+    want, _ = oracle.Scene(world.flatten_world(w), 4, True).cast(c, 1, 32, 24, rng_mode=oracle.RNG_COUNTER)
+    assert (bits(img) == bits(want)).all() and float(img.min()) > 0.3
+
+
 def test_long_ray_stream(oracle, gpu_tracer):
     """Ray streams of 2^18 rays and more go through the resident-wave kernel with lane refill: same
     answers and the same traversal counters as the oracle, with a ragged tail."""

@@ -145,3 +145,15 @@ def test_occlusion_matches_reference(oracle):
         # with the full interval, occlusion is "the closest-hit query found something"
         inst = sc.trace(o, d, want_normal=False)[0]
         assert ((inst > 0).astype(np.uint8) == g[f"{name}_ref_occluded2"]).all()
+
+
+def test_edge_case_rays_match_reference(oracle):
+    """Axis-parallel directions (1/0 and 0 * inf in the slab test), origins on box planes, edges and vertices,
+    degenerate / coincident / sliver triangles: the reference's own answers."""
+    g = golden("edge_rays")
+    for name, w in (("edge", scenes.edge_scene()), ("cornell", scenes.cornell()[0])):
+        sc = oracle.Scene(world.flatten_world(w), 4, True)
+        inst, tri, t, uv, nrm, _ = sc.trace(g[f"{name}_o"], g[f"{name}_d"])
+        assert (inst == g[f"{name}_ref_inst"]).all() and (tri == g[f"{name}_ref_tri"]).all(), name
+        assert (bits(t) == bits(g[f"{name}_ref_t"])).all() and (bits(uv) == bits(g[f"{name}_ref_uv"])).all(), name
+        assert (bits(nrm) == bits(g[f"{name}_ref_normal"])).all(), name
