@@ -86,8 +86,9 @@ __device__ __forceinline__ void slab_axis(float lo, float hi, float o, float inv
     const float t0 = (lo - o) * inv, t1 = (hi - o) * inv;
     const bool ordered = t0 < t1;
     const float near = ordered ? t0 : t1, far = ordered ? t1 : t0;
-    tmin = (near > tmin) ? near : tmin;
-    tmax = (far < tmax) ? far : tmax;
+    // the interval ends are never NaN, so maxNum / minNum (a NaN candidate is ignored) are the strict comparisons
+    tmin = fmaxf(tmin, near);
+    tmax = fminf(tmax, far);
 }
 __device__ __forceinline__ bool slab(float4 lo, float4 hi, V3 o, V3 inv, float tmin, float tmax) {
     slab_axis(lo.x, hi.x, o.x, inv.x, tmin, tmax);
