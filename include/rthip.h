@@ -20,6 +20,13 @@
  *     exactly like `id = idx + 1` in src/lbvh/lbvh.c:116.
  *   - one context drives one GPU.  Multi-GPU jobs run one process (one context)
  *     per GPU and shard with rthip_shard.
+ *   - a context is not thread-safe: its calls must come from one thread at a time
+ *     (the reference's callers are single-threaded, demos_inc.c:9-10).  Different
+ *     contexts are independent.  The *_device entry points only enqueue work on
+ *     the given stream; builds (rthip_blas_commit, rthip_tlas_build) wait for the
+ *     GPU, so a cast enqueued after them on any stream sees the finished trees.
+ *     The builder's workspace belongs to the context: two builds on different
+ *     streams of one context must not overlap.
  */
 #ifndef RTHIP_H
 #define RTHIP_H
