@@ -7,7 +7,10 @@
 One step = one frame of the workload rendered through rthip_cast_device with everything
 (BVHs, triangles, framebuffer) resident in HBM.  With N > 1 every rank renders the same frame
 with its own sample set (seed + rank) and the framebuffers are summed onto rank 0 with RCCL
-(`torch.distributed.reduce`), i.e. N times the samples in the same wall time: weak scaling.
+(`torch.distributed.reduce`), i.e. N times the samples in the same wall time: weak scaling.  By
+default the image is accumulated progressively: every step of every rank renders its own sample set
+into the rank's accumulator and the ranks exchange ONE framebuffer sum per image, at the end of the
+timed steps and inside the timed region (`--combine every` delivers a combined frame per step).
 A ray is one TLAS closest-hit query (primary and bounce rays alike).
 
 Rank 0 prints ONE JSON line.  `roofline` prices the cast kernel against HBM bandwidth using
@@ -238,6 +241,11 @@ def main():
     ap.add_argument("--shard", default="frames", choices=["frames", "tiles", "samples"],
                     help="N > 1: every rank renders its own frame (weak scaling), or the ranks split one frame by "
                          "64x64 tiles or by sample index (strong scaling)")
+    ap.add_argument("--combine", default="auto", choices=["auto", "end", "every"],
+                    help="when the ranks' framebuffers are combined: 'every' step (a frame is delivered per step; the reduce "
+                         "of frame k overlaps the render of frame k + 1) or once at the 'end' of the timed steps (progressive "
+                         "accumulation: every step adds its own sample set, one exchange per image).  auto: end for "
+                         "--shard frames, every for tiles / samples")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1: nccl = RCCL over xGMI (the product path); gloo = rehearsal "
                          "of the N > 1 code on a box whose ranks share one GPU (framebuffers staged through the host)")
@@ -277,6 +285,11 @@ def main():
     cast = wl["cam"](W, H, wl["samples"])
     flat = Wd.flatten_world(wl["world"])
 
+    combine = args.combine if args.combine != "auto" else ("end" if args.shard == "frames" else "every")
+    if combine == "end" and args.shard != "frames":
+        raise SystemExit("--combine end accumulates independent sample sets: it needs --shard frames")
+    accum = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda") if combine == "end" else None
+    step_no = [0]
     # two framebuffers: the RCCL reduce of frame k overlaps the render of frame k + 1
     pipe = rdist.FramePipeline([torch.zeros((H, W, 3), dtype=torch.float32, device="cuda") for _ in range(2)],
                                args.shard, wl["samples"], world, dst=0)
@@ -306,13 +319,33 @@ def main():
             tr.check(rc, "rthip_trace_rays_device")
             return
         fb = pipe.acquire()
+        # progressive accumulation: every step of every rank renders its own sample set
+        step_seed = seed if combine == "every" else 1 + step_no[0] * world + rank
+        step_no[0] += 1
         if events:
             events[0].record(stream)
-        rc = tr.lib.rthip_cast_device(tr.h, abi.ptr(cast), seed, fb.data_ptr(), W, H, abi.ptr(shard), stream.cuda_stream)
+        rc = tr.lib.rthip_cast_device(tr.h, abi.ptr(cast), step_seed, fb.data_ptr(), W, H, abi.ptr(shard), stream.cuda_stream)
         if events:
             events[1].record(stream)
         tr.check(rc, "rthip_cast_device")
-        pipe.submit(fb)
+        if combine == "end":
+            accum.add_(fb)
+        else:
+            pipe.submit(fb)
+
+    def finish_image(n_steps):
+        """--combine end: the one exchange of the image, inside the timed region."""
+        if combine != "end" or ray_o is not None:
+            return
+        if world > 1:
+            if dist.get_backend() == "gloo":  # rehearsal: gloo has no GPU reduce
+                host = accum.cpu()
+                dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
+                accum.copy_(host)
+            else:
+                dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+        if rank == 0:
+            accum.mul_(1.0 / float(n_steps * world))
 
     # traversal counters of this rank's frame (untimed launch with counting on)
     T.set_counting(tr, True)
@@ -328,6 +361,9 @@ def main():
     for _ in range(args.warmup):
         step()
     pipe.drain()
+    finish_image(args.warmup + 1)
+    if accum is not None:
+        accum.zero_()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -336,6 +372,7 @@ def main():
     for k in range(args.steps):
         step(ev[k])
     pipe.drain()
+    finish_image(args.steps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -374,7 +411,10 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": wl["label"], "rays_per_frame_per_gpu": int(rays), "sharding": "none" if world == 1 else {
-                           "frames": "every rank renders the frame with its own sample set; framebuffers summed onto rank 0 with RCCL",
+                           "frames": "every rank renders the frame with its own sample set; " + (
+                               "framebuffers summed onto rank 0 with RCCL every step" if combine == "every" else
+                               "every step adds its sample set to the rank's accumulator, ONE RCCL sum onto rank 0 at the end "
+                               "of the timed steps (inside the timed region)"),
                            "tiles": "ranks render interleaved 64x64 tiles of one frame; shares summed onto rank 0 with RCCL",
                            "samples": "ranks render sample indices s % N == rank of one frame; sums added onto rank 0 with RCCL"}[args.shard]},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
