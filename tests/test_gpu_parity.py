@@ -360,6 +360,45 @@ def test_edge_case_rays(oracle, gpu_tracer):
     assert (bits(img) == bits(want)).all() and float(img.min()) > 0.3
 
 
+def test_full_size_frame_agrees_across_kernels_and_shards(gpu_tracer):
+    """Benchmark configuration 3 at full size (10 000 instances, 1920x1080, 4 spp, 8 bounces): too big for the
+    CPU oracle, so the three renderer kernels (each bit-exact against the oracle at small sizes) must agree with
+    each other bit for bit, and three tile shards must add up to the frame."""
+    import torch
+
+    verts, indices = scenes.bunny_class_mesh()
+    w, cam, sky = scenes.instanced_grid(100, seed=1, verts=verts, indices=indices)
+    build(gpu_tracer, w, 8, sky)
+    wd, ht = 1920, 1080
+    c = cam(wd, ht, 2)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def render(shard=None):
+        buf = torch.full((ht, wd, 3), -1.0, dtype=torch.float32, device="cuda:0")
+        sh = None
+        if shard:
+            sh = np.zeros(1, dtype=abi.SHARD)
+            sh[0] = shard
+        gpu_tracer.check(gpu_tracer.lib.rthip_cast_device(gpu_tracer.h, abi.ptr(c), 7, buf.data_ptr(), wd, ht,
+                                                          abi.ptr(sh) if shard else None, stream), "rthip_cast_device")
+        torch.cuda.synchronize()
+        return buf
+
+    try:
+        frames = {}
+        for kernel in ("static", "persistent", "wavefront"):
+            T.set_cast_kernel(gpu_tracer, kernel)
+            frames[kernel] = render()
+        assert float(frames["static"].min()) >= 0.0 and float(frames["static"].mean()) > 0.05
+        for kernel in ("persistent", "wavefront"):
+            assert torch.equal(frames[kernel].view(torch.int32), frames["static"].view(torch.int32)), kernel
+        T.set_cast_kernel(gpu_tracer, "auto")
+        total = sum(render((1, r, 3)) for r in range(3))
+        assert torch.equal((total + 0.0).view(torch.int32), (frames["static"] + 0.0).view(torch.int32)), "tile shards"
+    finally:
+        T.set_cast_kernel(gpu_tracer, "auto")
+
+
 def test_long_ray_stream(oracle, gpu_tracer):
     """Ray streams of 2^18 rays and more go through the resident-wave kernel with lane refill: same
     answers and the same traversal counters as the oracle, with a ragged tail."""
