@@ -451,15 +451,9 @@ __global__ __launch_bounds__(kBlock) void scan_add_kernel(uint32_t* __restrict__
 // ---- K4: priority of every gap -----------------------------------------------------------
 // lbvh_get_split_idx, lbvh.c:15-42, seen from the gap: differing codes -> shared leading
 // bits; equal codes -> 64 + depth of the gap in the count/2 tree of its run.
-__global__ __launch_bounds__(kBlock) void gap_priority_kernel(const uint64_t* __restrict__ keys, uint64_t n,
-                                                              uint8_t* __restrict__ prio) {
-    uint64_t g = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (g + 1 >= n) return;
+__device__ __forceinline__ uint8_t gap_priority_of(const uint64_t* keys, uint64_t n, uint64_t g) {
     uint64_t k0 = keys[g], k1 = keys[g + 1];
-    if (k0 != k1) {
-        prio[g] = (uint8_t)__clzll((long long)(k0 ^ k1));
-        return;
-    }
+    if (k0 != k1) return (uint8_t)__clzll((long long)(k0 ^ k1));
     // run of equal codes [a, b): a = first index with key == k0, b = first index with key > k0
     uint64_t lo = 0, hi = g;
     while (lo < hi) {
@@ -489,7 +483,14 @@ __global__ __launch_bounds__(kBlock) void gap_priority_kernel(const uint64_t* __
         }
         depth++;
     }
-    prio[g] = (uint8_t)(64u + depth);
+    return (uint8_t)(64u + depth);
+}
+
+__global__ __launch_bounds__(kBlock) void gap_priority_kernel(const uint64_t* __restrict__ keys, uint64_t n,
+                                                              uint8_t* __restrict__ prio) {
+    uint64_t g = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (g + 1 >= n) return;
+    prio[g] = gap_priority_of(keys, n, g);
 }
 
 // ---- K5 + K6: hierarchy emission with box refit ------------------------------------------
@@ -580,7 +581,7 @@ __device__ __forceinline__ void node_store(NodeInfo* node_info, uint8_t* node_dl
     node_dl[gap] = (uint8_t)dl;
 }
 
-__global__ __launch_bounds__(kChunk) void hierarchy_local_kernel(uint32_t n, const uint8_t* __restrict__ prio,
+__device__ __forceinline__ void hierarchy_local_body(uint32_t c0, uint32_t n, const uint8_t* __restrict__ prio,
                                                                  const uint32_t* __restrict__ sorted_idx,
                                                                  const float* __restrict__ aabb6,
                                                                  ChildRec* __restrict__ child, uint32_t* flags,
@@ -598,7 +599,6 @@ __global__ __launch_bounds__(kChunk) void hierarchy_local_kernel(uint32_t n, con
     __shared__ uint32_t n_start, base_start;  // gaps that this workgroup found complete for the upper kernel
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const uint32_t c0 = blockIdx.x * (uint32_t)kChunk;
     if (tid == 0) n_start = 0;
 
     {
@@ -713,6 +713,19 @@ __global__ __launch_bounds__(kChunk) void hierarchy_local_kernel(uint32_t n, con
     if (my_start != 0xffffffffu) starters[base_start + my_slot] = my_start;
 }
 
+__global__ __launch_bounds__(kChunk) void hierarchy_local_kernel(uint32_t n, const uint8_t* __restrict__ prio,
+                                                                 const uint32_t* __restrict__ sorted_idx,
+                                                                 const float* __restrict__ aabb6,
+                                                                 ChildRec* __restrict__ child, uint32_t* flags,
+                                                                 uint32_t* __restrict__ cnt_l,
+                                                                 NodeInfo* __restrict__ node_info,
+                                                                 uint8_t* __restrict__ node_dl,
+                                                                 LeafRec* __restrict__ leaf_sorted,
+                                                                 uint32_t* __restrict__ starters, uint32_t* start_count) {
+    hierarchy_local_body(blockIdx.x * (uint32_t)kChunk, n, prio, sorted_idx, aabb6, child, flags, cnt_l, node_info, node_dl,
+                         leaf_sorted, starters, start_count);
+}
+
 template <bool FENCE>
 __global__ __launch_bounds__(kBlock) void hierarchy_upper_kernel(uint32_t n, const uint8_t* __restrict__ prio,
                                                                  ChildRec* child, uint32_t* flags,
@@ -774,12 +787,9 @@ __global__ __launch_bounds__(kBlock) void hierarchy_upper_kernel(uint32_t n, con
 // ---- K7: pre-order records ------------------------------------------------------------------
 // Thread t writes leaf t and inner node (gap) t: neighbours in pre-order are written by
 // neighbouring threads, so the 32-byte records combine into full lines on their way to HBM.
-__global__ __launch_bounds__(kBlock) void emit_kernel(uint32_t n, const LeafRec* __restrict__ leaf_sorted,
-                                                      const NodeInfo* __restrict__ node_info,
-                                                      const uint8_t* __restrict__ node_dl,
-                                                      const uint32_t* __restrict__ spine_scan,
-                                                      float4* __restrict__ nodes) {
-    const uint64_t t = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+__device__ __forceinline__ void emit_body(uint64_t t, uint32_t n, const LeafRec* __restrict__ leaf_sorted,
+                                          const NodeInfo* __restrict__ node_info, const uint8_t* __restrict__ node_dl,
+                                          const uint32_t* __restrict__ spine_scan, float4* __restrict__ nodes) {
     if (t >= n) return;
     {
         const uint32_t i = (uint32_t)t;
@@ -796,6 +806,109 @@ __global__ __launch_bounds__(kBlock) void emit_kernel(uint32_t n, const LeafRec*
         nodes[2 * (uint64_t)pre] = make_float4(ni.box[0], ni.box[1], ni.box[2], __uint_as_float(pre + size));
         nodes[2 * (uint64_t)pre + 1] = make_float4(ni.box[3], ni.box[4], ni.box[5], __uint_as_float(0u));
     }
+}
+
+__global__ __launch_bounds__(kBlock) void emit_kernel(uint32_t n, const LeafRec* __restrict__ leaf_sorted,
+                                                      const NodeInfo* __restrict__ node_info,
+                                                      const uint8_t* __restrict__ node_dl,
+                                                      const uint32_t* __restrict__ spine_scan,
+                                                      float4* __restrict__ nodes) {
+    emit_body((uint64_t)blockIdx.x * kBlock + threadIdx.x, n, leaf_sorted, node_info, node_dl, spine_scan, nodes);
+}
+
+// ---- the whole build in one workgroup, for n <= kChunk ---------------------------------------
+// Small trees (the demos' meshes and TLASes have 1 .. 12 primitives) are all launch overhead in the
+// pipeline above.  Here one 512-thread workgroup, one primitive per thread, runs the same steps with
+// the same device functions: centroid bounds, Morton codes, a stable sort in LDS (bitonic network on
+// (code, index) pairs), gap priorities, the chunk-local hierarchy climb (every gap is local), the
+// prefix sum of the left-spine lengths and the pre-order records.
+__global__ __launch_bounds__(kChunk) void lbvh_small_kernel(uint32_t n, const float* __restrict__ aabb6,
+                                                            uint64_t* __restrict__ codes_unsorted,
+                                                            uint64_t* __restrict__ keys_sorted,
+                                                            uint32_t* __restrict__ vals_sorted, uint8_t* __restrict__ prio,
+                                                            ChildRec* __restrict__ child, uint32_t* flags,
+                                                            uint32_t* __restrict__ cnt_l, NodeInfo* __restrict__ node_info,
+                                                            uint8_t* __restrict__ node_dl, LeafRec* __restrict__ leaf_sorted,
+                                                            uint32_t* __restrict__ starters, float4* __restrict__ nodes) {
+    __shared__ uint64_t skey[kChunk];
+    __shared__ uint32_t sidx[kChunk];
+    __shared__ uint32_t sbounds[6];
+    __shared__ uint32_t wave_tot[kChunk / 64];
+    const uint32_t t = threadIdx.x;
+    const int wave = t >> 6, lane = t & 63;
+
+    if (t < 3) sbounds[t] = f2ord(3.402823466e+38f);
+    else if (t < 6) sbounds[t] = f2ord(-3.402823466e+38f);
+    __syncthreads();
+    float c[3] = {0.f, 0.f, 0.f};
+    if (t < n) {
+        const float* b = aabb6 + 6 * (uint64_t)t;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            c[k] = (b[k] + b[k + 3]) * 0.5f;  // lbvh.c:98
+            atomicMin(&sbounds[k], f2ord(c[k]));
+            atomicMax(&sbounds[k + 3], f2ord(c[k]));
+        }
+    }
+    __syncthreads();
+    uint64_t code = ~0ull;
+    if (t < n) {
+        code = 0;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const float mn = ord2f(sbounds[k]);
+            const float ext = ord2f(sbounds[k + 3]) - mn;  // extents = max - min, lbvh.c:106
+            code |= spread21(morton_axis(c[k], mn, ext)) << k;
+        }
+        codes_unsorted[t] = code;
+    }
+    skey[t] = code;
+    sidx[t] = (t < n) ? t : 0xffffffffu;
+    __syncthreads();
+    // ascending by (code, index): equal codes keep ascending primitive index, like the stable radix passes
+    for (uint32_t k = 2; k <= (uint32_t)kChunk; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            const uint32_t other = t ^ j;
+            if (other > t) {
+                const uint64_t ka = skey[t], kb = skey[other];
+                const uint32_t ia = sidx[t], ib = sidx[other];
+                const bool a_after_b = ka > kb || (ka == kb && ia > ib);
+                const bool ascending = (t & k) == 0;
+                if (a_after_b == ascending) {
+                    skey[t] = kb;
+                    skey[other] = ka;
+                    sidx[t] = ib;
+                    sidx[other] = ia;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (t < n) {
+        keys_sorted[t] = skey[t];
+        vals_sorted[t] = sidx[t];
+    }
+    if (t + 1 < n) prio[t] = gap_priority_of(skey, n, t);
+    __syncthreads();  // the climb reads prio and vals_sorted back from memory
+    hierarchy_local_body(0u, n, prio, vals_sorted, aabb6, child, flags, cnt_l, node_info, node_dl, leaf_sorted, starters,
+                         flags /* never counted: no gap spans chunks */);
+    __syncthreads();
+    {   // inclusive prefix sum of the left-spine lengths
+        const uint32_t v = (t < n) ? cnt_l[t] : 0u;
+        uint32_t incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            uint32_t up = __shfl_up(incl, o);
+            if (lane >= o) incl += up;
+        }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        uint32_t before = 0;
+        for (int w = 0; w < wave; w++) before += wave_tot[w];
+        if (t < n) cnt_l[t] = before + incl;
+    }
+    __syncthreads();
+    emit_body(t, n, leaf_sorted, node_info, node_dl, cnt_l, nodes);
 }
 
 // ---- K8: world box of every instance, rt_cpu_tlas_node_to_aabb, raytracer_cpu.c:131-147 ------
@@ -946,6 +1059,18 @@ int lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, float4* 
     uint32_t* vals[2] = {(uint32_t*)w.vals[0].p, (uint32_t*)w.vals[1].p};
     uint32_t* scan_tmp = (uint32_t*)w.scan_tmp.p;
 
+    if (n <= (uint64_t)kChunk) {  // one workgroup does everything
+        ctx->bounds_of = nullptr;
+        lbvh_small_kernel<<<1, kChunk, 0, s>>>((uint32_t)n, d_aabb6, keys[0], keys[1], vals[1], (uint8_t*)w.prio.p,
+                                               (ChildRec*)w.child.p, (uint32_t*)w.flags.p, (uint32_t*)w.cnt_l.p,
+                                               (NodeInfo*)w.node_info.p, (uint8_t*)w.node_dl.p, (LeafRec*)w.leaf_sorted.p,
+                                               (uint32_t*)w.starters.p, d_nodes);
+        RT_HIP(ctx, hipGetLastError());
+        if (d_codes_unsorted) RT_HIP(ctx, hipMemcpyAsync(d_codes_unsorted, keys[0], n * 8, hipMemcpyDeviceToDevice, s));
+        if (d_keys_sorted) RT_HIP(ctx, hipMemcpyAsync(d_keys_sorted, keys[1], n * 8, hipMemcpyDeviceToDevice, s));
+        if (d_ids_sorted) RT_HIP(ctx, hipMemcpyAsync(d_ids_sorted, vals[1], n * 4, hipMemcpyDeviceToDevice, s));
+        return RTHIP_OK;
+    }
     if (!(ctx->bounds_of == d_aabb6 && ctx->bounds_n == n && ctx->bounds_stream == s)) {
         bounds_init_kernel<<<1, 64, 0, s>>>(bounds);
         uint32_t bblocks = div_up(n, kBlock);

@@ -35,7 +35,7 @@ def test_lbvh_golden_sets(oracle, gpu_tracer, name):
         assert oracle.dump_bytes(nodes) == g["ref_dump"].tobytes(), "tree dump differs from the reference's"
 
 
-@pytest.mark.parametrize("n", [1, 2, 3, 5, 63, 64, 65, 255, 256, 257, 4095, 4096, 4097, 8193, 50_000])
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 63, 64, 65, 255, 256, 257, 511, 512, 513, 1024, 4095, 4096, 4097, 8193, 50_000])
 def test_lbvh_sizes(oracle, gpu_tracer, n):
     rng = np.random.default_rng(n)
     cen = rng.random((n, 3)).astype(np.float32)
