@@ -117,8 +117,6 @@ int rthip_create(rthip_ctx** out_ctx, int device_id) {
     if (mode && strcmp(mode, "persistent") == 0) ctx->cast_mode = 0;
     if (mode && strcmp(mode, "auto") == 0) ctx->cast_mode = 3;
     ctx->persistent_blocks = (uint32_t)prop.multiProcessorCount * 5u;
-    const char* stat = getenv("RTHIP_STATIC");
-    if (stat && atoi(stat) >= 0 && atoi(stat) <= 100) ctx->static_percent = (uint32_t)atoi(stat);
     const char* refill = getenv("RTHIP_REFILL");
     if (refill && atoi(refill) >= 1 && atoi(refill) <= 64) ctx->refill_lanes = (uint32_t)atoi(refill);
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||

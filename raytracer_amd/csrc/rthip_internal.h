@@ -132,7 +132,6 @@ struct rthip_ctx {
     uint32_t persistent_blocks = 256u * 5u;  // resident workgroups of the persistent kernel (CUs x 5)
     DevBuf wf[11];               // path-state arrays of the wavefront renderer
     uint64_t wf_capacity = 1ull << 23;  // paths per wavefront batch
-    uint32_t static_percent = 0;   // share of the tiles dealt round-robin up front (RTHIP_STATIC overrides)
     uint32_t refill_lanes = 16;  // lanes with other work that end a traversal phase (RTHIP_REFILL overrides)
     DevBuf scratch_a, scratch_b, scratch_c, scratch_d, scratch_e;  // staging for host <-> device taps
     // set by mesh_prepare_device: the workspace holds the centroid bounds of this box array (consumed by the next build)

@@ -31,8 +31,7 @@ enum : uint32_t { ST_NEED_PIXEL = 0, ST_NEED_SAMPLE = 1, ST_TRAVERSE = 2, ST_SHA
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock, 5) void cast_kernel(DevScene S, rthip_cast_settings c, uint64_t seed,
                                                       float* __restrict__ out, int width, int height,
-                                                      rthip_shard shard, uint32_t* work_counters,
-                                                      uint32_t static_rounds, uint32_t refill,
+                                                      rthip_shard shard, uint32_t* work_counters, uint32_t refill,
                                                       uint64_t* counters) {
     extern __shared__ uint32_t bounce_stack[];
     uint32_t* stack = bounce_stack + threadIdx.x;
@@ -42,13 +41,10 @@ __global__ __launch_bounds__(kBlock, 5) void cast_kernel(DevScene S, rthip_cast_
     const uint32_t spp = (uint32_t)(samples * samples);
     const uint32_t tiles_x = (uint32_t)(width + 7) / 8, tiles_y = (uint32_t)(height + 7) / 8;
     const uint64_t n_tiles = (uint64_t)tiles_x * tiles_y;
-    const uint32_t n_waves = gridDim.x * (kBlock / 64);
     const uint32_t wave_id = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     // wave-uniform bookkeeping of the tile the wave is handing out
     uint64_t tile_id = 0;
     uint32_t tile_pos = 64;  // positions of tile_id already handed out (64: none left)
-    uint32_t static_left = static_rounds;
-    const uint64_t dyn_first = (uint64_t)static_rounds * n_waves;  // first tile of the dynamically shared part
     uint32_t qslot = wave_id & 7u, qtried = 0;  // which of the 8 dynamic counters, and how many ran dry
     const uint32_t shard_tiles_x = (uint32_t)(width + 63) / 64;
 
@@ -84,38 +80,30 @@ __global__ __launch_bounds__(kBlock, 5) void cast_kernel(DevScene S, rthip_cast_
 
         // ---- phase 2: pixels for the lanes that have none ---------------------------------------------
         // A wave owns one 8x8 tile at a time and hands its 64 positions to idle lanes with a ballot and
-        // an mbcnt-style prefix.  A new tile costs ONE atomic per wave.  The first `static_rounds` tiles
-        // of a wave are dealt round-robin without any atomic (wave w gets tiles w, w + W, ...); the rest
-        // of the image is shared out dynamically from 8 interleaved counters (counter s serves tiles
-        // dyn_first + 8k + s), so that waves with cheap tiles take over work from waves with expensive
-        // ones and no single word has to serve every wave.
+        // an mbcnt-style prefix.  A new tile costs ONE atomic per wave.  Tiles come from 8 interleaved
+        // counters (counter s serves tiles 8k + s), so that waves with cheap tiles take over work from
+        // waves with expensive ones and no single word has to serve every wave.
         uint64_t need = __ballot(state == ST_NEED_PIXEL);
         while (need != 0 && !exhausted) {
             if (tile_pos >= 64u) {  // the wave's tile is used up: next tile (wave-uniform)
-                if (static_left != 0) {
-                    tile_id = (uint64_t)wave_id + (uint64_t)(static_rounds - static_left) * n_waves;
-                    static_left--;
-                    tile_pos = 0;
-                } else {
-                    bool got = false;
-                    while (qtried < 8u) {
-                        uint32_t k = 0;
-                        if (lane == 0) k = atomicAdd(&work_counters[qslot * 32u], 1u);
-                        k = __shfl(k, 0);
-                        const uint64_t t = dyn_first + (uint64_t)k * 8u + qslot;
-                        if (t < n_tiles) {
-                            tile_id = t;
-                            tile_pos = 0;
-                            got = true;
-                            break;
-                        }
-                        qslot = (qslot + 1u) & 7u;
-                        qtried++;
-                    }
-                    if (!got) {
-                        exhausted = true;
+                bool got = false;
+                while (qtried < 8u) {
+                    uint32_t k = 0;
+                    if (lane == 0) k = atomicAdd(&work_counters[qslot * 32u], 1u);
+                    k = __shfl(k, 0);
+                    const uint64_t t = (uint64_t)k * 8u + qslot;
+                    if (t < n_tiles) {
+                        tile_id = t;
+                        tile_pos = 0;
+                        got = true;
                         break;
                     }
+                    qslot = (qslot + 1u) & 7u;
+                    qtried++;
+                }
+                if (!got) {
+                    exhausted = true;
+                    break;
                 }
             }
             const uint32_t room = 64u - tile_pos;
@@ -503,16 +491,12 @@ int launch_persistent(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_se
     // ring, so that casts enqueued back to back (or on two streams) do not share them
     uint32_t* work = (uint32_t*)ctx->work_ring.p + (size_t)(ctx->work_next++ % 16u) * 256u;
     RT_HIP(ctx, hipMemsetAsync(work, 0, 1024, stream));
-    const uint64_t n_tiles = total / 64ull;
-    const uint64_t n_waves = (uint64_t)blocks * (kBlock / 64);
-    // share of the tiles that is dealt round-robin up front (the rest is pulled dynamically)
-    const uint32_t static_rounds = (uint32_t)((n_tiles * ctx->static_percent / 100ull) / n_waves);
     if (d_counters)
         cast_kernel<true><<<blocks, kBlock, lds, stream>>>(scene, cast, seed, d_rgb, width, height, shard, work,
-                                                           static_rounds, refill, d_counters);
+                                                           refill, d_counters);
     else
         cast_kernel<false><<<blocks, kBlock, lds, stream>>>(scene, cast, seed, d_rgb, width, height, shard, work,
-                                                            static_rounds, refill, nullptr);
+                                                            refill, nullptr);
     RT_HIP(ctx, hipGetLastError());
     return RTHIP_OK;
 }
