@@ -269,6 +269,11 @@ int rthip_set_counting(rthip_ctx* ctx, int enabled);
  * The environment variable RTHIP_CAST=auto|persistent|static|wavefront sets the initial value. */
 enum { RTHIP_KERNEL_PERSISTENT = 0, RTHIP_KERNEL_STATIC = 1, RTHIP_KERNEL_WAVEFRONT = 2, RTHIP_KERNEL_AUTO = 3 };
 int rthip_set_cast_kernel(rthip_ctx* ctx, int kernel);
+/* Scheduling parameters of RTHIP_KERNEL_PERSISTENT when it is selected by name (AUTO picks its own): `refill`
+ * in 1..64 = lanes with no ray to walk that make a wave stop walking and shade / fetch new paths (default 16);
+ * `inst_batch` in 0..64 = lanes parked at an instance that make the wave enter the instances, 0 = a lane enters
+ * at once (default 0).  They change the schedule only, never a bit of the result.  No counterpart in the reference. */
+int rthip_set_persistent_params(rthip_ctx* ctx, uint32_t refill, uint32_t inst_batch);
 
 /* TLAS / BLAS tree read-back for dumps in the reference's format
  * (src/lbvh/extra/dump.c): which = -1 for the TLAS, otherwise a blas_id.

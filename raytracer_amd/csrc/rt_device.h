@@ -151,6 +151,8 @@ struct Trav {
     uint32_t resume;    // TLAS index to continue from when the current BLAS walk ends
     uint32_t cur_inst;  // TLAS id of the instance being walked (0: in the TLAS)
     uint32_t tri_base;
+    uint32_t pend_id;   // TLAS leaf whose instance is still to be entered (0: none); see trav_enter
+    uint32_t pend_skip; // where the TLAS walk continues after that instance
     Hit h;
 };
 
@@ -168,6 +170,8 @@ __device__ __forceinline__ void trav_begin(Trav& T, const DevScene& S, V3 o, V3 
     T.resume = 0;
     T.cur_inst = 0;
     T.tri_base = 0;
+    T.pend_id = 0;
+    T.pend_skip = 0;
     T.h.inst = 0;
     T.h.tri = 0;
     T.h.u = 0.f;
@@ -175,8 +179,51 @@ __device__ __forceinline__ void trav_begin(Trav& T, const DevScene& S, V3 o, V3 
     T.h.t = kMaxF;
 }
 
-// One step of the walk.  Returns true when the query has ended (T.h is final).
+// A TLAS leaf whose box the ray hits (rt_cpu_intersect_tlas_node, raytracer_cpu.c:494-531): a sphere is tested,
+// a mesh instance is entered (the ray goes to model space and the BLAS walk starts).
 template <bool COUNT>
+__device__ __forceinline__ void trav_enter_leaf(Trav& T, const DevScene& S, Counters& cnt, uint32_t id, uint32_t skip) {
+    const DevInstance* it = &S.inst[id - 1];
+    if (COUNT) cnt.insts++;
+    if (it->type == RTHIP_INST_SPHERE) {
+        const float4 cr = *(const float4*)it->sphere_center;
+        if (sphere_test(T.o, T.d, mk(cr.x, cr.y, cr.z), it->sphere_radius, kEps, T.tmax)) {
+            T.h.inst = id;
+            T.h.tri = 0;
+            T.h.u = 0.f;
+            T.h.v = 0.f;
+        }
+        T.idx = skip;
+        return;
+    }
+    // rt_cpu_inv_transform_ray, raytracer_cpu.c:572-580,607-612; the model-space direction is
+    // not renormalised, so t is shared between the two spaces
+    const float4 tr = *(const float4*)it->translation;
+    const float4 q = *(const float4*)it->rotation;
+    const float4 sc = *(const float4*)it->scale;
+    const V3 qv = mk(-q.x, -q.y, -q.z);  // inv_quat, common_math.c:90
+    const V3 s3 = mk(sc.x, sc.y, sc.z);
+    T.o = divv(rot_quat(sub(T.wo, mk(tr.x, tr.y, tr.z)), qv, q.w), s3);
+    T.d = divv(rot_quat(T.wd, qv, q.w), s3);
+    T.inv = mk(1.f / T.d.x, 1.f / T.d.y, 1.f / T.d.z);
+    T.resume = skip;
+    T.cur_inst = id;
+    T.tri_base = it->tri_base;
+    T.nodes = S.blas + 2 * (size_t)it->node_base;
+    T.idx = 0;
+    T.end = it->n_nodes;
+}
+
+// Enters the instance a lane was parked at by trav_step<COUNT, true>.
+template <bool COUNT>
+__device__ __forceinline__ void trav_enter(Trav& T, const DevScene& S, Counters& cnt) {
+    const uint32_t id = T.pend_id, skip = T.pend_skip;
+    T.pend_id = 0;
+    trav_enter_leaf<COUNT>(T, S, cnt, id, skip);
+}
+
+// One step of the walk.  Returns true when the query has ended (T.h is final).
+template <bool COUNT, bool DEFER = false>
 __device__ __forceinline__ bool trav_step(Trav& T, const DevScene& S, Counters& cnt) {
     if (T.idx >= T.end) {
         if (T.cur_inst == 0) {
@@ -221,36 +268,13 @@ __device__ __forceinline__ bool trav_step(Trav& T, const DevScene& S, Counters& 
         T.idx = skip;
         return false;
     }
-    // TLAS leaf: enter the instance
-    const DevInstance* it = &S.inst[id - 1];
-    if (COUNT) cnt.insts++;
-    if (it->type == RTHIP_INST_SPHERE) {
-        const float4 cr = *(const float4*)it->sphere_center;
-        if (sphere_test(T.o, T.d, mk(cr.x, cr.y, cr.z), it->sphere_radius, kEps, T.tmax)) {
-            T.h.inst = id;
-            T.h.tri = 0;
-            T.h.u = 0.f;
-            T.h.v = 0.f;
-        }
-        T.idx = skip;
+    // TLAS leaf
+    if (DEFER) {  // the caller enters the instance later, for several lanes at once (trav_enter)
+        T.pend_id = id;
+        T.pend_skip = skip;
         return false;
     }
-    // rt_cpu_inv_transform_ray, raytracer_cpu.c:572-580,607-612; the model-space direction is
-    // not renormalised, so t is shared between the two spaces
-    const float4 tr = *(const float4*)it->translation;
-    const float4 q = *(const float4*)it->rotation;
-    const float4 sc = *(const float4*)it->scale;
-    const V3 qv = mk(-q.x, -q.y, -q.z);  // inv_quat, common_math.c:90
-    const V3 s3 = mk(sc.x, sc.y, sc.z);
-    T.o = divv(rot_quat(sub(T.wo, mk(tr.x, tr.y, tr.z)), qv, q.w), s3);
-    T.d = divv(rot_quat(T.wd, qv, q.w), s3);
-    T.inv = mk(1.f / T.d.x, 1.f / T.d.y, 1.f / T.d.z);
-    T.resume = skip;
-    T.cur_inst = id;
-    T.tri_base = it->tri_base;
-    T.nodes = S.blas + 2 * (size_t)it->node_base;
-    T.idx = 0;
-    T.end = it->n_nodes;
+    trav_enter_leaf<COUNT>(T, S, cnt, id, skip);
     return false;
 }
 

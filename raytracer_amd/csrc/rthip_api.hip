@@ -117,6 +117,8 @@ int rthip_create(rthip_ctx** out_ctx, int device_id) {
     if (mode && strcmp(mode, "persistent") == 0) ctx->cast_mode = 0;
     if (mode && strcmp(mode, "auto") == 0) ctx->cast_mode = 3;
     ctx->persistent_blocks = (uint32_t)prop.multiProcessorCount * 5u;
+    const char* ib = getenv("RTHIP_INST_BATCH");
+    if (ib && atoi(ib) >= 0 && atoi(ib) <= 64) ctx->inst_batch = (uint32_t)atoi(ib);
     const char* refill = getenv("RTHIP_REFILL");
     if (refill && atoi(refill) >= 1 && atoi(refill) <= 64) ctx->refill_lanes = (uint32_t)atoi(refill);
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
@@ -169,6 +171,15 @@ int rthip_set_cast_kernel(rthip_ctx* ctx, int kernel) {
     if (!ctx) return RTHIP_E_INVALID;
     if (kernel < 0 || kernel > 3) return rthip_fail(ctx, RTHIP_E_INVALID, "unknown cast kernel %d", kernel);
     ctx->cast_mode = kernel;
+    return RTHIP_OK;
+}
+
+int rthip_set_persistent_params(rthip_ctx* ctx, uint32_t refill, uint32_t inst_batch) {
+    if (!ctx) return RTHIP_E_INVALID;
+    if (refill < 1 || refill > 64 || inst_batch > 64)
+        return rthip_fail(ctx, RTHIP_E_INVALID, "refill must be in 1..64 and inst_batch in 0..64, got %u and %u", refill, inst_batch);
+    ctx->refill_lanes = refill;
+    ctx->inst_batch = inst_batch;
     return RTHIP_OK;
 }
 

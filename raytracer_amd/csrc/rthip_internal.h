@@ -132,6 +132,7 @@ struct rthip_ctx {
     uint32_t persistent_blocks = 256u * 5u;  // resident workgroups of the persistent kernel (CUs x 5)
     DevBuf wf[11];               // path-state arrays of the wavefront renderer
     uint64_t wf_capacity = 1ull << 23;  // paths per wavefront batch
+    uint32_t inst_batch = 0;     // persistent kernel chosen by name: 0 = enter instances at once, k = park and enter k lanes at a time (RTHIP_INST_BATCH)
     uint32_t refill_lanes = 16;  // lanes with other work that end a traversal phase (RTHIP_REFILL overrides)
     DevBuf scratch_a, scratch_b, scratch_c, scratch_d, scratch_e;  // staging for host <-> device taps
     // set by mesh_prepare_device: the workspace holds the centroid bounds of this box array (consumed by the next build)
@@ -147,7 +148,7 @@ struct rthip_ctx {
     bool tuned = false;
     uint64_t tuned_key[4] = {0, 0, 0, 0};
     int tuned_kernel = 1;
-    uint32_t tuned_refill = 16;
+    uint32_t tuned_refill = 16, tuned_inst_batch = 0;
 };
 
 // ---- helpers (rthip_api.hip) -------------------------------------------------

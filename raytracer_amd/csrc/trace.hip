@@ -28,10 +28,10 @@ namespace {
 // prefix; there is no global queue and no lane ever waits for another wave.
 enum : uint32_t { ST_NEED_PIXEL = 0, ST_NEED_SAMPLE = 1, ST_TRAVERSE = 2, ST_SHADE = 3, ST_DONE = 4 };
 
-template <bool COUNT>
+template <bool COUNT, bool DEFER>
 __global__ __launch_bounds__(kBlock, 5) void cast_kernel(DevScene S, rthip_cast_settings c, uint64_t seed,
                                                       float* __restrict__ out, int width, int height,
-                                                      rthip_shard shard, uint32_t* work_counters, uint32_t refill,
+                                                      rthip_shard shard, uint32_t* work_counters, uint32_t refill, uint32_t inst_batch,
                                                       uint64_t* counters) {
     extern __shared__ uint32_t bounce_stack[];
     uint32_t* stack = bounce_stack + threadIdx.x;
@@ -165,9 +165,25 @@ __global__ __launch_bounds__(kBlock, 5) void cast_kernel(DevScene S, rthip_cast_
             if (walking == 0) break;
             const uint64_t waiting = __ballot(state != ST_TRAVERSE && state != ST_DONE);
             if ((uint32_t)__popcll(waiting) >= refill) break;
+            // Entering an instance (two quaternion rotations, nine divisions) is by far the longest branch of
+            // a step and only a few lanes need it in any one iteration.  With DEFER a lane that reaches an
+            // instance parks there, and the wave runs the entry once `inst_batch` lanes are parked (or nobody
+            // else can step): the same work per lane, in fewer executions of the long branch.  It pays where
+            // rays enter instances often (many small instances); elsewhere the plain step is faster.
             if (COUNT && (int)lane == __ffsll((long long)walking) - 1) cnt.wave_steps++;
-            if (state == ST_TRAVERSE) {
-                if (trav_step<COUNT>(T, S, cnt)) state = ST_SHADE;
+            if (DEFER) {
+                const uint64_t parked = __ballot(state == ST_TRAVERSE && T.pend_id != 0);
+                const bool enter_now =
+                    parked != 0 && ((uint32_t)__popcll(parked) >= inst_batch || (walking & ~parked) == 0);
+                if (state == ST_TRAVERSE) {
+                    if (T.pend_id != 0) {
+                        if (enter_now) trav_enter<COUNT>(T, S, cnt);
+                    } else if (trav_step<COUNT, true>(T, S, cnt)) {
+                        state = ST_SHADE;
+                    }
+                }
+            } else if (state == ST_TRAVERSE) {
+                if (trav_step<COUNT, false>(T, S, cnt)) state = ST_SHADE;
             }
         }
 
@@ -481,7 +497,8 @@ int launch_static(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_settin
 }
 
 int launch_persistent(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_settings& cast, uint64_t seed, float* d_rgb,
-                      int width, int height, rthip_shard shard, uint32_t refill, uint64_t* d_counters, hipStream_t stream) {
+                      int width, int height, rthip_shard shard, uint32_t refill, uint32_t inst_batch, uint64_t* d_counters,
+                      hipStream_t stream) {
     // persistent grid: as many workgroups as are resident at once (CUs x 5 at 96 VGPRs), never more than the work
     const uint64_t total = (uint64_t)div_up(width, 8) * div_up(height, 8) * 64ull;
     uint32_t blocks = div_up(total, kBlock);
@@ -491,19 +508,26 @@ int launch_persistent(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_se
     // ring, so that casts enqueued back to back (or on two streams) do not share them
     uint32_t* work = (uint32_t*)ctx->work_ring.p + (size_t)(ctx->work_next++ % 16u) * 256u;
     RT_HIP(ctx, hipMemsetAsync(work, 0, 1024, stream));
-    if (d_counters)
-        cast_kernel<true><<<blocks, kBlock, lds, stream>>>(scene, cast, seed, d_rgb, width, height, shard, work,
-                                                           refill, d_counters);
-    else
-        cast_kernel<false><<<blocks, kBlock, lds, stream>>>(scene, cast, seed, d_rgb, width, height, shard, work,
-                                                            refill, nullptr);
+    const bool defer = inst_batch != 0;
+#define RT_LAUNCH_CAST(COUNT, DEFER, CNT)                                                                              \
+    cast_kernel<COUNT, DEFER><<<blocks, kBlock, lds, stream>>>(scene, cast, seed, d_rgb, width, height, shard, work, \
+                                                               refill, inst_batch, CNT)
+    if (d_counters) {
+        if (defer) RT_LAUNCH_CAST(true, true, d_counters);
+        else RT_LAUNCH_CAST(true, false, d_counters);
+    } else {
+        if (defer) RT_LAUNCH_CAST(false, true, nullptr);
+        else RT_LAUNCH_CAST(false, false, nullptr);
+    }
+#undef RT_LAUNCH_CAST
     RT_HIP(ctx, hipGetLastError());
     return RTHIP_OK;
 }
 
 struct Candidate {
-    int kernel;       // RTHIP_KERNEL_STATIC or RTHIP_KERNEL_PERSISTENT
-    uint32_t refill;  // persistent only
+    int kernel;           // RTHIP_KERNEL_STATIC or RTHIP_KERNEL_PERSISTENT
+    uint32_t refill;      // persistent only
+    uint32_t inst_batch;  // persistent only: 0 = enter instances at once, else park and enter in batches
 };
 
 // Which renderer suits a scene and camera depends on how long and how unequal the paths of one wave
@@ -514,7 +538,10 @@ struct Candidate {
 //   lane utilisation = box tests / (64 x wave steps): below 0.28 most lanes of a wave wait for its
 //     longest path, and the persistent kernel's refill pays for its bookkeeping;
 //   box tests per ray: short walks want more lanes gathered before shading (refill 32), long ones
-//     want idle lanes back in the walk quickly (refill 16).
+//     want idle lanes back in the walk quickly (refill 16);
+//   instance entries per box test: above 2 % the long entry branch runs in most iterations for two or
+//     three lanes, and parking lanes to enter in batches of 8 pays (+10 % on Cornell + mesh; -5 % where
+//     entries are rare).
 // The thresholds sit between the measured workloads (Cornell 0.33 / 18 keeps the static kernel; 10M-triangle
 // soup 0.30 / 145, 10k instances 0.24 / 146, Cornell + mesh at 4K 0.16 / 22 are 25-45 % faster on the
 // persistent one).  The counters are deterministic, so the choice is the same on every run.  The probe
@@ -538,7 +565,7 @@ int tune_cast(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_settings& 
     RT_TRY(launch_static(ctx, scene, pc, seed, d_rgb, width, height, probe, d_cnt, stream));
     RT_HIP(ctx, hipMemcpyAsync(h, d_cnt, 64, hipMemcpyDeviceToHost, stream));
     RT_HIP(ctx, hipStreamSynchronize(stream));
-    const double rays = (double)h[0], nodes = (double)h[1], steps = (double)h[4];
+    const double rays = (double)h[0], nodes = (double)h[1], entries = (double)h[3], steps = (double)h[4];
     const double util = steps > 0 ? nodes / (64.0 * steps) : 1.0;
     const double nodes_per_ray = rays > 0 ? nodes / rays : 0.0;
     // deep scenes sit further from the border: their walks are long-tailed even where the sample looks even
@@ -546,13 +573,15 @@ int tune_cast(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_settings& 
     if (util < (deep ? 0.45 : 0.28)) {
         best->kernel = 0;
         best->refill = nodes_per_ray < 64.0 ? 32u : 16u;
+        best->inst_batch = (nodes > 0 && entries / nodes > 0.02) ? 8u : 0u;
     } else {
         best->kernel = 1;
         best->refill = 0;
+        best->inst_batch = 0;
     }
     if (getenv("RTHIP_TUNE_LOG"))
-        fprintf(stderr, "rthip tune: 1 tile in %u, %.0f rays, %.1f box tests per ray, lane utilisation %.3f -> kernel %d refill %u\n",
-                stride, rays, nodes_per_ray, util, best->kernel, best->refill);
+        fprintf(stderr, "rthip tune: 1 tile in %u, %.0f rays, %.1f box tests per ray, lane utilisation %.3f -> kernel %d refill %u instance batch %u\n",
+                stride, rays, nodes_per_ray, util, best->kernel, best->refill, best->inst_batch);
     return RTHIP_OK;
 }
 
@@ -563,7 +592,7 @@ int cast_launch(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_settings
     ctx->last_cast_kernel = 2;
     if (ctx->cast_mode == 2)
         return cast_wavefront_launch(ctx, scene, cast, seed, d_rgb, width, height, shard, d_counters, stream);
-    Candidate choice = {ctx->cast_mode, ctx->refill_lanes};
+    Candidate choice = {ctx->cast_mode, ctx->refill_lanes, ctx->inst_batch};
     if (ctx->cast_mode == 3) {
         const uint64_t spp = (uint64_t)cast.samples * cast.samples;
         const uint64_t paths = (uint64_t)width * (uint64_t)height * spp;
@@ -572,23 +601,26 @@ int cast_launch(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_settings
         hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
         if (stream) (void)hipStreamIsCapturing(stream, &capturing);
         if (ctx->tuned && memcmp(key, ctx->tuned_key, sizeof key) == 0) {
-            choice = {ctx->tuned_kernel, ctx->tuned_refill};
+            choice = {ctx->tuned_kernel, ctx->tuned_refill, ctx->tuned_inst_batch};
         } else if (paths >= (1ull << 20) && capturing == hipStreamCaptureStatusNone) {
             RT_TRY(tune_cast(ctx, scene, cast, seed, d_rgb, width, height, shard, stream, &choice));
             ctx->tuned = true;
             memcpy(ctx->tuned_key, key, sizeof key);
             ctx->tuned_kernel = choice.kernel;
             ctx->tuned_refill = choice.refill;
+            ctx->tuned_inst_batch = choice.inst_batch;
         } else {
             // Small frames are not worth a probe.  Paths through a small scene are short and alike, and the
             // pixel-per-thread kernel has the least bookkeeping per ray; deep scenes (many instances, large
             // meshes) have long-tailed walks that pay for the persistent kernel's lane refill.
             choice.kernel = (ctx->n_inst >= 64u || ctx->total_tris >= (1ull << 20)) ? 0 : 1;
             choice.refill = ctx->refill_lanes;
+            choice.inst_batch = 0;
         }
     }
     ctx->last_cast_kernel = (uint32_t)choice.kernel;
     ctx->last_cast_refill = choice.kernel == 0 ? choice.refill : 0u;
     if (choice.kernel == 1) return launch_static(ctx, scene, cast, seed, d_rgb, width, height, shard, d_counters, stream);
-    return launch_persistent(ctx, scene, cast, seed, d_rgb, width, height, shard, choice.refill, d_counters, stream);
+    return launch_persistent(ctx, scene, cast, seed, d_rgb, width, height, shard, choice.refill, choice.inst_batch, d_counters,
+                             stream);
 }

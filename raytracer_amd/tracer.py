@@ -194,5 +194,10 @@ def set_cast_kernel(tracer: RT_Tracer, kernel: str) -> None:
     tracer.check(tracer.lib.rthip_set_cast_kernel(tracer.h, CAST_KERNELS[kernel]), "rthip_set_cast_kernel")
 
 
+def set_persistent_params(tracer: RT_Tracer, refill: int = 16, inst_batch: int = 0) -> None:
+    """Scheduling of the persistent kernel when it is selected by name; see include/rthip.h."""
+    tracer.check(tracer.lib.rthip_set_persistent_params(tracer.h, refill, inst_batch), "rthip_set_persistent_params")
+
+
 def set_counting(tracer: RT_Tracer, enabled: bool) -> None:
     tracer.check(tracer.lib.rthip_set_counting(tracer.h, 1 if enabled else 0), "rthip_set_counting")

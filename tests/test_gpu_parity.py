@@ -238,13 +238,15 @@ def test_instanced_scene_and_counters(oracle, gpu_tracer):
     assert (bits(img) == bits(want)).all()
 
 
-@pytest.mark.parametrize("kernel", ["persistent", "static", "wavefront"])
+@pytest.mark.parametrize("kernel", ["persistent", "persistent-batched", "static", "wavefront"])
 def test_every_cast_kernel_gives_the_same_bits(oracle, gpu_tracer, kernel):
     """The three renderer implementations against the oracle: full frames, partial tiles, both shard
     modes, a scene with refraction/metal (spheres) and one with instances."""
     import torch
 
-    T.set_cast_kernel(gpu_tracer, kernel)
+    T.set_cast_kernel(gpu_tracer, kernel.split("-")[0])
+    if kernel == "persistent-batched":
+        T.set_persistent_params(gpu_tracer, refill=24, inst_batch=6)
     try:
         verts, indices = scenes.bunny_class_mesh(3)
         cases = [(scenes.cornell(), 8, (70, 50, 2, 6)), (scenes.spheres(), 8, (64, 40, 2, 3)),
@@ -275,6 +277,7 @@ def test_every_cast_kernel_gives_the_same_bits(oracle, gpu_tracer, kernel):
         assert not img.any()
     finally:
         T.set_cast_kernel(gpu_tracer, "auto")
+        T.set_persistent_params(gpu_tracer)
 
 
 def test_cornell_with_mesh_scene(oracle, gpu_tracer):
