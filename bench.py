@@ -432,9 +432,10 @@ def main():
             line["lbvh_build_ms_per_1M_triangles"] = line["lbvh_build"][big]["ms_per_1M"]
         if args.workload == "bunny":
             line["shadow_rays"] = shadow_ray_rate(tr, torch, cast, W, H, args.steps)
-        if not args.no_cpu_baseline and ray_o is not None:
+        want_cpu = not args.no_cpu_baseline and world == 1  # the CPU baseline is reported at N = 1 only
+        if want_cpu and ray_o is not None:
             line["cpu_baseline"] = cpu_baseline_rays(wl, flat, ray_o[: 1 << 16].cpu().numpy(), ray_d[: 1 << 16].cpu().numpy())
-        if not args.no_cpu_baseline and ray_o is None:
+        if want_cpu and ray_o is None:
             line["cpu_baseline"] = cpu_baseline(wl, cast, flat)
             threads = min(16, os.cpu_count() or 1)  # the box's CPU share for one GPU
             line["cpu_port_all_cores"] = cpu_port_parallel(wl, cast, flat, threads)
