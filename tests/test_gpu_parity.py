@@ -364,7 +364,7 @@ def test_edge_case_rays(oracle, gpu_tracer):
 
 
 def test_full_size_frame_agrees_across_kernels_and_shards(gpu_tracer):
-    """Benchmark configuration 3 at full size (10 000 instances, 1920x1080, 4 spp, 8 bounces): too big for the
+    """The instanced benchmark workload at full size (10 000 instances, 1920x1080, 4 spp, 8 bounces): too big for the
     CPU oracle, so the three renderer kernels (each bit-exact against the oracle at small sizes) must agree with
     each other bit for bit, and three tile shards must add up to the frame."""
     import torch

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Everything the numbers in DESIGN.md come from, in one GPU call (run from the repository root on the GPU box).
+# Every measurement and profile of a round, in one GPU call (run from the repository root on the GPU box).
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/round
 mkdir -p $OUT
