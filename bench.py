@@ -130,7 +130,7 @@ def camera_rays_torch(torch, cast, W, H):
 
 
 def shadow_ray_rate(tr, torch, cast, W, H, steps):
-    """Config 2's shadow rays: from every primary hit point towards a directional light, answered by the
+    """Shadow rays of the bunny workload: from every primary hit point towards a directional light, answered by the
     any-hit kernel (rthip_occluded_device).  Reported beside the headline, never mixed into it."""
     stream = torch.cuda.current_stream()
     o, d = camera_rays_torch(torch, cast, W, H)
