@@ -187,6 +187,17 @@ def write_occlusion():
           out["bunny_o"].shape[0])
 
 
+def write_converged():
+    """High-sample images of the Cornell box from the reference itself: 4096 spp (the yardstick) and 1024 spp
+    (the reference's own distance from it), 32x32 pixels."""
+    out = {}
+    out["ref_rgb_32_s64_seed1"] = O.ref_demo("cornell", 32, 32, 64, 8, 1)["rgb"]
+    out["ref_rgb_32_s32_seed2"] = O.ref_demo("cornell", 32, 32, 32, 8, 2)["rgb"]
+    np.savez_compressed(os.path.join(OUT, "cornell_converged.npz"), **out)
+    a, b = out["ref_rgb_32_s64_seed1"].astype(np.float64), out["ref_rgb_32_s32_seed2"].astype(np.float64)
+    print("converged: relMSE(ref 1024 spp, ref 4096 spp) =", float(np.mean((b - a) ** 2 / (a ** 2 + 1e-3))))
+
+
 def write_edges():
     out = {}
     o, d = scenes.edge_rays()
@@ -206,6 +217,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "occlusion":
         write_occlusion()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "converged":
+        write_converged()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "edges":
         write_edges()
         sys.exit(0)
@@ -214,3 +228,4 @@ if __name__ == "__main__":
     write_bunny()
     write_occlusion()
     write_edges()
+    write_converged()

@@ -188,6 +188,20 @@ def test_cornell_radiance_within_reference_noise(gpu_tracer):
     assert abs(lum(img) - lum(a)) <= 0.01 * lum(a) + 2.0 * abs(lum(a) - lum(b))
 
 
+def test_cornell_converges_to_the_reference(gpu_tracer):
+    """1024 spp on the GPU against the reference's 4096-spp image: the relative MSE may be at most twice the
+    reference's own 1024-spp image's (a different noise realisation of the same estimator), and the means agree."""
+    g = golden("cornell_converged")
+    w, cam, sky = scenes.cornell()
+    build(gpu_tracer, w, 8, sky)
+    img = np.zeros((32, 32, 3), dtype=np.float32)
+    T.rt_tracer_cast(gpu_tracer, cam(32, 32, 32), img, 32, 32, seed=5)
+    truth, ref1024 = g["ref_rgb_32_s64_seed1"].astype(np.float64), g["ref_rgb_32_s32_seed2"].astype(np.float64)
+    rel = lambda x: float(np.mean((x.astype(np.float64) - truth) ** 2 / (truth ** 2 + 1e-3)))
+    assert rel(img) <= 2.0 * rel(ref1024), f"relMSE {rel(img):.4f} vs the reference's own {rel(ref1024):.4f}"
+    assert abs(float(img.mean()) - float(truth.mean())) <= 0.01 * float(truth.mean())
+
+
 def test_bunny_class_scene(oracle, gpu_tracer):
     g = golden("demo_bunny_class")
     verts, indices = scenes.bunny_class_mesh()
