@@ -171,12 +171,25 @@ def recorded_traffic(workload: str, kernel_name: str):
     return None if rec is None else rec["hbm_bytes_per_launch"]
 
 
+def cpu_sample_frame(wl, max_paths=1 << 21):
+    """The frame the CPU renders: the workload's own when it has at most ~2M paths, otherwise the same scene,
+    camera and samples per pixel at a resolution reduced to that many paths (a bounded sample, tens of seconds)."""
+    W, H, smp = wl["width"], wl["height"], wl["samples"]
+    scale = 1
+    while (W // scale) * (H // scale) * smp * smp > max_paths:
+        scale += 1
+    Ws, Hs = max(W // scale, 16), max(H // scale, 16)
+    what = f"the full {W}x{H} frame of the same workload" if scale == 1 else \
+        f"the same workload at {Ws}x{Hs} (1/{scale} of the resolution, same camera and samples per pixel)"
+    return Ws, Hs, wl["cam"](Ws, Hs, smp), what
+
+
 def cpu_baseline(wl, cast, flat, budget_s=20.0):
     """The CPU path on this box's host cores: the unmodified reference when oracle/_ref travelled
     with the tree (kind 'reference'), otherwise the repo's CPU restatement (kind 'port')."""
     from oracle import oracle as O
 
-    W, H = wl["width"], wl["height"]
+    W, H, cast, what = cpu_sample_frame(wl)
     ora = O.Scene(flat, wl["bounces"], wl["sky"])
     # the oracle in glibc-rand mode reproduces the reference's paths exactly, so its ray count is the reference's
     t0 = time.time()
@@ -194,10 +207,10 @@ def cpu_baseline(wl, cast, flat, budget_s=20.0):
             if spent > budget_s:
                 break
         return dict(value=round(rays / best / 1e6, 3), unit="Mrays/s", cores=1, kind="reference",
-                    sample=f"the full {W}x{H} frame of the same workload, {reps} repeats, best of them; rays counted by the "
-                           "oracle run with the same glibc rand() stream")
+                    sample=f"{what}, {reps} repeats, best of them; rays counted by the oracle run with the same glibc "
+                           "rand() stream")
     return dict(value=round(rays / port_s / 1e6, 3), unit="Mrays/s", cores=1, kind="port",
-                sample=f"the full {W}x{H} frame of the same workload, one pass of the CPU restatement")
+                sample=f"{what}, one pass of the CPU restatement")
 
 
 def cpu_baseline_rays(wl, flat, o, d, sample=1 << 16):
@@ -222,13 +235,13 @@ def cpu_port_parallel(wl, cast, flat, threads):
     """The CPU restatement row-parallel over the host cores (the reference itself is single-threaded)."""
     from oracle import oracle as O
 
-    W, H = wl["width"], wl["height"]
+    W, H, cast, what = cpu_sample_frame(wl)
     ora = O.Scene(flat, wl["bounces"], wl["sky"])
     t0 = time.time()
     _, cnt = ora.cast(cast, 1, W, H, rng_mode=O.RNG_COUNTER, threads=threads)
     sec = time.time() - t0
     return dict(value=round(cnt["rays"] / sec / 1e6, 3), unit="Mrays/s", cores=threads, kind="port",
-                sample=f"the full {W}x{H} frame, one pass, rows dealt to {threads} threads")
+                sample=f"{what}, one pass, rows dealt to {threads} threads")
 
 
 def main():
