@@ -206,6 +206,10 @@ __global__ __launch_bounds__(kBlock, 5) void cast_kernel(DevScene S, rthip_cast_
     if (COUNT) flush_counters(counters, cnt, rays);
 }
 
+#ifdef RT_STAMP
+__device__ uint64_t g_stamps[1u << 18];  // dev build only: start / end wall clock of every wave of the static kernel
+#endif
+
 // A wave covers an 8x8 pixel tile, a workgroup 16x16, so that the rays of a wave stay close.
 __device__ __forceinline__ bool pixel_of_thread(int width, int height, int& x, int& y) {
     const int tiles_x = (width + 15) / 16;
@@ -232,6 +236,9 @@ __global__ __launch_bounds__(kBlock, RT_STATIC_WAVES) void cast_static_kernel(De
     const bool inside = pixel_of_thread(width, height, x, y);
     Counters cnt = {0, 0, 0, 0};
     uint32_t rays = 0;
+#ifdef RT_STAMP
+    const uint64_t stamp0 = wall_clock64();
+#endif
     if (inside) {
         const int samples = (int)c.samples;
         const uint32_t pixel = (uint32_t)(y * width + x);
@@ -271,6 +278,24 @@ __global__ __launch_bounds__(kBlock, RT_STATIC_WAVES) void cast_static_kernel(De
         o3[1] = acc.y;
         o3[2] = acc.z;
     }
+#ifdef RT_STAMP
+    {
+        uint64_t steps = 0, nodes = 0;
+        for (int l = 0; l < 64; l++) {
+            steps += __shfl((unsigned)cnt.wave_steps, l);
+            nodes += __shfl((unsigned)cnt.nodes, l);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            const uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6);
+            if (w < (1u << 16)) {
+                g_stamps[4 * w] = stamp0;
+                g_stamps[4 * w + 1] = wall_clock64();
+                g_stamps[4 * w + 2] = steps;
+                g_stamps[4 * w + 3] = nodes;
+            }
+        }
+    }
+#endif
     if (COUNT) flush_counters(counters, cnt, rays);
 }
 
@@ -624,3 +649,9 @@ int cast_launch(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_settings
     return launch_persistent(ctx, scene, cast, seed, d_rgb, width, height, shard, choice.refill, choice.inst_batch, d_counters,
                              stream);
 }
+
+#ifdef RT_STAMP
+extern "C" int rthip_debug_stamps(uint64_t* host, size_t n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), n * sizeof(uint64_t));
+}
+#endif
