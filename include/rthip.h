@@ -137,6 +137,8 @@ typedef struct rthip_stats {
     float last_build_ms;    /* device time of the last LBVH build             */
     uint32_t last_cast_kernel; /* RTHIP_KERNEL_* the last cast ran (never AUTO)  */
     uint32_t last_cast_refill; /* persistent kernel: idle lanes that end a traversal phase; else 0 */
+    float last_encode_ms;   /* device time of the last rthip_hdr_encode       */
+    uint32_t reserved;
 } rthip_stats;
 
 typedef struct rthip_ctx rthip_ctx;
@@ -279,6 +281,32 @@ int rthip_set_persistent_params(rthip_ctx* ctx, uint32_t refill, uint32_t inst_b
  * (src/lbvh/extra/dump.c): which = -1 for the TLAS, otherwise a blas_id.
  * *out_count receives the node count; out_nodes (may be NULL) must hold that many. */
 int rthip_get_tree(rthip_ctx* ctx, int which, rthip_node* out_nodes, uint64_t* out_count);
+
+/* ---- image output ------------------------------------------------------- */
+
+/* The reference writes its image with stbi_write_hdr(path, width, height, 3, rgb)
+ * (src/third_party/stb/stb_image_write.h:794, called at src/demos/cornell/main.c:222,
+ * bunny/main.c:73, spheres/main.c:68, tri/main.c:58): a Radiance header and per scanline
+ * the RGBE bytes (stb_image_write.h:639-654), run-length coded per component for
+ * 8 <= width < 32768 (:672-759).  rthip_hdr_encode produces exactly those file bytes on
+ * the GPU, so that at most ~4 bytes per pixel return to the host and the caller only
+ * has to fwrite them.
+ *
+ * rgb: float[height][width][3] in host memory, or NULL to encode the image of the last
+ * rthip_cast, which is still in device memory (no upload; width / height must match it).
+ * out: host buffer of `capacity` bytes; *out_size receives the file length.  A capacity
+ * of rthip_hdr_bound(width, height) always suffices; with less the call fails with
+ * RTHIP_E_LIMIT when the file is longer (and *out_size still tells the length).
+ * Components that are negative, NaN or >= 2^31 after scaling convert as the reference's
+ * x86-64 build converts them (truncate to int32, low byte; out of range -> 0). */
+uint64_t rthip_hdr_bound(int width, int height);
+int rthip_hdr_encode(rthip_ctx* ctx, const float* rgb, int width, int height, uint8_t* out, uint64_t capacity,
+                     uint64_t* out_size);
+/* The same between device buffers, enqueued on `stream` without synchronising: d_rgb as
+ * rthip_cast_device writes it, d_out of capacity >= rthip_hdr_bound(width, height),
+ * *d_size (device memory, 8 bytes) receives the file length. */
+int rthip_hdr_encode_device(rthip_ctx* ctx, const float* d_rgb, int width, int height, uint8_t* d_out,
+                            uint64_t capacity, uint64_t* d_size, void* stream);
 
 #ifdef __cplusplus
 }

@@ -211,6 +211,23 @@ def write_edges():
     np.savez_compressed(os.path.join(OUT, "edge_rays.npz"), **out)
 
 
+def write_hdr():
+    """Inputs and the bytes the reference's stbi_write_hdr produces for them (oracle/_ref/libref_hdr.so)."""
+    assert O.have_ref("hdr"), "build oracle/_ref first: make -C oracle ref"
+    out = {}
+    images = dict(scenes.hdr_test_images())
+    # radiance buffers the reference rendered (fixtures written by write_demos / write_bunny)
+    images["cornell_ref_rgb"] = np.load(os.path.join(OUT, "demo_cornell.npz"))["ref_rgb_64_s8_seed1"]
+    images["spheres_ref_rgb"] = np.load(os.path.join(OUT, "demo_spheres.npz"))["ref_rgb_s1_seed1"]
+    images["bunny_ref_rgb"] = np.load(os.path.join(OUT, "demo_bunny_class.npz"))["ref_rgb_96x54_s2_b2_seed5"]
+    for name, img in images.items():
+        data = O.ref_hdr_encode(img)
+        out[f"{name}_rgb"] = img
+        out[f"{name}_hdr"] = np.frombuffer(data, dtype=np.uint8)
+        print("hdr", name, img.shape, len(data), "bytes")
+    np.savez_compressed(os.path.join(OUT, "hdr.npz"), **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     assert O.have_ref("core"), "build oracle/_ref first: make -C oracle ref"
@@ -219,6 +236,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "converged":
         write_converged()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "hdr":
+        write_hdr()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "edges":
         write_edges()
@@ -229,3 +249,4 @@ if __name__ == "__main__":
     write_occlusion()
     write_edges()
     write_converged()
+    write_hdr()

@@ -91,8 +91,40 @@ def lib() -> C.CDLL:
         L.ora_primary_rays.argtypes = [_P, C.c_int, C.c_int, _P, _P]
         L.ora_scene_cast.restype = None
         L.ora_scene_cast.argtypes = [_P, _P, C.c_uint64, C.c_int, _P, C.c_int, C.c_int, _P, C.c_int, _P]
+        L.ora_hdr_encode.restype = C.c_uint64
+        L.ora_hdr_encode.argtypes = [_P, C.c_int, C.c_int, _P, C.c_uint64]
+        L.ora_rgbe.restype = None
+        L.ora_rgbe.argtypes = [_P, _P]
         _oracle = L
     return _oracle
+
+
+# ---- .hdr output -----------------------------------------------------------------
+
+
+def hdr_bound(width: int, height: int) -> int:
+    """An upper bound of the encoded size: header, and per scanline the marker and four components of which every
+    128 bytes cost one more."""
+    return 128 + height * (4 + 4 * (width + (width + 127) // 128))
+
+
+def _hdr_call(fn, rgb: np.ndarray) -> bytes:
+    rgb = np.ascontiguousarray(rgb, dtype=np.float32)
+    h, w = rgb.shape[0], rgb.shape[1]
+    out = np.zeros(hdr_bound(w, h), dtype=np.uint8)
+    n = fn(rgb.ctypes.data, w, h, out.ctypes.data, out.size)
+    assert 0 < n <= out.size, n
+    return out[:n].tobytes()
+
+
+def hdr_encode(rgb: np.ndarray) -> bytes:
+    """The file stbi_write_hdr writes for float32 rgb[h, w, 3], by the CPU restatement."""
+    return _hdr_call(lib().ora_hdr_encode, rgb)
+
+
+def ref_hdr_encode(rgb: np.ndarray) -> bytes:
+    """The same by the reference's writer (oracle/_ref/libref_hdr.so)."""
+    return _hdr_call(ref("hdr").ref_hdr_encode, rgb)
 
 
 # ---- LBVH ------------------------------------------------------------------------
@@ -288,6 +320,9 @@ def ref(name: str = "core") -> C.CDLL:
                 L.ref_scene_occluded.argtypes = [_P, _P, _P, C.c_uint64, C.c_float, _P]
             L.ref_scene_dump_tree.argtypes = [_P, C.c_int, _P, C.c_uint64, _P]
             L.ref_load_obj.argtypes = [C.c_char_p, C.c_uint32, _P, C.c_uint64, _P, _P, C.c_uint64, _P]
+        elif name == "hdr":
+            L.ref_hdr_encode.restype = C.c_uint64
+            L.ref_hdr_encode.argtypes = [_P, C.c_int, C.c_int, _P, C.c_uint64]
         else:
             L.ref_demo_run.restype = C.c_int
             L.ref_demo_run.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, _P, _P, _P, _P,

@@ -12,6 +12,7 @@
 
 #include <math.h>
 #include <pthread.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -1115,4 +1116,101 @@ void ora_a_to_b_quat(const float* a_, const float* b_, float* out4) {
         return;
     }
     out4[0] = x; out4[1] = y; out4[2] = z; out4[3] = w;
+}
+
+/* ---- .hdr output (the reference writes its image with stbi_write_hdr, e.g. src/demos/cornell/main.c:222) ---------- */
+
+/* (unsigned char)(float) as the reference's x86-64 build performs it: truncate to a 32-bit integer (out of range and
+ * NaN give INT_MIN), keep the low byte.  The C standard leaves negative and too-large values undefined; the image
+ * never holds them, the edge vectors do. */
+static uint8_t byte_of_float(float x) {
+    int32_t v = (x >= -2147483648.f && x < 2147483648.f) ? (int32_t)x : INT32_MIN;
+    return (uint8_t)((uint32_t)v & 0xffu);
+}
+
+void ora_rgbe(const float* l, uint8_t* out4) { /* stbiw__linear_to_rgbe, stb_image_write.h:639-654 */
+    const float m12 = l[1] > l[2] ? l[1] : l[2];
+    const float maxcomp = l[0] > m12 ? l[0] : m12;
+    if (maxcomp < 1e-32f) {
+        out4[0] = out4[1] = out4[2] = out4[3] = 0;
+        return;
+    }
+    int exponent = 0;
+    const float mant = (float)frexp((double)maxcomp, &exponent);
+    const float normalize = mant * 256.0f / maxcomp;
+    out4[0] = byte_of_float(l[0] * normalize);
+    out4[1] = byte_of_float(l[1] * normalize);
+    out4[2] = byte_of_float(l[2] * normalize);
+    out4[3] = (uint8_t)((uint32_t)(exponent + 128) & 0xffu);
+}
+
+typedef struct {
+    uint8_t* out;
+    uint64_t cap, len;
+} hdr_sink;
+
+static void hdr_put(hdr_sink* s, const uint8_t* data, uint64_t n) {
+    for (uint64_t i = 0; i < n; i++)
+        if (s->len + i < s->cap) s->out[s->len + i] = data[i];
+    s->len += n;
+}
+
+/* one component of one scanline, stb_image_write.h:722-757: stretches without three equal bytes in a row are copied
+ * in packets of at most 128, runs of at least three equal bytes become (128 + length, byte) packets of at most 127 */
+static void hdr_rle_component(hdr_sink* s, const uint8_t* comp, int width) {
+    int x = 0;
+    while (x < width) {
+        int r = x;
+        while (r + 2 < width && !(comp[r] == comp[r + 1] && comp[r] == comp[r + 2])) r++;
+        const int found = r + 2 < width;
+        if (!found) r = width;
+        while (x < r) {
+            const int len = r - x > 128 ? 128 : r - x;
+            const uint8_t lb = (uint8_t)len;
+            hdr_put(s, &lb, 1);
+            hdr_put(s, comp + x, (uint64_t)len);
+            x += len;
+        }
+        if (found) {
+            while (r < width && comp[r] == comp[x]) r++;
+            while (x < r) {
+                const int len = r - x > 127 ? 127 : r - x;
+                const uint8_t pk[2] = {(uint8_t)(len + 128), comp[x]};
+                hdr_put(s, pk, 2);
+                x += len;
+            }
+        }
+    }
+}
+
+uint64_t ora_hdr_encode(const float* rgb, int width, int height, uint8_t* out, uint64_t cap) { /* :761-785 */
+    if (width <= 0 || height <= 0 || !rgb) return 0;
+    hdr_sink s = {out, cap, 0};
+    char head[192];
+    const int hl = snprintf(head, sizeof head,
+                            "#?RADIANCE\n# Written by stb_image_write.h\nFORMAT=32-bit_rle_rgbe\n"
+                            "EXPOSURE=          1.0000000000000\n\n-Y %d +X %d\n", height, width);
+    hdr_put(&s, (const uint8_t*)head, (uint64_t)hl);
+    uint8_t* planes = (uint8_t*)malloc((size_t)width * 4);
+    for (int y = 0; y < height; y++) {
+        const float* row = rgb + (size_t)y * width * 3;
+        if (width < 8 || width >= 32768) { /* :683-697: no run-length coding */
+            for (int x = 0; x < width; x++) {
+                uint8_t px[4];
+                ora_rgbe(row + 3 * x, px);
+                hdr_put(&s, px, 4);
+            }
+            continue;
+        }
+        for (int x = 0; x < width; x++) {
+            uint8_t px[4];
+            ora_rgbe(row + 3 * x, px);
+            for (int c = 0; c < 4; c++) planes[x + (size_t)width * c] = px[c];
+        }
+        const uint8_t marker[4] = {2, 2, (uint8_t)((width & 0xff00) >> 8), (uint8_t)(width & 0xff)};
+        hdr_put(&s, marker, 4);
+        for (int c = 0; c < 4; c++) hdr_rle_component(&s, planes + (size_t)width * c, width);
+    }
+    free(planes);
+    return s.len;
 }

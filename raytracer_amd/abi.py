@@ -41,11 +41,12 @@ SHARD = np.dtype([("mode", "<u4"), ("rank", "<u4"), ("world", "<u4")], align=Fal
 STATS = np.dtype(
     [("rays", "<u8"), ("nodes_tested", "<u8"), ("tris_tested", "<u8"), ("inst_entered", "<u8"),
      ("wave_steps", "<u8"), ("last_cast_ms", "<f4"), ("last_build_ms", "<f4"),
-     ("last_cast_kernel", "<u4"), ("last_cast_refill", "<u4")],
+     ("last_cast_kernel", "<u4"), ("last_cast_refill", "<u4"),
+     ("last_encode_ms", "<f4"), ("reserved", "<u4")],
     align=False,
 )
 assert MATERIAL.itemsize == 40 and INSTANCE.itemsize == 68 and CAST.itemsize == 84
-assert NODE.itemsize == 32 and SHARD.itemsize == 12 and STATS.itemsize == 56
+assert NODE.itemsize == 32 and SHARD.itemsize == 12 and STATS.itemsize == 64
 
 MAT_LAMBERTIAN, MAT_DIELECTRIC, MAT_METAL, MAT_NORMAL, MAT_LIGHT = range(5)
 INST_SPHERE, INST_MESH = 0, 1
@@ -78,6 +79,9 @@ SYMBOLS = [
     ("rthip_set_cast_kernel", C.c_int, [_P, C.c_int]),
     ("rthip_set_persistent_params", C.c_int, [_P, C.c_uint32, C.c_uint32]),
     ("rthip_get_tree", C.c_int, [_P, C.c_int, _P, _P]),
+    ("rthip_hdr_bound", C.c_uint64, [C.c_int, C.c_int]),
+    ("rthip_hdr_encode", C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_uint64, _P]),
+    ("rthip_hdr_encode_device", C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_uint64, _P, _P]),
 ]
 
 _lib = None

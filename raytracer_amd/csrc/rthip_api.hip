@@ -141,7 +141,8 @@ void rthip_destroy(rthip_ctx* ctx) {
     DevBuf* all[] = {&w.aabb, &w.keys[0], &w.keys[1], &w.vals[0], &w.vals[1], &w.block_hist, &w.scan_tmp, &w.prio,
                      &w.child, &w.flags, &w.starters, &w.node_info, &w.node_dl, &w.leaf_sorted, &w.cnt_l, &w.bounds, &ctx->blas_nodes, &ctx->tri_v, &ctx->tri_n,
                      &ctx->tlas_nodes, &ctx->inst, &ctx->mats, &ctx->inst_aabb, &ctx->counters, &ctx->work_ring, &ctx->scratch_a,
-                     &ctx->scratch_b, &ctx->scratch_c, &ctx->scratch_d, &ctx->scratch_e};
+                     &ctx->scratch_b, &ctx->scratch_c, &ctx->scratch_d, &ctx->scratch_e, &ctx->frame, &ctx->hdr_stage,
+                     &ctx->hdr_lengths, &ctx->hdr_offsets, &ctx->hdr_out, &ctx->hdr_size};
     for (DevBuf* b : all) rthip_release(*b);
     for (DevBuf& b : ctx->wf) rthip_release(b);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -392,13 +393,65 @@ int rthip_cast(rthip_ctx* ctx, const rthip_cast_settings* cast, uint64_t seed, f
     if (!out_rgb) return rthip_fail(ctx, RTHIP_E_INVALID, "out_rgb is NULL");
     RT_HIP(ctx, hipSetDevice(ctx->device));
     const size_t bytes = (size_t)width * height * 3 * sizeof(float);
-    RT_TRY(rthip_reserve(ctx, ctx->scratch_a, bytes));
+    ctx->frame_w = ctx->frame_h = 0;
+    RT_TRY(rthip_reserve(ctx, ctx->frame, bytes));
     RT_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-    RT_TRY(rthip_cast_device(ctx, cast, seed, (float*)ctx->scratch_a.p, width, height, nullptr, ctx->stream));
+    RT_TRY(rthip_cast_device(ctx, cast, seed, (float*)ctx->frame.p, width, height, nullptr, ctx->stream));
     RT_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-    RT_HIP(ctx, hipMemcpyAsync(out_rgb, ctx->scratch_a.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(ctx, hipMemcpyAsync(out_rgb, ctx->frame.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     RT_HIP(ctx, hipEventElapsedTime(&ctx->last_cast_ms, ctx->ev0, ctx->ev1));
+    ctx->frame_w = width;  // the image stays in device memory for rthip_hdr_encode(rgb = NULL)
+    ctx->frame_h = height;
+    return RTHIP_OK;
+}
+
+// ---- .hdr output -------------------------------------------------------------------
+
+uint64_t rthip_hdr_bound(int width, int height) { return hdr_bound(width, height); }
+
+int rthip_hdr_encode_device(rthip_ctx* ctx, const float* d_rgb, int width, int height, uint8_t* d_out, uint64_t capacity,
+                            uint64_t* d_size, void* stream) {
+    if (!ctx) return RTHIP_E_INVALID;
+    if (!d_rgb || !d_out || !d_size) return rthip_fail(ctx, RTHIP_E_INVALID, "NULL device pointer");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    return hdr_encode_device(ctx, d_rgb, width, height, d_out, capacity, d_size, (hipStream_t)stream);
+}
+
+int rthip_hdr_encode(rthip_ctx* ctx, const float* rgb, int width, int height, uint8_t* out, uint64_t capacity,
+                     uint64_t* out_size) {
+    if (!ctx) return RTHIP_E_INVALID;
+    if (!out || !out_size) return rthip_fail(ctx, RTHIP_E_INVALID, "out / out_size is NULL");
+    if (width <= 0 || height <= 0) return rthip_fail(ctx, RTHIP_E_INVALID, "image %d x %d", width, height);
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    const float* d_rgb = nullptr;
+    if (rgb) {
+        const size_t bytes = (size_t)width * height * 3 * sizeof(float);
+        RT_TRY(rthip_reserve(ctx, ctx->scratch_a, bytes));
+        RT_HIP(ctx, hipMemcpyAsync(ctx->scratch_a.p, rgb, bytes, hipMemcpyHostToDevice, ctx->stream));
+        d_rgb = (const float*)ctx->scratch_a.p;
+    } else {
+        if (ctx->frame_w != width || ctx->frame_h != height)
+            return rthip_fail(ctx, RTHIP_E_INVALID, "rgb is NULL but the last rthip_cast produced %d x %d, not %d x %d",
+                              ctx->frame_w, ctx->frame_h, width, height);
+        d_rgb = (const float*)ctx->frame.p;
+    }
+    const uint64_t bound = hdr_bound(width, height);
+    RT_TRY(rthip_reserve(ctx, ctx->hdr_out, bound));
+    RT_TRY(rthip_reserve(ctx, ctx->hdr_size, 16));
+    RT_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    RT_TRY(hdr_encode_device(ctx, d_rgb, width, height, (uint8_t*)ctx->hdr_out.p, bound, (uint64_t*)ctx->hdr_size.p,
+                             ctx->stream));
+    RT_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    uint64_t size = 0;
+    RT_HIP(ctx, hipMemcpyAsync(&size, ctx->hdr_size.p, sizeof size, hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    RT_HIP(ctx, hipEventElapsedTime(&ctx->last_encode_ms, ctx->ev0, ctx->ev1));
+    *out_size = size;
+    if (size > capacity)
+        return rthip_fail(ctx, RTHIP_E_LIMIT, "the encoded image has %llu bytes, the buffer %llu",
+                          (unsigned long long)size, (unsigned long long)capacity);
+    RT_HIP(ctx, hipMemcpy(out, ctx->hdr_out.p, size, hipMemcpyDeviceToHost));
     return RTHIP_OK;
 }
 
@@ -568,6 +621,8 @@ int rthip_get_stats(rthip_ctx* ctx, rthip_stats* out) {
     out->last_build_ms = ctx->last_build_ms;
     out->last_cast_kernel = ctx->last_cast_kernel;
     out->last_cast_refill = ctx->last_cast_refill;
+    out->last_encode_ms = ctx->last_encode_ms;
+    out->reserved = 0;
     return RTHIP_OK;
 }
 

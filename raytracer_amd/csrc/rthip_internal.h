@@ -135,11 +135,14 @@ struct rthip_ctx {
     uint32_t inst_batch = 0;     // persistent kernel chosen by name: 0 = enter instances at once, k = park and enter k lanes at a time (RTHIP_INST_BATCH)
     uint32_t refill_lanes = 16;  // lanes with other work that end a traversal phase (RTHIP_REFILL overrides)
     DevBuf scratch_a, scratch_b, scratch_c, scratch_d, scratch_e;  // staging for host <-> device taps
+    DevBuf frame;                // float[3 w h]: the image of the last rthip_cast, kept for rthip_hdr_encode(rgb = NULL)
+    int frame_w = 0, frame_h = 0;
+    DevBuf hdr_stage, hdr_lengths, hdr_offsets, hdr_out, hdr_size;  // .hdr encoder: coded components, their lengths and file offsets
     // set by mesh_prepare_device: the workspace holds the centroid bounds of this box array (consumed by the next build)
     const float* bounds_of = nullptr;
     uint64_t bounds_n = 0;
     hipStream_t bounds_stream = nullptr;
-    float last_cast_ms = 0.f, last_build_ms = 0.f;
+    float last_cast_ms = 0.f, last_build_ms = 0.f, last_encode_ms = 0.f;
     uint32_t last_cast_kernel = 0, last_cast_refill = 0;
     // measured kernel choice of RTHIP_KERNEL_AUTO for big frames (see tune_cast); scene_generation changes with every
     // build and tracer setting
@@ -201,3 +204,8 @@ int cast_wavefront_launch(rthip_ctx* ctx, const DevScene& scene, const rthip_cas
                           hipStream_t stream);
 int cast_launch(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_settings& cast, uint64_t seed, float* d_rgb,
                 int width, int height, rthip_shard shard, uint64_t* d_counters, hipStream_t stream);
+
+// ---- .hdr output (hdr_encode.hip) ---------------------------------------------------
+uint64_t hdr_bound(int width, int height);
+int hdr_encode_device(rthip_ctx* ctx, const float* d_rgb, int width, int height, uint8_t* d_out, uint64_t capacity,
+                      uint64_t* d_size, hipStream_t stream);

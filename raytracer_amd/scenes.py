@@ -526,3 +526,30 @@ def edge_rays():
     dd = rng.normal(size=(400, 3))
     d += list(dd / np.linalg.norm(dd, axis=1, keepdims=True))
     return np.asarray(o, dtype=np.float32), np.asarray(d, dtype=np.float32)
+
+
+def hdr_test_images(seed: int = 7):
+    """Small float images that exercise every branch of the .hdr writer (stb_image_write.h:639-757): the widths at which
+    run-length coding switches on, runs and literal stretches around the packet limits (127 / 128), and the pixel values
+    at which the RGBE conversion changes behaviour (the 1e-32 cut-off, negative, huge, infinite and NaN components).
+    Returns {name: float32[h, w, 3]}."""
+    rng = np.random.default_rng(seed)
+    out = {}
+    for w in (1, 7, 8, 9, 127, 128, 129, 130, 257, 300):
+        out[f"rand_{w}"] = (rng.random((3, w, 3), dtype=np.float32) * np.float32(rng.choice([1e-3, 1.0, 100.0, 1e5]))).astype(np.float32)
+        out[f"steps_{w}"] = ((rng.integers(0, 3, (3, w, 1)) * 0.25).astype(np.float32) * np.ones((1, 1, 3), np.float32)).astype(np.float32)
+    img = np.zeros((2, 1500, 3), np.float32)
+    x = 0
+    for run in (1, 2, 3, 4, 126, 127, 128, 129, 254, 255, 256):
+        img[:, x:x + run] = np.float32(rng.random() * 5)
+        x += run
+    out["runs"] = img
+    img = rng.random((4, 700, 3), dtype=np.float32)
+    img[1, 100:500] = img[1, 100]      # one long run inside noise
+    img[2, :, 1] = 0.5                 # one constant component
+    img[3] = 0.0                       # a black scanline
+    out["mixed"] = img
+    sp = np.array([0, 1e-33, 1e-32, 1.0000001e-32, 1e-38, 1e-45, -1.0, -0.25, 1.0, 0.5, 255.0, 256.0, 1e10, 3.4e38,
+                   np.inf, -np.inf, np.nan, 65504.0, 0.99999994, 2.0 ** -100], np.float32)
+    out["special"] = np.stack(np.meshgrid(sp, sp, sp, indexing="ij"), -1).reshape(20, 400, 3).astype(np.float32)
+    return out

@@ -189,6 +189,27 @@ def occluded(tracer: RT_Tracer, origins, directions, tmax: float = 3.402823466e+
 CAST_KERNELS = {"persistent": 0, "static": 1, "wavefront": 2, "auto": 3}
 
 
+def hdr_encode(tracer: RT_Tracer, rgb, width: int, height: int) -> bytes:
+    """The bytes of the .hdr file the reference writes with stbi_write_hdr(path, width, height, 3, rgb)
+    (stb_image_write.h:794; src/demos/cornell/main.c:222), encoded on the GPU.  rgb: float32 [height, width, 3], or
+    None for the image of the last rt_tracer_cast (still in device memory)."""
+    if rgb is not None:
+        rgb = np.ascontiguousarray(rgb, dtype=np.float32)
+        assert rgb.size == width * height * 3
+    cap = int(tracer.lib.rthip_hdr_bound(width, height))
+    out = np.empty(cap, dtype=np.uint8)
+    size = C.c_uint64(0)
+    tracer.check(tracer.lib.rthip_hdr_encode(tracer.h, abi.ptr(rgb), width, height, abi.ptr(out), cap, C.addressof(size)),
+                 "rthip_hdr_encode")
+    return out[: size.value].tobytes()
+
+
+def write_hdr(tracer: RT_Tracer, path: str, rgb, width: int, height: int) -> None:
+    """stbi_write_hdr's file, encoded on the GPU (see hdr_encode)."""
+    with open(path, "wb") as f:
+        f.write(hdr_encode(tracer, rgb, width, height))
+
+
 def set_cast_kernel(tracer: RT_Tracer, kernel: str) -> None:
     """Selects the renderer implementation (all produce the same bits); see include/rthip.h."""
     tracer.check(tracer.lib.rthip_set_cast_kernel(tracer.h, CAST_KERNELS[kernel]), "rthip_set_cast_kernel")

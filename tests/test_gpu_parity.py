@@ -509,3 +509,74 @@ def test_errors_are_reported(gpu_tracer):
     img = np.zeros((4, 4, 3), dtype=np.float32)
     c = scenes.get_rt_cast_settings(4, 4, 1, (0, 0, 1), (0, 0, 0))
     assert lib.rthip_cast(gpu_tracer.h, abi.ptr(c), 0, abi.ptr(img), 4, 4) == 1  # no TLAS
+
+
+# ---- .hdr output ------------------------------------------------------------------------------
+
+
+def test_hdr_encode_matches_reference_bytes(gpu_tracer):
+    """rthip_hdr_encode against the bytes the reference's stbi_write_hdr wrote for the same images."""
+    g = golden("hdr")
+    names = sorted(k[:-4] for k in g.files if k.endswith("_hdr"))
+    assert len(names) >= 20
+    for name in names:
+        img = g[name + "_rgb"]
+        got = T.hdr_encode(gpu_tracer, img, img.shape[1], img.shape[0])
+        assert got == g[name + "_hdr"].tobytes(), name
+
+
+@pytest.mark.parametrize("w,h", [(8, 1), (63, 3), (64, 3), (65, 3), (127, 2), (128, 2), (129, 2), (191, 5), (192, 5),
+                                 (1000, 11), (4097, 3), (16384, 2), (32767, 2), (32768, 2), (5, 7)])
+def test_hdr_encode_shapes(oracle, gpu_tracer, w, h):
+    rng = np.random.default_rng(w * 131 + h)
+    img = (rng.random((h, w, 3), dtype=np.float32) * np.float32(3.0)).astype(np.float32)
+    # runs that start and end at every offset relative to the 64-byte blocks a wave codes
+    x = 0
+    while x < w:
+        run = int(rng.integers(1, 200))
+        if rng.random() < 0.5:
+            img[h // 2, x:x + run] = img[h // 2, x]
+        x += run
+    img[0, :, 2] = 0.25
+    assert T.hdr_encode(gpu_tracer, img, w, h) == oracle.hdr_encode(img)
+
+
+def test_hdr_encode_full_frame(oracle, gpu_tracer):
+    """A 3840 x 2160 frame with flat regions, gradients and noise."""
+    w, h = 3840, 2160
+    rng = np.random.default_rng(5)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    img = np.stack([xx / w, yy / h, np.float32(0.2) + 0 * xx], -1).astype(np.float32)
+    img[500:900, 1000:2500] = np.float32(0.73)                                  # flat
+    img[1200:1500] = rng.random((300, w, 3), dtype=np.float32) * np.float32(50)  # noise
+    img[1800:, :, :] = 0.0                                                      # black
+    got = T.hdr_encode(gpu_tracer, img, w, h)
+    want = oracle.hdr_encode(img)
+    assert len(got) == len(want)
+    assert hashlib.sha256(got).hexdigest() == hashlib.sha256(want).hexdigest()
+
+
+def test_hdr_encode_of_the_resident_frame(oracle, gpu_tracer):
+    """rgb = NULL encodes the image the last rthip_cast left in device memory."""
+    w, cam, sky = scenes.cornell()
+    tr = T.rt_make_tracer(T.RT_TracerSettings(max_bounces=4, sky=sky))
+    try:
+        T.rt_tracer_build_blas(tr, w)
+        T.rt_tracer_build_tlas(tr, w)
+        W, H = 200, 120
+        out = np.zeros((H, W, 3), np.float32)
+        T.rt_tracer_cast(tr, cam(W, H, 2), out, W, H, seed=3)
+        assert T.hdr_encode(tr, None, W, H) == oracle.hdr_encode(out)
+        with pytest.raises(T.RTHipError):
+            T.hdr_encode(tr, None, W + 1, H)
+    finally:
+        T.rt_tracer_cleanup(tr)
+
+
+def test_hdr_encode_rejects_a_short_buffer(gpu_tracer):
+    import ctypes as C
+    img = np.random.default_rng(1).random((4, 64, 3), dtype=np.float32)
+    out = np.zeros(64, np.uint8)
+    size = C.c_uint64(0)
+    rc = gpu_tracer.lib.rthip_hdr_encode(gpu_tracer.h, abi.ptr(img), 64, 4, abi.ptr(out), out.size, C.addressof(size))
+    assert rc == 4 and size.value > 64  # RTHIP_E_LIMIT, and the length is still reported

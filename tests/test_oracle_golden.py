@@ -157,3 +157,36 @@ def test_edge_case_rays_match_reference(oracle):
         assert (inst == g[f"{name}_ref_inst"]).all() and (tri == g[f"{name}_ref_tri"]).all(), name
         assert (bits(t) == bits(g[f"{name}_ref_t"])).all() and (bits(uv) == bits(g[f"{name}_ref_uv"])).all(), name
         assert (bits(nrm) == bits(g[f"{name}_ref_normal"])).all(), name
+
+
+def _hdr_names():
+    g = golden("hdr")
+    return sorted(k[:-4] for k in g.files if k.endswith("_hdr"))
+
+
+def test_hdr_encoder_matches_reference_writer(oracle):
+    """The restated .hdr writer against the bytes the reference's stbi_write_hdr produced (tests/golden/hdr.npz):
+    every run-length branch (widths 1..300, runs of 1..256 equal bytes) and every special pixel value."""
+    g = golden("hdr")
+    names = _hdr_names()
+    assert len(names) >= 20
+    for name in names:
+        got = oracle.hdr_encode(g[name + "_rgb"])
+        assert got == g[name + "_hdr"].tobytes(), name
+
+
+def test_hdr_test_images_are_reproducible():
+    g = golden("hdr")
+    for name, img in scenes.hdr_test_images().items():
+        assert bits(img).tobytes() == bits(g[name + "_rgb"]).tobytes(), f"generator of {name} drifted"
+
+
+def test_hdr_encoder_against_reference_when_built(oracle):
+    """Random images through the reference itself (only where oracle/_ref has been built)."""
+    if not oracle.have_ref("hdr"):
+        pytest.skip("oracle/_ref/libref_hdr.so is not built here")
+    rng = np.random.default_rng(11)
+    for w, h in ((64, 5), (63, 4), (65, 4), (500, 7), (4097, 2), (7, 9), (32768, 1)):
+        img = (rng.random((h, w, 3), dtype=np.float32) * np.float32(4.0)).astype(np.float32)
+        img[:, w // 3: w // 2] = img[:, w // 3: w // 3 + 1]  # a run in every scanline
+        assert oracle.hdr_encode(img) == oracle.ref_hdr_encode(img), (w, h)
