@@ -158,6 +158,50 @@ def shadow_ray_rate(tr, torch, cast, W, H, steps):
                 what="any-hit occlusion rays from the primary hit points towards a directional light, occlusion_kernel")
 
 
+def hdr_output(tr, torch, cast, W, H, steps, want_cpu):
+    """The image output step that follows every cast in the reference's programs (stbi_write_hdr,
+    src/demos/cornell/main.c:222): rthip_hdr_encode_device on the frame in HBM, HIP-event time of its three kernels,
+    against the reference's writer (or its CPU restatement) on the same frame on this host."""
+    from raytracer_amd import abi
+
+    stream = torch.cuda.current_stream()
+    fb = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+    tr.check(tr.lib.rthip_cast_device(tr.h, abi.ptr(cast), 1, fb.data_ptr(), W, H, None, stream.cuda_stream), "rthip_cast_device")
+    cap = int(tr.lib.rthip_hdr_bound(W, H))
+    out = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+    size = torch.zeros(1, dtype=torch.int64, device="cuda")
+
+    def encode():
+        tr.check(tr.lib.rthip_hdr_encode_device(tr.h, fb.data_ptr(), W, H, out.data_ptr(), cap, size.data_ptr(),
+                                                stream.cuda_stream), "rthip_hdr_encode_device")
+
+    encode()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(stream)
+    for _ in range(steps):
+        encode()
+    b.record(stream)
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / steps
+    n = int(size.item())
+    algo = 12 * W * H + n  # the float frame read once, the file written once
+    res = {"what": "Radiance .hdr file bytes of the frame (RGBE + run-length coding), hdr_rows_kernel + hdr_offsets_kernel + "
+                   "hdr_gather_kernel", "ms": round(ms, 4), "file_bytes": n, "bytes_per_pixel": round(n / (W * H), 3),
+           "hbm_roofline_frac": round(algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    if want_cpu:
+        from oracle import oracle as O
+
+        host = fb.cpu().numpy()
+        use_ref = O.have_ref("hdr")
+        t0 = time.perf_counter()
+        want = O.ref_hdr_encode(host) if use_ref else O.hdr_encode(host)
+        res["cpu_ms"] = round((time.perf_counter() - t0) * 1e3, 2)
+        res["cpu_kind"] = "reference" if use_ref else "port"
+        res["identical_to_cpu"] = bool(out[:n].cpu().numpy().tobytes() == want)
+    return res
+
+
 def recorded_traffic(workload: str, kernel_name: str):
     """HBM bytes per launch of the cast kernel from the PMC passes kept under profiles/ (FETCH_SIZE and
     WRITE_SIZE, separate rocprofv3 runs of this same command; tools/pmc_traffic.py writes the file).
@@ -446,6 +490,8 @@ def main():
         if args.workload == "bunny":
             line["shadow_rays"] = shadow_ray_rate(tr, torch, cast, W, H, args.steps)
         want_cpu = not args.no_cpu_baseline and world == 1  # the CPU baseline is reported at N = 1 only
+        if ray_o is None:
+            line["hdr_output"] = hdr_output(tr, torch, cast, W, H, args.steps, want_cpu)
         if want_cpu and ray_o is not None:
             line["cpu_baseline"] = cpu_baseline_rays(wl, flat, ray_o[: 1 << 16].cpu().numpy(), ray_d[: 1 << 16].cpu().numpy())
         if want_cpu and ray_o is None:

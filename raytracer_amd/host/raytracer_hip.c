@@ -244,4 +244,31 @@ rt_hook void rt_tracer_cast(RT_Handle handle, RT_CastSettings settings, vec3_f32
             fclose(f);
         }
     }
+    const char* hdr = getenv("RT_HIP_HDR");
+    if (hdr) rt_hip_write_hdr(handle, hdr, width, height);
+}
+
+// The image of the last rt_tracer_cast as a Radiance .hdr file, byte for byte the file
+// stbi_write_hdr(path, width, height, 3, radiance) writes (stb_image_write.h:794; the call every demo makes
+// after its cast, e.g. src/demos/cornell/main.c:222), encoded on the GPU from the frame that is still in
+// device memory: the host only writes the bytes out.  Returns 1 on success like stbi_write_hdr, 0 otherwise.
+// RT_HIP_HDR=<path> makes rt_tracer_cast call it after every cast.
+internal int rt_hip_write_hdr(RT_Handle handle, const char* path, int width, int height) {
+    RT_HIP_Tracer* tracer = rt_hip_handle_to_tracer(handle);
+    int ok = 0;
+    {DeferResource(Temp scratch = scratch_begin(NULL, 0), scratch_end(scratch)) {
+        u64 capacity = rthip_hdr_bound(width, height), size = 0;
+        u8* bytes = push_array(scratch.arena, u8, capacity + 1);
+        int rc = rthip_hdr_encode(tracer->ctx, NULL, width, height, bytes, capacity, &size);
+        if (rc != RTHIP_OK) {
+            fprintf(stderr, "rthip: rthip_hdr_encode failed (%d): %s\n", rc, rthip_last_error(tracer->ctx));
+        } else {
+            FILE* f = fopen(path, "wb");
+            if (f) {
+                ok = fwrite(bytes, 1, (size_t)size, f) == (size_t)size;
+                fclose(f);
+            }
+        }
+    }}
+    return ok;
 }

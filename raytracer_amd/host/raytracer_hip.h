@@ -23,3 +23,6 @@ struct RT_HIP_Tracer {
 
 internal RT_HIP_Tracer* rt_hip_handle_to_tracer(RT_Handle handle);
 internal RT_Handle      rt_hip_tracer_to_handle(RT_HIP_Tracer* tracer);
+
+// not one of the five hooks: the GPU-side replacement of the stbi_write_hdr call that follows rt_tracer_cast
+internal int rt_hip_write_hdr(RT_Handle handle, const char* path, int width, int height);

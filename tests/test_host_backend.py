@@ -40,7 +40,7 @@ def test_reference_demo_binary_renders_through_the_backend(gpu_tracer, tmp_path,
 
     wd, ht, seed = 72, 56, 4
     raw = tmp_path / "frame.f32"
-    env = dict(os.environ, RT_HIP_DUMP_F32=str(raw))
+    env = dict(os.environ, RT_HIP_DUMP_F32=str(raw), RT_HIP_HDR=str(tmp_path / "gpu.hdr"))
     subprocess.check_call([exe, str(tmp_path / "out.hdr"), f"--width={wd}", f"--height={ht}", f"--samples={samples}",
                            "--bounces=8", f"--seed={seed}"], cwd=str(tmp_path), env=env, timeout=120)
     got = np.fromfile(str(raw), dtype=np.float32).reshape(ht, wd, 3)
@@ -61,3 +61,6 @@ def test_reference_demo_binary_renders_through_the_backend(gpu_tracer, tmp_path,
 
     dump = (tmp_path / "out.bvh").read_bytes()
     assert dump == golden("demo_" + demo)["ref_tlas_dump"].tobytes(), "out.bvh differs from the reference's"
+    # the demo wrote out.hdr with the reference's own stbi_write_hdr; the backend's GPU encoder (RT_HIP_HDR) wrote
+    # the frame still in device memory: the two files must be the same bytes
+    assert (tmp_path / "gpu.hdr").read_bytes() == (tmp_path / "out.hdr").read_bytes()
