@@ -11,9 +11,10 @@
 // The writer's greedy loop cuts a component into maximal runs of >= 3 equal bytes and the stretches between them, and
 // both kinds are cut into packets from their own start.  That is a function of each byte's neighbourhood and of two
 // running positions (start of the current run, start of the current stretch), so a wave codes a component 64 bytes
-// at a time: every byte knows from its neighbours i-3..i+3 whether it lies in a run, ballots give the two start
-// positions and the output offset of every byte (a byte emits 0, 1 or 2 bytes), and the last byte of each packet
-// writes the packet's length.
+// at a time: one ballot of "equal to the next byte" per block, shifted and combined with the masks of the
+// neighbouring blocks, tells every byte whether it lies in a run; further ballots give the two start positions and
+// the output offset of every byte (a byte emits 0, 1 or 2 bytes), and the last byte of each packet writes the
+// packet's length.
 //
 // Three launches: hdr_rows_kernel (one workgroup per scanline: RGBE conversion into LDS planes, then one wave per
 // component codes its plane into a staging slot and records the length), hdr_offsets_kernel (scan of the lengths,
@@ -65,13 +66,6 @@ __global__ __launch_bounds__(kBlock) void hdr_flat_kernel(const float* __restric
     out[4 * i + 3] = (uint8_t)(v >> 24);
 }
 
-// byte at block position lane + d (d in -3..3) out of the previous, current and next 64-byte blocks
-__device__ __forceinline__ uint32_t neighbour(uint32_t prev, uint32_t cur, uint32_t next, int lane, int d) {
-    const int l = lane + d;
-    const uint32_t a = __shfl(cur, l & 63), p = __shfl(prev, l & 63), n = __shfl(next, l & 63);
-    return l < 0 ? p : (l > 63 ? n : a);
-}
-
 // One workgroup per scanline y.  planes (LDS): 4 x width bytes.  Wave c codes component c into
 // stage + (4 y + c) * stage_pitch and stores the coded length in lengths[4 y + c].
 __global__ __launch_bounds__(kBlock) void hdr_rows_kernel(const float* __restrict__ rgb, int width,
@@ -98,27 +92,34 @@ __global__ __launch_bounds__(kBlock) void hdr_rows_kernel(const float* __restric
     uint32_t total = 0;      // bytes coded so far
     int run_start = 0;       // where the run of equal bytes that reaches into this block began
     int stretch_start = 0;   // where the current stretch of literal bytes began
-    uint32_t prev = 0, cur = lane < width ? b[lane] : 0u, next = 0;
+    // Lane masks of the previous block (wave-uniform): eq bit l = byte l equals byte l + 1, tri bit l = bytes l, l + 1,
+    // l + 2 exist and are equal, run bit l = byte l lies in a run of >= 3.
+    uint64_t eq_prev = 0, tri_prev = 0, run_prev = 0;
+    uint32_t cur = lane < width ? b[lane] : 0u, next = 0;
     for (int base = 0; base < width; base += 64) {
         const int i = base + lane;
         next = (i + 64 < width) ? b[i + 64] : 0u;
         const bool valid = i < width;
-        const uint32_t m1 = neighbour(prev, cur, next, lane, -1), m2 = neighbour(prev, cur, next, lane, -2),
-                       m3 = neighbour(prev, cur, next, lane, -3), p1 = neighbour(prev, cur, next, lane, 1),
-                       p2 = neighbour(prev, cur, next, lane, 2), p3 = neighbour(prev, cur, next, lane, 3);
-        // t(j): bytes j, j+1, j+2 exist and are equal
-        const bool t_m3 = i - 3 >= 0 && i - 1 < width && m3 == m2 && m2 == m1;
-        const bool t_m2 = i - 2 >= 0 && valid && m2 == m1 && m1 == cur;
-        const bool t_m1 = i - 1 >= 0 && i + 1 < width && m1 == cur && cur == p1;
-        const bool t_0 = i + 2 < width && cur == p1 && cur == p2;
-        const bool t_p1 = i + 3 < width && p1 == p2 && p2 == p3;
-        const bool in_run = valid && (t_m2 || t_m1 || t_0);
-        const bool prev_in_run = i >= 1 && (t_m3 || t_m2 || t_m1);      // byte i - 1
-        const bool next_in_run = i + 1 < width && (t_m1 || t_0 || t_p1);  // byte i + 1
+        // the first three bytes of the next block decide the last lanes' flags
+        const uint32_t n0 = __shfl(next, 0), n1 = __shfl(next, 1), n2 = __shfl(next, 2);
+        const uint32_t down = __shfl_down(cur, 1);
+        const uint32_t p1 = lane == 63 ? n0 : down;
+        const bool same_as_next = i + 1 < width && cur == p1;
+        const uint64_t eq = __ballot(same_as_next);
+        const uint64_t eq_n0 = (base + 65 < width && n0 == n1) ? 1ull : 0ull;  // eq of the next block's lanes 0, 1
+        const uint64_t eq_n1 = (base + 66 < width && n1 == n2) ? 1ull : 0ull;
+        const uint64_t tri = eq & ((eq >> 1) | (eq_n0 << 63));
+        const uint64_t tri_n0 = eq_n0 & eq_n1;
+        const uint64_t run = tri | (tri << 1) | (tri_prev >> 63) | (tri << 2) | (tri_prev >> 62);
+        const uint64_t run_n0 = tri_n0 | (tri >> 63) | ((tri >> 62) & 1ull);
+        const uint64_t before_in_run = (run << 1) | (run_prev >> 63);  // bit l: byte l - 1 lies in a run
+        const uint64_t after_in_run = (run >> 1) | (run_n0 << 63);     // bit l: byte l + 1 lies in a run
+        const uint64_t same_as_before = (eq << 1) | (eq_prev >> 63);
+        const uint64_t valid_mask = __ballot(valid);
+        const uint64_t rh = run & ~same_as_before;  // first byte of a run
+        const uint64_t sh = valid_mask & ~run & (before_in_run | (base == 0 ? 1ull : 0ull));  // first literal byte of a stretch
+        const bool in_run = (run >> lane) & 1ull;
         // start of the run / stretch this byte belongs to: the last start at or before it
-        const bool run_head = in_run && (i == 0 || cur != m1);
-        const bool stretch_head = valid && !in_run && (i == 0 || prev_in_run);
-        const uint64_t rh = __ballot(run_head), sh = __ballot(stretch_head);
         const uint64_t rh_le = rh & le_mask, sh_le = sh & le_mask;
         const int my_run_start = rh_le ? base + 63 - __clzll((long long)rh_le) : run_start;
         const int my_stretch_start = sh_le ? base + 63 - __clzll((long long)sh_le) : stretch_start;
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(kBlock) void hdr_rows_kernel(const float* __restric
         const uint32_t off = total + (uint32_t)__popcll(e1 & lt_mask) + (uint32_t)__popcll(e2 & lt_mask);
         total += (uint32_t)__popcll(e1) + (uint32_t)__popcll(e2);
         if (in_run) {
-            const bool last = in_packet == 126 || i + 1 >= width || p1 != cur;
+            const bool last = in_packet == 126 || !same_as_next;
             if (last) {  // bytes after the packet's first emit nothing, so they all see the offset behind it
                 const uint32_t at = in_packet == 0 ? off : off - 2u;
                 o[at] = (uint8_t)(128 + in_packet + 1);
@@ -140,10 +141,12 @@ __global__ __launch_bounds__(kBlock) void hdr_rows_kernel(const float* __restric
             }
         } else if (valid) {
             o[in_packet == 0 ? off + 1u : off] = (uint8_t)cur;
-            const bool last = in_packet == 127 || i + 1 >= width || next_in_run;
+            const bool last = in_packet == 127 || i + 1 >= width || ((after_in_run >> lane) & 1ull);
             if (last) o[in_packet == 0 ? off : off - (uint32_t)in_packet - 1u] = (uint8_t)(in_packet + 1);
         }
-        prev = cur;
+        eq_prev = eq;
+        tri_prev = tri;
+        run_prev = run;
         cur = next;
     }
     if (lane == 0) lengths[4 * y + c] = total;
