@@ -511,6 +511,46 @@ def test_errors_are_reported(gpu_tracer):
     assert lib.rthip_cast(gpu_tracer.h, abi.ptr(c), 0, abi.ptr(img), 4, 4) == 1  # no TLAS
 
 
+def test_animated_instances_rebuild_the_tlas_every_frame(oracle, gpu_tracer):
+    """The reference animates by calling rt_tracer_build_tlas again (raytracer_cpu.c:32-37).  Four frames: instances
+    move, turn, shrink, disappear and come back; the BLAS is built once.  Every frame's TLAS and hits against the
+    oracle built from scratch for that frame."""
+    verts, indices = scenes.bunny_class_mesh(3)
+    w, cam, sky = scenes.instanced_grid(9, seed=3, verts=verts, indices=indices)
+    gpu_tracer.check(gpu_tracer.lib.rthip_set_tracer(gpu_tracer.h, 3, 1 if sky else 0), "set_tracer")
+    T.rt_tracer_build_blas(gpu_tracer, w)
+    blas0 = T.get_tree(gpu_tracer, 0).copy()
+    o, d = scenes.random_rays(6000, seed=8, lo=(-12, -2, -12), hi=(12, 3, 12))
+    removed = []
+    for frame in range(4):
+        for k, it in enumerate(w.instances):
+            a = 0.37 * frame + 0.11 * k
+            it.translation = (np.float32(it.translation[0] + 0.4 * np.sin(a)), np.float32(it.translation[1] + 0.05 * frame),
+                              np.float32(it.translation[2] + 0.4 * np.cos(a)))
+            it.rotation = (np.float32(0), np.float32(np.sin(a / 2)), np.float32(0), np.float32(np.cos(a / 2)))
+            s = np.float32(0.5 + 0.4 * abs(np.sin(a)))
+            it.scale = (s, s, s)
+        if frame == 1:  # 30 instances leave ...
+            removed = [w.instances.pop() for _ in range(30)]
+        if frame == 3:  # ... and return
+            w.instances.extend(removed)
+        T.rt_tracer_build_tlas(gpu_tracer, w)
+        flat = world.flatten_world(w)
+        sc = oracle.Scene(flat, 3, sky)
+        assert_same_tree(T.get_tree(gpu_tracer, -1), sc.tree(-1), f"frame {frame} TLAS")
+        inst, tri, t, uv, nrm = T.trace_rays(gpu_tracer, o, d)
+        oi, ot, ott, ouv, onrm, _ = sc.trace(o, d, threads=8)
+        assert (inst == oi).all() and (tri == ot).all() and (bits(t) == bits(ott)).all(), f"frame {frame}"
+        assert (bits(uv) == bits(ouv)).all() and (bits(nrm) == bits(onrm)).all()
+        assert int((inst > 0).sum()) > 200
+        c = cam(64, 36, 1)
+        img = np.zeros((36, 64, 3), dtype=np.float32)
+        T.rt_tracer_cast(gpu_tracer, c, img, 64, 36, seed=frame)
+        want, _ = sc.cast(c, frame, 64, 36, rng_mode=oracle.RNG_COUNTER, threads=8)
+        assert (bits(img) == bits(want)).all(), f"frame {frame} radiance"
+    assert T.get_tree(gpu_tracer, 0).tobytes() == blas0.tobytes(), "the BLAS must not change"
+
+
 # ---- .hdr output ------------------------------------------------------------------------------
 
 
