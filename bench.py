@@ -454,7 +454,7 @@ def main():
     total_rays = float(r_all.item())
 
     last = T.get_stats(tr)
-    kernel_name = {0: f"cast_kernel (persistent, refill {last['last_cast_refill']})", 1: "cast_static_kernel",
+    kernel_name = {0: f"cast_kernel (persistent, refill {last['last_cast_refill']})", 1: "cast_static_kernel", 4: "cast_samples_kernel",
                    2: "wf_trace_kernel + wf_shade_kernel (wavefront)"}[last["last_cast_kernel"]]
     if ray_o is not None:
         kernel_name = "trace_rays_kernel"

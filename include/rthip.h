@@ -267,9 +267,20 @@ int rthip_set_counting(rthip_ctx* ctx, int enabled);
  *                            persistent for deep ones
  *   RTHIP_KERNEL_PERSISTENT  resident waves, lanes take a new path as soon as theirs ends
  *   RTHIP_KERNEL_STATIC      one pixel per thread
+ *   RTHIP_KERNEL_STATIC_SAMPLES  one SAMPLE per thread, the samples of a pixel in neighbouring lanes and summed
+ *                            in sample order (samples = 2, 4 or 8; any other count runs RTHIP_KERNEL_STATIC).
+ *                            AUTO uses it wherever it would run STATIC, and without a probe for frames of
+ *                            fewer than 40 000 8x8 pixel tiles (20 480 for scenes of >= 64 instances or
+ *                            >= 2^20 triangles)
  *   RTHIP_KERNEL_WAVEFRONT   ray generation, traversal, shading and resolve as separate kernels
- * The environment variable RTHIP_CAST=auto|persistent|static|wavefront sets the initial value. */
-enum { RTHIP_KERNEL_PERSISTENT = 0, RTHIP_KERNEL_STATIC = 1, RTHIP_KERNEL_WAVEFRONT = 2, RTHIP_KERNEL_AUTO = 3 };
+ * The environment variable RTHIP_CAST=auto|persistent|static|static-samples|wavefront sets the initial value. */
+enum {
+    RTHIP_KERNEL_PERSISTENT = 0,
+    RTHIP_KERNEL_STATIC = 1,
+    RTHIP_KERNEL_WAVEFRONT = 2,
+    RTHIP_KERNEL_AUTO = 3,
+    RTHIP_KERNEL_STATIC_SAMPLES = 4
+};
 int rthip_set_cast_kernel(rthip_ctx* ctx, int kernel);
 /* Scheduling parameters of RTHIP_KERNEL_PERSISTENT when it is selected by name (AUTO picks its own): `refill`
  * in 1..64 = lanes with no ray to walk that make a wave stop walking and shade / fetch new paths (default 16);

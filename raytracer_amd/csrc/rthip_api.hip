@@ -113,6 +113,7 @@ int rthip_create(rthip_ctx** out_ctx, int device_id) {
     ctx->refit_fence = (fence && fence[0] == '1') ? 1 : 0;
     const char* mode = getenv("RTHIP_CAST");
     if (mode && strcmp(mode, "static") == 0) ctx->cast_mode = 1;
+    if (mode && strcmp(mode, "static-samples") == 0) ctx->cast_mode = 4;
     if (mode && strcmp(mode, "wavefront") == 0) ctx->cast_mode = 2;
     if (mode && strcmp(mode, "persistent") == 0) ctx->cast_mode = 0;
     if (mode && strcmp(mode, "auto") == 0) ctx->cast_mode = 3;
@@ -170,7 +171,7 @@ int rthip_set_counting(rthip_ctx* ctx, int enabled) {
 
 int rthip_set_cast_kernel(rthip_ctx* ctx, int kernel) {
     if (!ctx) return RTHIP_E_INVALID;
-    if (kernel < 0 || kernel > 3) return rthip_fail(ctx, RTHIP_E_INVALID, "unknown cast kernel %d", kernel);
+    if (kernel < 0 || kernel > 4) return rthip_fail(ctx, RTHIP_E_INVALID, "unknown cast kernel %d", kernel);
     ctx->cast_mode = kernel;
     return RTHIP_OK;
 }

@@ -299,6 +299,73 @@ __global__ __launch_bounds__(kBlock, RT_STATIC_WAVES) void cast_static_kernel(De
     if (COUNT) flush_counters(counters, cnt, rays);
 }
 
+// The pixel-per-thread renderer with one lane per SAMPLE instead: 2^log2_group lanes (4, 16 or 64 = samples^2)
+// share a pixel, a wave covers 4x4, 2x2 or 1 pixel.  A frame with few pixels and many samples per pixel becomes
+// samples^2 times as many waves of one path per lane, which the dispatcher spreads where the pixel-per-thread
+// kernel would hold the frame in a few long-running waves (Cornell 512^2 at 4 spp: 4096 waves, all resident from the
+// start, the slowest 1.5 times the median).  The samples of a pixel are added in the order of the sample loop
+// (raytracer_cpu.c:196-236) by the pixel's first lane, so the sum has the same bits.
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock, RT_STATIC_WAVES) void cast_samples_kernel(DevScene S, rthip_cast_settings c, uint64_t seed,
+                                                              float* __restrict__ out, int width, int height,
+                                                              rthip_shard shard, uint32_t log2_group, uint64_t* counters) {
+    extern __shared__ uint32_t bounce_stack[];
+    uint32_t* stack = bounce_stack + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t group = 1u << log2_group;
+    const uint32_t sidx = lane & (group - 1u);
+    const uint32_t pix = lane >> log2_group;                                   // pixel of the wave
+    const uint32_t side = log2_group == 2 ? 4u : (log2_group == 4 ? 2u : 1u);  // the wave covers side x side pixels
+    const uint32_t tiles_x = ((uint32_t)width + 2u * side - 1u) / (2u * side);
+    const int x = (int)((blockIdx.x % tiles_x) * 2u * side + (wave & 1u) * side + pix % side);
+    const int y = (int)((blockIdx.x / tiles_x) * 2u * side + (wave >> 1) * side + pix / side);
+    const bool inside = x < width && y < height;
+    const int samples = (int)c.samples;
+    const uint32_t pixel = inside ? (uint32_t)(y * width + x) : 0u;
+    Counters cnt = {0, 0, 0, 0};
+    uint32_t rays = 0;
+    bool mine = inside;
+    if (inside && shard.mode == 1) {
+        const uint32_t tile = (uint32_t)((y / 64) * ((width + 63) / 64) + (x / 64));
+        mine = (tile % shard.world) == shard.rank;
+    }
+    const bool have = mine && !(shard.mode == 2 && (sidx % shard.world) != shard.rank);
+    V3 L = mk(0.f, 0.f, 0.f);
+    if (have) {
+        PathState P;
+        P.g = rng_make(seed, pixel, sidx);
+        V3 o, d;
+        camera_ray(c, width, height, x, y, (int)(sidx % (uint32_t)samples), (int)(sidx / (uint32_t)samples), true, P.g, o, d);
+        P.depth = S.max_bounces;
+        P.sp = 0;
+        P.ior_top = P.ior_below = c.ior;
+        if (P.depth != 0) {
+            for (;;) {
+                rays++;
+                const Hit h = closest_hit_query<COUNT>(S, o, d, cnt);
+                if (path_bounce(S, P, h, o, d, L, stack, kBlock)) break;
+            }
+            L = path_fold(S, P, L, stack, kBlock);
+        }
+    }
+    // every lane of a pixel walks through the pixel's samples in order; the first lane keeps the sum
+    V3 acc = mk(0.f, 0.f, 0.f);
+    const uint32_t first = lane & ~(group - 1u);
+    for (uint32_t k = 0; k < group; k++) {
+        const float lx = __shfl(L.x, (int)(first + k)), ly = __shfl(L.y, (int)(first + k)), lz = __shfl(L.z, (int)(first + k));
+        const int has = __shfl((int)have, (int)(first + k));
+        if (has) acc = add(acc, mk(lx, ly, lz));
+    }
+    if (inside && sidx == 0) {
+        if (mine && shard.mode != 2) acc = scale(acc, 1.f / ((float)samples * (float)samples));
+        float* o3 = out + 3 * (size_t)pixel;
+        o3[0] = acc.x;
+        o3[1] = acc.y;
+        o3[2] = acc.z;
+    }
+    if (COUNT) flush_counters(counters, cnt, rays);
+}
+
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void primary_hits_kernel(DevScene S, rthip_cast_settings c, int width, int height,
                                                               uint32_t* __restrict__ hits4, uint64_t* counters) {
@@ -460,7 +527,7 @@ int trace_rays_launch(rthip_ctx* ctx, const DevScene& scene, const float* d_o, c
     // scene is larger than the Infinity Cache the walk is bound by HBM line fetches, not by idle lanes,
     // and the plain kernel (fewer registers, more waves) is the faster one.
     const uint64_t scene_bytes = ctx->total_blas_nodes * 32ull + ctx->total_tris * 48ull;
-    const bool resident = ctx->cast_mode == 0 || (ctx->cast_mode != 1 && scene_bytes <= (256ull << 20));
+    const bool resident = ctx->cast_mode == 0 || (ctx->cast_mode != 1 && ctx->cast_mode != 4 && scene_bytes <= (256ull << 20));
     if (n >= (1ull << 18) && n < (1ull << 32) * kRayGrab && resident) {
         uint32_t blocks = div_up(n, kBlock);
         if (blocks > ctx->persistent_blocks) blocks = ctx->persistent_blocks;
@@ -517,6 +584,21 @@ int launch_static(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_settin
         cast_static_kernel<true><<<blocks, kBlock, lds, stream>>>(scene, cast, seed, d_rgb, width, height, shard, d_counters);
     else
         cast_static_kernel<false><<<blocks, kBlock, lds, stream>>>(scene, cast, seed, d_rgb, width, height, shard, nullptr);
+    RT_HIP(ctx, hipGetLastError());
+    return RTHIP_OK;
+}
+
+// samples = 2, 4 or 8 only (4, 16 or 64 lanes per pixel)
+int launch_samples(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_settings& cast, uint64_t seed, float* d_rgb,
+                   int width, int height, rthip_shard shard, uint64_t* d_counters, hipStream_t stream) {
+    const size_t lds = (size_t)(scene.max_bounces ? scene.max_bounces : 1) * kBlock * sizeof(uint32_t);
+    const uint32_t log2_group = cast.samples == 2 ? 2u : (cast.samples == 4 ? 4u : 6u);
+    const uint32_t tile = log2_group == 2 ? 8u : (log2_group == 4 ? 4u : 2u);  // pixels a workgroup covers, per side
+    const uint32_t blocks = div_up(width, tile) * div_up(height, tile);
+    if (d_counters)
+        cast_samples_kernel<true><<<blocks, kBlock, lds, stream>>>(scene, cast, seed, d_rgb, width, height, shard, log2_group, d_counters);
+    else
+        cast_samples_kernel<false><<<blocks, kBlock, lds, stream>>>(scene, cast, seed, d_rgb, width, height, shard, log2_group, nullptr);
     RT_HIP(ctx, hipGetLastError());
     return RTHIP_OK;
 }
@@ -618,7 +700,18 @@ int cast_launch(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_settings
     if (ctx->cast_mode == 2)
         return cast_wavefront_launch(ctx, scene, cast, seed, d_rgb, width, height, shard, d_counters, stream);
     Candidate choice = {ctx->cast_mode, ctx->refill_lanes, ctx->inst_batch};
-    if (ctx->cast_mode == 3) {
+    // One lane per sample needs samples^2 = 4, 16 or 64.  Measured against the other two kernels over frame sizes
+    // (tools/probe_samples.py): never slower than the pixel-per-thread kernel (its waves are shorter and the samples of
+    // a pixel walk the same part of the tree), 1.2x (Cornell 512^2) to 7x (256^2 frames of deep scenes) faster on
+    // small frames, and faster than the persistent kernel up to about 1024^2 pixels on deep scenes and 1920x1080 on
+    // shallow ones; beyond that the persistent kernel's lane refill wins where the probe says so.
+    const bool by_samples_possible = cast.samples == 2 || cast.samples == 4 || cast.samples == 8;
+    const bool deep = ctx->n_inst >= 64u || ctx->total_tris >= (1ull << 20);
+    const uint64_t pixel_waves = (uint64_t)div_up(width, 8) * div_up(height, 8);
+    if (choice.kernel == 4 && !by_samples_possible) choice.kernel = 1;
+    if (ctx->cast_mode == 3 && by_samples_possible && pixel_waves < (deep ? 20480ull : 40000ull)) {
+        choice.kernel = 4;
+    } else if (ctx->cast_mode == 3) {
         const uint64_t spp = (uint64_t)cast.samples * cast.samples;
         const uint64_t paths = (uint64_t)width * (uint64_t)height * spp;
         const uint64_t key[4] = {ctx->scene_generation, ((uint64_t)(uint32_t)width << 32) | (uint32_t)height, spp,
@@ -638,13 +731,15 @@ int cast_launch(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_settings
             // Small frames are not worth a probe.  Paths through a small scene are short and alike, and the
             // pixel-per-thread kernel has the least bookkeeping per ray; deep scenes (many instances, large
             // meshes) have long-tailed walks that pay for the persistent kernel's lane refill.
-            choice.kernel = (ctx->n_inst >= 64u || ctx->total_tris >= (1ull << 20)) ? 0 : 1;
+            choice.kernel = deep ? 0 : 1;
             choice.refill = ctx->refill_lanes;
             choice.inst_batch = 0;
         }
+        if (choice.kernel == 1 && by_samples_possible) choice.kernel = 4;
     }
     ctx->last_cast_kernel = (uint32_t)choice.kernel;
     ctx->last_cast_refill = choice.kernel == 0 ? choice.refill : 0u;
+    if (choice.kernel == 4) return launch_samples(ctx, scene, cast, seed, d_rgb, width, height, shard, d_counters, stream);
     if (choice.kernel == 1) return launch_static(ctx, scene, cast, seed, d_rgb, width, height, shard, d_counters, stream);
     return launch_persistent(ctx, scene, cast, seed, d_rgb, width, height, shard, choice.refill, choice.inst_batch, d_counters,
                              stream);

@@ -186,7 +186,7 @@ def occluded(tracer: RT_Tracer, origins, directions, tmax: float = 3.402823466e+
     return out
 
 
-CAST_KERNELS = {"persistent": 0, "static": 1, "wavefront": 2, "auto": 3}
+CAST_KERNELS = {"persistent": 0, "static": 1, "wavefront": 2, "auto": 3, "static-samples": 4}
 
 
 def hdr_encode(tracer: RT_Tracer, rgb, width: int, height: int) -> bytes:

@@ -294,6 +294,55 @@ def test_every_cast_kernel_gives_the_same_bits(oracle, gpu_tracer, kernel):
         T.set_persistent_params(gpu_tracer)
 
 
+@pytest.mark.parametrize("samples,wd,ht", [(2, 70, 50), (4, 37, 23), (8, 19, 13), (3, 33, 20)])
+def test_sample_per_lane_kernel_gives_the_same_bits(oracle, gpu_tracer, samples, wd, ht):
+    """RTHIP_KERNEL_STATIC_SAMPLES: the samples of a pixel in neighbouring lanes, added in sample order.  Frames
+    with ragged edges, both shard modes; samples = 3 has no lane layout and must run the pixel-per-thread kernel."""
+    import torch
+
+    T.set_cast_kernel(gpu_tracer, "static-samples")
+    try:
+        verts, indices = scenes.bunny_class_mesh(3)
+        for (w, cam, sky), bounces in ((scenes.cornell(), 8), (scenes.spheres(), 6),
+                                        (scenes.instanced_grid(6, seed=2, verts=verts, indices=indices), 3)):
+            build(gpu_tracer, w, bounces, sky)
+            sc = oracle.Scene(world.flatten_world(w), bounces, sky)
+            c = cam(wd, ht, samples)
+            img = np.zeros((ht, wd, 3), dtype=np.float32)
+            T.rt_tracer_cast(gpu_tracer, c, img, wd, ht, seed=5)
+            assert T.get_stats(gpu_tracer)["last_cast_kernel"] == (4 if samples in (2, 4, 8) else 1)
+            want, _ = sc.cast(c, 5, wd, ht, rng_mode=oracle.RNG_COUNTER, threads=8)
+            assert (bits(img) == bits(want)).all(), "frame differs"
+            for shard in ((1, 1, 2), (2, 2, 3), (2, 0, 5)):
+                buf = torch.full((ht, wd, 3), 7.0, dtype=torch.float32, device="cuda:0")
+                sh = np.zeros(1, dtype=abi.SHARD)
+                sh[0] = shard
+                rc = gpu_tracer.lib.rthip_cast_device(gpu_tracer.h, abi.ptr(c), 5, buf.data_ptr(), wd, ht, abi.ptr(sh),
+                                                      torch.cuda.current_stream().cuda_stream)
+                gpu_tracer.check(rc, "rthip_cast_device")
+                torch.cuda.synchronize()
+                want, _ = sc.cast(c, 5, wd, ht, rng_mode=oracle.RNG_COUNTER, shard=shard, threads=8)
+                assert (bits(buf.cpu().numpy()) == bits(want)).all(), f"shard {shard} differs"
+        # max_bounces 0: black frame
+        w, cam, sky = scenes.cornell()
+        build(gpu_tracer, w, 0, sky)
+        img = np.ones((16, 16, 3), dtype=np.float32)
+        T.rt_tracer_cast(gpu_tracer, cam(16, 16, 2), img, 16, 16, seed=1)
+        assert not img.any()
+        # AUTO takes the same kernel for a small frame of a shallow scene with 4 samples per pixel
+        T.set_cast_kernel(gpu_tracer, "auto")
+        build(gpu_tracer, w, 4, sky)
+        img = np.zeros((40, 40, 3), dtype=np.float32)
+        T.rt_tracer_cast(gpu_tracer, cam(40, 40, 2), img, 40, 40, seed=2)
+        assert T.get_stats(gpu_tracer)["last_cast_kernel"] == 4
+        T.set_cast_kernel(gpu_tracer, "static")
+        ref = np.zeros((40, 40, 3), dtype=np.float32)
+        T.rt_tracer_cast(gpu_tracer, cam(40, 40, 2), ref, 40, 40, seed=2)
+        assert (bits(img) == bits(ref)).all()
+    finally:
+        T.set_cast_kernel(gpu_tracer, "auto")
+
+
 def test_cornell_with_mesh_scene(oracle, gpu_tracer):
     """The multi-GPU configuration's scene (Cornell box + a metal PN mesh): trees, radiance and a tile shard."""
     verts, indices = scenes.bunny_class_mesh(3)
