@@ -306,6 +306,11 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1: nccl = RCCL over xGMI (the product path); gloo = rehearsal "
                          "of the N > 1 code on a box whose ranks share one GPU (framebuffers staged through the host)")
+    ap.add_argument("--streams", type=int, default=8,
+                    help="HIP streams the steps are dealt to in turn (each with its own framebuffer and accumulator, summed "
+                         "inside the timed region): a frame's first waves run while the previous frames' last waves drain.  "
+                         "1 = strictly one launch after the other.  Only with --combine end (progressive accumulation) and "
+                         "for ray streams; --combine every delivers frames in order on one stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--build-sizes", default="81920,1000000,10000000")
     args = ap.parse_args()
@@ -353,17 +358,22 @@ def main():
     combine = args.combine if args.combine != "auto" else ("end" if args.shard == "frames" else "every")
     if combine == "end" and args.shard != "frames":
         raise SystemExit("--combine end accumulates independent sample sets: it needs --shard frames")
-    accum = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda") if combine == "end" else None
+    is_rays = "rays" in wl
+    n_streams = max(1, args.streams) if (combine == "end" or is_rays) else 1
+    main_stream = torch.cuda.current_stream()
+    streams = [main_stream] if n_streams == 1 else [torch.cuda.Stream() for _ in range(n_streams)]
+    accums = [torch.zeros((H, W, 3), dtype=torch.float32, device="cuda") for _ in streams] if combine == "end" else None
+    accum = accums[0] if accums else None
+    fbs = [torch.zeros((H, W, 3), dtype=torch.float32, device="cuda") for _ in streams] if combine == "end" else None
     step_no = [0]
-    # two framebuffers: the RCCL reduce of frame k overlaps the render of frame k + 1
+    # --combine every: two framebuffers, the RCCL reduce of frame k overlaps the render of frame k + 1
     pipe = rdist.FramePipeline([torch.zeros((H, W, 3), dtype=torch.float32, device="cuda") for _ in range(2)],
                                args.shard, wl["samples"], world, dst=0)
-    stream = torch.cuda.current_stream()
     seed = 1 + (rank if args.shard == "frames" else 0)
     shard = rdist.shard_record(args.shard, rank, world)
 
     ray_o = ray_d = ray_hits = None
-    if "rays" in wl:  # a ray-stream workload: closest-hit queries for explicit rays instead of a frame
+    if is_rays:  # a ray-stream workload: closest-hit queries for explicit rays instead of a frame
         g = torch.Generator(device="cuda")
         g.manual_seed(2 + rank)
         lo, hi = wl.get("ray_box", ((0.0, 0.0, 0.0), (1.0, 1.0, 1.0)))
@@ -371,19 +381,23 @@ def main():
         ray_o = (lo + torch.rand((wl["rays"], 3), device="cuda", generator=g) * (hi - lo)).contiguous()
         v = torch.randn((wl["rays"], 3), device="cuda", generator=g)
         ray_d = (v / v.norm(dim=1, keepdim=True)).contiguous()
-        ray_hits = torch.zeros((wl["rays"], 4), dtype=torch.int32, device="cuda")
+        ray_hits = [torch.zeros((wl["rays"], 4), dtype=torch.int32, device="cuda") for _ in streams]
+    torch.cuda.synchronize()
 
     def step(events=None):
+        k = step_no[0] % n_streams
+        stream = streams[k]
         if ray_o is not None:
+            step_no[0] += 1
             if events:
                 events[0].record(stream)
-            rc = tr.lib.rthip_trace_rays_device(tr.h, ray_o.data_ptr(), ray_d.data_ptr(), wl["rays"], ray_hits.data_ptr(),
+            rc = tr.lib.rthip_trace_rays_device(tr.h, ray_o.data_ptr(), ray_d.data_ptr(), wl["rays"], ray_hits[k].data_ptr(),
                                                 stream.cuda_stream)
             if events:
                 events[1].record(stream)
             tr.check(rc, "rthip_trace_rays_device")
             return
-        fb = pipe.acquire()
+        fb = fbs[k] if combine == "end" else pipe.acquire()
         # progressive accumulation: every step of every rank renders its own sample set
         step_seed = seed if combine == "every" else 1 + step_no[0] * world + rank
         step_no[0] += 1
@@ -394,14 +408,19 @@ def main():
             events[1].record(stream)
         tr.check(rc, "rthip_cast_device")
         if combine == "end":
-            accum.add_(fb)
+            with torch.cuda.stream(stream):
+                accums[k].add_(fb)
         else:
             pipe.submit(fb)
 
     def finish_image(n_steps):
-        """--combine end: the one exchange of the image, inside the timed region."""
+        """--combine end: the streams' accumulators are added up and the image is exchanged once, inside the timed region."""
+        for s in streams[0 if n_streams > 1 else 1:]:
+            main_stream.wait_stream(s)
         if combine != "end" or ray_o is not None:
             return
+        for a in accums[1:]:
+            accum.add_(a)
         if world > 1:
             if dist.get_backend() == "gloo":  # rehearsal: gloo has no GPU reduce
                 host = accum.cpu()
@@ -427,8 +446,9 @@ def main():
         step()
     pipe.drain()
     finish_image(args.warmup + 1)
-    if accum is not None:
-        accum.zero_()
+    if accums is not None:
+        for a in accums:
+            a.zero_()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -475,7 +495,8 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": wl["label"], "rays_per_frame_per_gpu": int(rays), "sharding": "none" if world == 1 else {
+            "config": {"workload": wl["label"], "rays_per_frame_per_gpu": int(rays), "streams": n_streams,
+                       "sharding": "none" if world == 1 else {
                            "frames": "every rank renders the frame with its own sample set; " + (
                                "framebuffers summed onto rank 0 with RCCL every step" if combine == "every" else
                                "every step adds its sample set to the rank's accumulator, ONE RCCL sum onto rank 0 at the end "
@@ -488,7 +509,13 @@ def main():
                          "per_ray": {"nodes": round(st["nodes_tested"] / max(rays, 1), 2),
                                      "triangles": round(st["tris_tested"] / max(rays, 1), 3),
                                      "instances": round(st["inst_entered"] / max(rays, 1), 3)},
-                         "lane_utilisation": round(st["nodes_tested"] / max(64 * st["wave_steps"], 1), 4)},
+                         "lane_utilisation": round(st["nodes_tested"] / max(64 * st["wave_steps"], 1), 4),
+                         # with --streams > 1 launches overlap: kernel_ms is the mean duration of ONE launch while others
+                         # run beside it (what rocprofv3 reports per launch); the overlapped figures divide the bytes of all
+                         # launches by the timed region instead
+                         "concurrent_launches": n_streams,
+                         "achieved_overlapped": round(algo_bytes * args.steps / elapsed / 1e9, 2),
+                         "frac_overlapped": round(algo_bytes * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 5)},
             "scene_build_ms": {"blas": round(blas_ms, 4), "tlas": round(tlas_ms, 4), "tlas_rebuild_call": round(tlas_call_ms, 4),
                                "instances": int(flat.instances.size)},
         }

@@ -26,7 +26,12 @@
  *     the given stream; builds (rthip_blas_commit, rthip_tlas_build) wait for the
  *     GPU, so a cast enqueued after them on any stream sees the finished trees.
  *     The builder's workspace belongs to the context: two builds on different
- *     streams of one context must not overlap.
+ *     streams of one context must not overlap.  Casts and ray queries may: frames
+ *     enqueued on different streams run concurrently (one frame's first waves fill
+ *     the GPU while another's last waves drain; measured 1.1x to 2.8x the frames
+ *     per second of one stream), each into its own framebuffer, at most 64 of them
+ *     unfinished at a time, and not with RTHIP_KERNEL_WAVEFRONT or with counting
+ *     on, whose buffers belong to the context.
  */
 #ifndef RTHIP_H
 #define RTHIP_H

@@ -98,6 +98,9 @@ struct HostMesh {
     DevMesh dev{};
 };
 
+// launches of the persistent kernels that may be unfinished at one time (each owns a slot of work counters)
+constexpr uint32_t kWorkSlots = 64;
+
 struct rthip_ctx {
     int device = 0;
     std::string err;
@@ -126,7 +129,7 @@ struct rthip_ctx {
     bool tlas_built = false;
 
     DevBuf counters;  // uint64[4]
-    DevBuf work_ring;  // 16 x 1 KiB: eight 128-byte-spaced work counters per launch of the persistent cast kernel
+    DevBuf work_ring;  // kWorkSlots x 1 KiB: eight 128-byte-spaced work counters per launch of a persistent kernel
     uint32_t work_next = 0;
     int cast_mode = 3;           // 0: persistent kernel, 1: fixed pixel per thread, 2: wavefront, 3: 0 or 1 by scene size (RTHIP_CAST=...)
     uint32_t persistent_blocks = 256u * 5u;  // resident workgroups of the persistent kernel (CUs x 5)

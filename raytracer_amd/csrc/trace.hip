@@ -531,7 +531,7 @@ int trace_rays_launch(rthip_ctx* ctx, const DevScene& scene, const float* d_o, c
     if (n >= (1ull << 18) && n < (1ull << 32) * kRayGrab && resident) {
         uint32_t blocks = div_up(n, kBlock);
         if (blocks > ctx->persistent_blocks) blocks = ctx->persistent_blocks;
-        uint32_t* work = (uint32_t*)ctx->work_ring.p + (size_t)(ctx->work_next++ % 16u) * 256u;
+        uint32_t* work = (uint32_t*)ctx->work_ring.p + (size_t)(ctx->work_next++ % kWorkSlots) * 256u;
         RT_HIP(ctx, hipMemsetAsync(work, 0, 1024, stream));
         if (d_counters)
             trace_rays_persistent_kernel<true><<<blocks, kBlock, 0, stream>>>(scene, d_o, d_d, n, d_hits4, d_uv, d_normal,
@@ -611,9 +611,9 @@ int launch_persistent(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_se
     uint32_t blocks = div_up(total, kBlock);
     if (blocks > ctx->persistent_blocks) blocks = ctx->persistent_blocks;
     const size_t lds = (size_t)(scene.max_bounces ? scene.max_bounces : 1) * kBlock * sizeof(uint32_t);
-    // every launch gets its own zeroed set of 8 work counters (one 128-byte line each) out of a small
-    // ring, so that casts enqueued back to back (or on two streams) do not share them
-    uint32_t* work = (uint32_t*)ctx->work_ring.p + (size_t)(ctx->work_next++ % 16u) * 256u;
+    // every launch gets its own zeroed set of 8 work counters (one 128-byte line each) out of a ring of
+    // kWorkSlots, so that casts enqueued back to back or on several streams do not share them
+    uint32_t* work = (uint32_t*)ctx->work_ring.p + (size_t)(ctx->work_next++ % kWorkSlots) * 256u;
     RT_HIP(ctx, hipMemsetAsync(work, 0, 1024, stream));
     const bool defer = inst_batch != 0;
 #define RT_LAUNCH_CAST(COUNT, DEFER, CNT)                                                                              \

@@ -343,6 +343,41 @@ def test_sample_per_lane_kernel_gives_the_same_bits(oracle, gpu_tracer, samples,
         T.set_cast_kernel(gpu_tracer, "auto")
 
 
+@pytest.mark.parametrize("kernel", ["persistent", "static", "static-samples"])
+def test_casts_on_several_streams_overlap_without_changing_a_bit(gpu_tracer, kernel):
+    """Frames enqueued on different streams of one context run concurrently; each must come out as it does alone."""
+    import torch
+
+    verts, indices = scenes.bunny_class_mesh(3)
+    w, cam, sky = scenes.instanced_grid(8, seed=4, verts=verts, indices=indices)
+    build(gpu_tracer, w, 4, sky)
+    wd, ht = 320, 200
+    c = cam(wd, ht, 2)
+    T.set_cast_kernel(gpu_tracer, kernel)
+    try:
+        def cast(seed, buf, stream):
+            gpu_tracer.check(gpu_tracer.lib.rthip_cast_device(gpu_tracer.h, abi.ptr(c), seed, buf.data_ptr(), wd, ht, None,
+                                                              stream.cuda_stream), "rthip_cast_device")
+
+        n = 24
+        alone = []
+        for k in range(n):
+            buf = torch.zeros((ht, wd, 3), dtype=torch.float32, device="cuda:0")
+            cast(100 + k, buf, torch.cuda.current_stream())
+            torch.cuda.synchronize()
+            alone.append(buf)
+        streams = [torch.cuda.Stream() for _ in range(3)]
+        bufs = [torch.full((ht, wd, 3), -1.0, dtype=torch.float32, device="cuda:0") for _ in range(n)]
+        torch.cuda.synchronize()
+        for k in range(n):
+            cast(100 + k, bufs[k], streams[k % 3])
+        torch.cuda.synchronize()
+        for k in range(n):
+            assert torch.equal(bufs[k].view(torch.int32), alone[k].view(torch.int32)), f"frame {k}"
+    finally:
+        T.set_cast_kernel(gpu_tracer, "auto")
+
+
 def test_cornell_with_mesh_scene(oracle, gpu_tracer):
     """The multi-GPU configuration's scene (Cornell box + a metal PN mesh): trees, radiance and a tile shard."""
     verts, indices = scenes.bunny_class_mesh(3)

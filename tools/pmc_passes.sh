@@ -7,7 +7,7 @@ k=0
 for pass in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_ACTIVE_INST_VALU" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_THREAD_CYCLES_VALU SQ_INSTS_SMEM SQ_INSTS_VMEM_WR SQ_INST_CYCLES_VMEM SQ_INSTS_BRANCH" "GRBM_GUI_ACTIVE GRBM_COUNT"; do
   k=$((k+1))
   out=$ROOT/gpurun_out/pmc_${W}_pass$k
-  env "$@" timeout -s KILL 200 rocprofv3 --pmc $pass --output-format csv -d $out -- python3 $ROOT/bench.py --workload $W --steps 2 --warmup 0 --no-cpu-baseline --build-sizes "" > $out.log 2>&1 || { tail -3 $out.log; exit 1; }
+  env "$@" timeout -s KILL 200 rocprofv3 --pmc $pass --output-format csv -d $out -- python3 $ROOT/bench.py --workload $W --streams 1 --steps 2 --warmup 0 --no-cpu-baseline --build-sizes "" > $out.log 2>&1 || { tail -3 $out.log; exit 1; }
 done
 python3 - <<PY
 import csv,glob,collections

@@ -10,7 +10,7 @@ for W in ${@:-bunny instanced soup cornell soup-rays}; do
   [ "$W" = "bunny" ] && SIZES="10000000"
   for C in FETCH_SIZE WRITE_SIZE; do
     timeout -s KILL 240 rocprofv3 --pmc $C --output-format csv -d $OUT/${W}_${C} -- \
-      python3 $ROOT/bench.py --workload $W --steps 2 --warmup 0 --no-cpu-baseline --build-sizes "$SIZES" \
+      python3 $ROOT/bench.py --workload $W --streams 1 --steps 2 --warmup 0 --no-cpu-baseline --build-sizes "$SIZES" \
       > $OUT/${W}_${C}.log 2>&1 || { echo "pass $W $C failed"; tail -5 $OUT/${W}_${C}.log; exit 1; }
     echo "pass $W $C done"
   done
