@@ -298,6 +298,40 @@ int rthip_set_persistent_params(rthip_ctx* ctx, uint32_t refill, uint32_t inst_b
  * *out_count receives the node count; out_nodes (may be NULL) must hold that many. */
 int rthip_get_tree(rthip_ctx* ctx, int which, rthip_node* out_nodes, uint64_t* out_count);
 
+/* ---- mesh files ---------------------------------------------------------- */
+
+/* ms_load_obj, src/mesh/mesh.c:73-219 (the demos load their meshes with it, src/demos/bunny/main.c:44): a Wavefront
+ * OBJ file as an indexed triangle list whose vertices are the distinct (position, normal, uv) index triples of the
+ * faces, numbered in the order of first appearance (mesh.c:19-37, 183-190), each attribute in a 16-byte slot
+ * (src/geo/geo.c:2-18).  attrs: GEO_VertexAttributes bits P = 1, N = 2, T = 4 (0 = all three, mesh.c:85-87); the face
+ * syntax must be the one the reference reads for them: "f a b c" (P), "a/t" (PT), "a//n" (PN), "a/t/n" (PNT); of a
+ * face with more corners the first three are used (mesh.c:145), and the last line of a file that ends in a newline
+ * counts twice, as it does in the reference's read loop (`while (!feof) { fgets ... }`, mesh.c:108-109, 140-141: a
+ * trailing face is a duplicated triangle).  Lines of more than 255 characters are not supported (the reference
+ * splits them).  The text is parsed on the host's cores (at most 16
+ * threads), the deduplication runs on the GPU; the mesh stays in device memory.
+ * Differences from the reference: a face that does not match the syntax is an error (RTHIP_E_INVALID with the line
+ * number; the reference prints a message and goes on with indices left over from the previous face), and so is an
+ * index beyond the file's records (undefined behaviour there); slots and padding floats no attribute writes are 0. */
+typedef struct rthip_obj_info {
+    uint32_t vertex_count;  /* MS_Mesh.vertices_count */
+    uint32_t index_count;   /* MS_Mesh.indices_count  */
+    uint32_t attrs;
+    uint32_t vertex_bytes;  /* 16 per attribute: geo_vertex_size */
+    float parse_ms;         /* host: map, count, parse                          */
+    float dedup_ms;         /* device: sort, scans, gather                      */
+    float total_ms;         /* the whole call, uploads included                 */
+    uint32_t host_threads;
+} rthip_obj_info;
+int rthip_obj_load(rthip_ctx* ctx, const char* path, uint32_t attrs, rthip_obj_info* out_info);
+/* Copies the loaded mesh to the host: MS_Mesh.vertices (vertex_count x vertex_bytes) and MS_Mesh.indices; either may
+ * be NULL. */
+int rthip_obj_get(rthip_ctx* ctx, float* out_vertices, uint32_t* out_indices);
+/* rthip_blas_add_mesh for the loaded mesh, device to device (between rthip_blas_begin and rthip_blas_commit): what
+ * rt_world_add_mesh + rt_tracer_build_blas do with the loader's result (src/demos/bunny/main.c:44-52) without the
+ * vertices visiting the host. */
+int rthip_blas_add_loaded_obj(rthip_ctx* ctx, uint32_t blas_id);
+
 /* ---- image output ------------------------------------------------------- */
 
 /* The reference writes its image with stbi_write_hdr(path, width, height, 3, rgb)

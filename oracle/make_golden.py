@@ -228,6 +228,32 @@ def write_hdr():
     np.savez_compressed(os.path.join(OUT, "hdr.npz"), **out)
 
 
+def write_obj():
+    """OBJ texts and what the reference's ms_load_obj makes of them (the big file: digests only)."""
+    import tempfile
+
+    out = {}
+    for name, (text, attrs) in scenes.obj_test_files().items():
+        with tempfile.NamedTemporaryFile("w", suffix=".obj", delete=False, newline="") as f:
+            f.write(text)
+        verts, idx = O.ref_load_obj(f.name, attrs, 200_000, 400_000)
+        os.unlink(f.name)
+        slots = verts.shape[1] // 4
+        written = np.concatenate([verts[:, 4 * k: 4 * k + (2 if (k == slots - 1 and (attrs or 7) & 4) else 3)] for k in range(slots)], axis=1)
+        out[f"{name}_attrs"] = np.uint32(attrs)
+        out[f"{name}_sha"] = sha(np.frombuffer(text.encode(), dtype=np.uint8))
+        if len(text) < 200_000:
+            out[f"{name}_text"] = np.frombuffer(text.encode(), dtype=np.uint8)
+            out[f"{name}_ref_vertices"] = written
+            out[f"{name}_ref_indices"] = idx
+        else:
+            out[f"{name}_ref_vertices_sha"] = sha(np.ascontiguousarray(written))
+            out[f"{name}_ref_indices_sha"] = sha(idx)
+            out[f"{name}_ref_counts"] = np.array([verts.shape[0], idx.size], dtype=np.uint32)
+        print("obj", name, "attrs", attrs, "vertices", verts.shape, "indices", idx.size, "text bytes", len(text))
+    np.savez_compressed(os.path.join(OUT, "obj.npz"), **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     assert O.have_ref("core"), "build oracle/_ref first: make -C oracle ref"
@@ -236,6 +262,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "converged":
         write_converged()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "obj":
+        write_obj()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "hdr":
         write_hdr()
@@ -250,3 +279,4 @@ if __name__ == "__main__":
     write_edges()
     write_converged()
     write_hdr()
+    write_obj()

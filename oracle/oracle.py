@@ -93,10 +93,42 @@ def lib() -> C.CDLL:
         L.ora_scene_cast.argtypes = [_P, _P, C.c_uint64, C.c_int, _P, C.c_int, C.c_int, _P, C.c_int, _P]
         L.ora_hdr_encode.restype = C.c_uint64
         L.ora_hdr_encode.argtypes = [_P, C.c_int, C.c_int, _P, C.c_uint64]
+        L.ora_load_obj.restype = C.c_int
+        L.ora_load_obj.argtypes = [C.c_char_p, C.c_uint32, _P, _P, _P, _P]
         L.ora_rgbe.restype = None
         L.ora_rgbe.argtypes = [_P, _P]
         _oracle = L
     return _oracle
+
+
+# ---- OBJ files -------------------------------------------------------------------
+
+
+def load_obj(path: str, attrs: int):
+    """ms_load_obj by the CPU restatement -> (vertices float32 [n, 4 * attributes], indices uint32)."""
+    nv, ni = C.c_uint32(0), C.c_uint32(0)
+    rc = lib().ora_load_obj(os.fsencode(path), attrs, None, C.addressof(nv), None, C.addressof(ni))
+    if rc:
+        raise ValueError(f"ora_load_obj({path}) = {rc}")
+    slots = bin(attrs or 7).count("1")
+    verts = np.zeros((nv.value, 4 * slots), dtype=np.float32)
+    idx = np.zeros(ni.value, dtype=np.uint32)
+    rc = lib().ora_load_obj(os.fsencode(path), attrs, verts.ctypes.data, C.addressof(nv), idx.ctypes.data, C.addressof(ni))
+    assert rc == 0
+    return verts, idx
+
+
+def ref_load_obj(path: str, attrs: int, max_vertices: int, max_indices: int):
+    """The reference's own ms_load_obj (oracle/_ref/libref_core.so)."""
+    slots = bin(attrs or 7).count("1")
+    verts = np.zeros((max_vertices, 4 * slots), dtype=np.float32)
+    idx = np.zeros(max_indices, dtype=np.uint32)
+    nv, ni = C.c_uint32(0), C.c_uint32(0)
+    rc = ref("core").ref_load_obj(os.fsencode(path), attrs, verts.ctypes.data, verts.size, C.addressof(nv), idx.ctypes.data,
+                                  idx.size, C.addressof(ni))
+    if rc:
+        raise ValueError(f"ref_load_obj({path}) = {rc}")
+    return verts[: nv.value].copy(), idx[: ni.value].copy()
 
 
 # ---- .hdr output -----------------------------------------------------------------

@@ -1214,3 +1214,147 @@ uint64_t ora_hdr_encode(const float* rgb, int width, int height, uint8_t* out, u
     free(planes);
     return s.len;
 }
+
+/* ---- OBJ loading (ms_load_obj, src/mesh/mesh.c:73-219) ----------------------------------------------------------- */
+
+typedef struct {
+    uint32_t p, n, t, index;
+    int used;
+} obj_slot;
+
+static int obj_scan_uint(const char** s, uint32_t* out) { /* " %u" */
+    const char* q = *s;
+    while (*q == ' ' || *q == '\t' || *q == '\r' || *q == '\v' || *q == '\f') q++;
+    if (!((*q >= '0' && *q <= '9') || *q == '+' || *q == '-')) return 0;
+    char* after = NULL;
+    unsigned long v = strtoul(q, &after, 10);
+    if (after == q) return 0;
+    *out = (uint32_t)v;
+    *s = after;
+    return 1;
+}
+
+static void obj_scan_floats(const char* s, float* out, int n) { /* "%f %f %f": stops at the first failure */
+    for (int k = 0; k < n; k++) {
+        char* after = NULL;
+        float v = strtof(s, &after);
+        if (after == s) return;
+        out[k] = v;
+        s = after;
+    }
+}
+
+int ora_load_obj(const char* path, uint32_t attrs, float* out_vertices, uint32_t* out_vertex_count,
+                 uint32_t* out_indices, uint32_t* out_index_count) {
+    if (attrs == 0) attrs = 7; /* mesh.c:85-87 */
+    FILE* f = fopen(path, "rb");
+    if (!f) return 2;
+    fseek(f, 0, SEEK_END);
+    long size = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    char* text = (char*)malloc((size_t)size + 1);
+    if (fread(text, 1, (size_t)size, f) != (size_t)size) {
+        fclose(f);
+        free(text);
+        return 2;
+    }
+    fclose(f);
+    text[size] = 0;
+    /* The reference reads with `while (!feof) { fgets; ... }` (mesh.c:108-109, 140-141; os_platform_linux+wasm.c:27-41):
+     * after the last line of a file that ends in a newline, end-of-file has not been seen yet, the next fgets fails and
+     * leaves the buffer as it was, and the loop body runs once more on the last line.  So such a file's last line counts
+     * twice, in both passes (a trailing face is a duplicated triangle). */
+    const int repeat_last = size > 0 && text[size - 1] == '\n';
+    /* first pass: counts (mesh.c:107-120) */
+    uint64_t nv = 0, nvn = 0, nvt = 0, nf = 0;
+    char* last_line = text;
+    for (char* s = text; s < text + size;) {
+        char* nl = memchr(s, '\n', (size_t)(text + size - s));
+        last_line = s;
+        for (int twice = 0; twice < ((nl == text + size - 1 && repeat_last) ? 2 : 1); twice++) {
+            if (strncmp(s, "v ", 2) == 0) nv++;
+            else if (strncmp(s, "vn ", 3) == 0) nvn++;
+            else if (strncmp(s, "vt ", 3) == 0) nvt++;
+            else if (strncmp(s, "f ", 2) == 0) nf++;
+        }
+        s = nl ? nl + 1 : text + size;
+    }
+    float* pos = (float*)calloc(3 * nv + 1, 4);
+    float* nrm = (float*)calloc(3 * nvn + 1, 4);
+    float* uv = (float*)calloc(2 * nvt + 1, 4);
+    uint32_t* corners = (uint32_t*)calloc(9 * nf + 1, 4); /* p, n, t per corner */
+    uint64_t iv = 0, ivn = 0, ivt = 0, ic = 0;
+    int rc = 0;
+    /* second pass (mesh.c:140-212) */
+    for (char* s = text; s < text + size && rc == 0;) {
+        char* nl = memchr(s, '\n', (size_t)(text + size - s));
+        if (nl) *nl = 0;
+        for (int twice = 0; twice < ((s == last_line && repeat_last) ? 2 : 1) && rc == 0; twice++) {
+            if (strncmp(s, "v ", 2) == 0) obj_scan_floats(s + 1, pos + 3 * iv++, 3);
+            else if (strncmp(s, "vn ", 3) == 0) obj_scan_floats(s + 2, nrm + 3 * ivn++, 3);
+            else if (strncmp(s, "vt ", 3) == 0) obj_scan_floats(s + 2, uv + 2 * ivt++, 2);
+            else if (strncmp(s, "f ", 2) == 0) {
+                const char* q = s + 1;
+                for (int k = 0; k < 3 && rc == 0; k++) {
+                    uint32_t p = 0, n = 0, t = 0;
+                    int ok = obj_scan_uint(&q, &p);
+                    if (ok && attrs == 5) ok = *q == '/' && (q++, obj_scan_uint(&q, &t));
+                    if (ok && attrs == 3) ok = q[0] == '/' && q[1] == '/' && (q += 2, obj_scan_uint(&q, &n));
+                    if (ok && attrs == 7) ok = *q == '/' && (q++, obj_scan_uint(&q, &t)) && *q == '/' && (q++, obj_scan_uint(&q, &n));
+                    if (!ok || p > nv || n > nvn || t > nvt) rc = 3;
+                    corners[3 * ic] = p;
+                    corners[3 * ic + 1] = n;
+                    corners[3 * ic + 2] = t;
+                    ic++;
+                }
+            }
+        }
+        s = nl ? nl + 1 : text + size;
+    }
+    free(text);
+    /* vertex = distinct (p, n, t), numbered by first appearance (mesh.c:19-37, 183-190) */
+    uint64_t cap = 16;
+    while (cap < 2 * (ic + 1)) cap <<= 1;
+    obj_slot* table = (obj_slot*)calloc(cap, sizeof(obj_slot));
+    uint32_t n_vertices = 0;
+    const uint32_t slots = (attrs & 1u) + ((attrs >> 1) & 1u) + ((attrs >> 2) & 1u);
+    for (uint64_t c = 0; c < ic && rc == 0; c++) {
+        const uint32_t p = corners[3 * c], n = corners[3 * c + 1], t = corners[3 * c + 2];
+        uint64_t h = (p * 0x9E3779B97F4A7C15ull) ^ (n * 0xC2B2AE3D27D4EB4Full) ^ (t * 0x165667B19E3779F9ull);
+        h ^= h >> 29;
+        uint64_t at = h & (cap - 1);
+        while (table[at].used && !(table[at].p == p && table[at].n == n && table[at].t == t)) at = (at + 1) & (cap - 1);
+        if (!table[at].used) {
+            table[at].used = 1;
+            table[at].p = p, table[at].n = n, table[at].t = t;
+            table[at].index = n_vertices;
+            if (out_vertices) { /* mesh.c:39-70: one 16-byte slot per attribute, 1-based indices, 0 = absent */
+                float* v = out_vertices + (size_t)n_vertices * slots * 4;
+                uint32_t slot = 0;
+                memset(v, 0, (size_t)slots * 16);
+                if (attrs & 1u) {
+                    if (p) memcpy(v + 4 * slot, pos + 3 * (size_t)(p - 1), 12);
+                    slot++;
+                }
+                if (attrs & 2u) {
+                    if (n) memcpy(v + 4 * slot, nrm + 3 * (size_t)(n - 1), 12);
+                    slot++;
+                }
+                if (attrs & 4u) {
+                    if (t) memcpy(v + 4 * slot, uv + 2 * (size_t)(t - 1), 8);
+                    slot++;
+                }
+            }
+            n_vertices++;
+        }
+        if (out_indices) out_indices[c] = table[at].index;
+    }
+    *out_vertex_count = n_vertices;
+    *out_index_count = (uint32_t)ic;
+    free(table);
+    free(corners);
+    free(pos);
+    free(nrm);
+    free(uv);
+    return rc;
+}

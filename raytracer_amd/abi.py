@@ -45,6 +45,10 @@ STATS = np.dtype(
      ("last_encode_ms", "<f4"), ("reserved", "<u4")],
     align=False,
 )
+# rthip_obj_info
+OBJ_INFO = np.dtype([("vertex_count", "<u4"), ("index_count", "<u4"), ("attrs", "<u4"), ("vertex_bytes", "<u4"),
+                     ("parse_ms", "<f4"), ("dedup_ms", "<f4"), ("total_ms", "<f4"), ("host_threads", "<u4")], align=False)
+assert OBJ_INFO.itemsize == 32
 assert MATERIAL.itemsize == 40 and INSTANCE.itemsize == 68 and CAST.itemsize == 84
 assert NODE.itemsize == 32 and SHARD.itemsize == 12 and STATS.itemsize == 64
 
@@ -79,6 +83,9 @@ SYMBOLS = [
     ("rthip_set_cast_kernel", C.c_int, [_P, C.c_int]),
     ("rthip_set_persistent_params", C.c_int, [_P, C.c_uint32, C.c_uint32]),
     ("rthip_get_tree", C.c_int, [_P, C.c_int, _P, _P]),
+    ("rthip_obj_load", C.c_int, [_P, C.c_char_p, C.c_uint32, _P]),
+    ("rthip_obj_get", C.c_int, [_P, _P, _P]),
+    ("rthip_blas_add_loaded_obj", C.c_int, [_P, C.c_uint32]),
     ("rthip_hdr_bound", C.c_uint64, [C.c_int, C.c_int]),
     ("rthip_hdr_encode", C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_uint64, _P]),
     ("rthip_hdr_encode_device", C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_uint64, _P, _P]),

@@ -993,6 +993,32 @@ size_t scan_tmp_elems(uint64_t n) {
 
 }  // namespace
 
+int radix_sort_workspace_device(rthip_ctx* ctx, uint64_t n, int n_bytes, hipStream_t s, int* cur_io) {
+    LbvhWorkspace& w = ctx->ws;
+    const uint32_t tiles = div_up(n, kSortTile);
+    RT_TRY(rthip_reserve(ctx, w.block_hist, (256ull * tiles + 256) * 4));
+    uint64_t* keys[2] = {(uint64_t*)w.keys[0].p, (uint64_t*)w.keys[1].p};
+    uint32_t* vals[2] = {(uint32_t*)w.vals[0].p, (uint32_t*)w.vals[1].p};
+    int cur = *cur_io;
+    for (int pass = 0; pass < n_bytes; pass++) {
+        const int shift = pass * 8;
+        radix_hist_kernel<<<tiles, kSortBlock, 0, s>>>(keys[cur], n, shift, (uint32_t*)w.block_hist.p, tiles);
+        RT_HIP(ctx, hipGetLastError());
+        radix_offsets_kernel<<<256, kBlock, 0, s>>>((uint32_t*)w.block_hist.p, tiles);
+        radix_scatter_kernel<<<tiles, kSortBlock, 0, s>>>(keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, shift,
+                                                      (const uint32_t*)w.block_hist.p, tiles);
+        RT_HIP(ctx, hipGetLastError());
+        cur ^= 1;
+    }
+    *cur_io = cur;
+    return RTHIP_OK;
+}
+
+int scan_inclusive_u32_device(rthip_ctx* ctx, uint32_t* d, uint64_t n, hipStream_t s) {
+    RT_TRY(rthip_reserve(ctx, ctx->ws.scan_aux, scan_tmp_elems(n) * 4));
+    return scan_u32<true>(ctx, d, n, (uint32_t*)ctx->ws.scan_aux.p, s);
+}
+
 int deinterleave_device(rthip_ctx* ctx, const void* d_interleaved, uint32_t vertex_count, uint32_t stride,
                         uint32_t off, float* x, float* y, float* z, hipStream_t stream) {
     if (vertex_count == 0) return RTHIP_OK;
@@ -1084,18 +1110,7 @@ int lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, float4* 
         RT_HIP(ctx, hipMemcpyAsync(d_codes_unsorted, keys[0], n * 8, hipMemcpyDeviceToDevice, s));
 
     int cur = 0;
-    if (n > 1) {
-        for (int pass = 0; pass < 8; pass++) {
-            int shift = pass * 8;
-            radix_hist_kernel<<<tiles, kSortBlock, 0, s>>>(keys[cur], n, shift, (uint32_t*)w.block_hist.p, tiles);
-            RT_HIP(ctx, hipGetLastError());
-            radix_offsets_kernel<<<256, kBlock, 0, s>>>((uint32_t*)w.block_hist.p, tiles);
-            radix_scatter_kernel<<<tiles, kSortBlock, 0, s>>>(keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, shift,
-                                                          (const uint32_t*)w.block_hist.p, tiles);
-            RT_HIP(ctx, hipGetLastError());
-            cur ^= 1;
-        }
-    }
+    if (n > 1) RT_TRY(radix_sort_workspace_device(ctx, n, 8, s, &cur));
     if (d_keys_sorted) RT_HIP(ctx, hipMemcpyAsync(d_keys_sorted, keys[cur], n * 8, hipMemcpyDeviceToDevice, s));
     if (d_ids_sorted) RT_HIP(ctx, hipMemcpyAsync(d_ids_sorted, vals[cur], n * 4, hipMemcpyDeviceToDevice, s));
 

@@ -139,11 +139,14 @@ void rthip_destroy(rthip_ctx* ctx) {
     (void)hipDeviceSynchronize();
     for (auto& m : ctx->meshes) release_mesh(m);
     LbvhWorkspace& w = ctx->ws;
-    DevBuf* all[] = {&w.aabb, &w.keys[0], &w.keys[1], &w.vals[0], &w.vals[1], &w.block_hist, &w.scan_tmp, &w.prio,
+    DevBuf* all[] = {&w.aabb, &w.keys[0], &w.keys[1], &w.vals[0], &w.vals[1], &w.block_hist, &w.scan_tmp, &w.scan_aux, &w.prio,
                      &w.child, &w.flags, &w.starters, &w.node_info, &w.node_dl, &w.leaf_sorted, &w.cnt_l, &w.bounds, &ctx->blas_nodes, &ctx->tri_v, &ctx->tri_n,
                      &ctx->tlas_nodes, &ctx->inst, &ctx->mats, &ctx->inst_aabb, &ctx->counters, &ctx->work_ring, &ctx->scratch_a,
                      &ctx->scratch_b, &ctx->scratch_c, &ctx->scratch_d, &ctx->scratch_e, &ctx->frame, &ctx->hdr_stage,
-                     &ctx->hdr_lengths, &ctx->hdr_offsets, &ctx->hdr_out, &ctx->hdr_size};
+                     &ctx->hdr_lengths, &ctx->hdr_offsets, &ctx->hdr_out, &ctx->hdr_size, &ctx->obj.cp, &ctx->obj.cn, &ctx->obj.ct,
+                     &ctx->obj.pos, &ctx->obj.nrm, &ctx->obj.uv, &ctx->obj.head, &ctx->obj.first, &ctx->obj.run_first,
+                     &ctx->obj.indices, &ctx->obj.px, &ctx->obj.py, &ctx->obj.pz, &ctx->obj.nx, &ctx->obj.ny, &ctx->obj.nz,
+                     &ctx->obj.interleaved};
     for (DevBuf* b : all) rthip_release(*b);
     for (DevBuf& b : ctx->wf) rthip_release(b);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -250,6 +253,50 @@ int rthip_blas_add_mesh(rthip_ctx* ctx, uint32_t blas_id, const void* verts, uin
                                    (float*)m.nx.p, (float*)m.ny.p, (float*)m.nz.p, ctx->stream));
     }
     // the caller's memory must not be referenced after this call returns
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    m.present = true;
+    return RTHIP_OK;
+}
+
+// ---- mesh files -----------------------------------------------------------------------
+
+int rthip_obj_load(rthip_ctx* ctx, const char* path, uint32_t attrs, rthip_obj_info* out_info) {
+    if (!ctx) return RTHIP_E_INVALID;
+    if (!path) return rthip_fail(ctx, RTHIP_E_INVALID, "path is NULL");
+    return obj_load(ctx, path, attrs, out_info);
+}
+
+int rthip_obj_get(rthip_ctx* ctx, float* out_vertices, uint32_t* out_indices) {
+    if (!ctx) return RTHIP_E_INVALID;
+    return obj_read_back(ctx, out_vertices, out_indices);
+}
+
+int rthip_blas_add_loaded_obj(rthip_ctx* ctx, uint32_t blas_id) {
+    if (!ctx) return RTHIP_E_INVALID;
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    const ObjState& o = ctx->obj;
+    if (!o.loaded) return rthip_fail(ctx, RTHIP_E_INVALID, "no OBJ file has been loaded");
+    if (blas_id >= ctx->meshes.size()) return rthip_fail(ctx, RTHIP_E_INVALID, "blas_id %u out of range (%zu meshes)", blas_id, ctx->meshes.size());
+    if (ctx->blas_committed) return rthip_fail(ctx, RTHIP_E_INVALID, "rthip_blas_add_loaded_obj after rthip_blas_commit");
+    if (o.index_count < 3 || o.vertex_count == 0) return rthip_fail(ctx, RTHIP_E_INVALID, "the loaded file has no triangles");
+    HostMesh& m = ctx->meshes[blas_id];
+    release_mesh(m);
+    const bool normals = (o.attrs & 2u) != 0;
+    m.vertex_count = o.vertex_count;
+    m.stride = 16u * ((o.attrs & 1u) + ((o.attrs >> 1) & 1u) + ((o.attrs >> 2) & 1u));
+    m.pos_off = 0;
+    m.nrm_off = normals ? 16 : -1;
+    m.n_tris = o.index_count / 3;
+    m.index_count = m.n_tris * 3;
+    const size_t fbytes = (size_t)o.vertex_count * 4;
+    RT_TRY(rthip_reserve(ctx, m.indices, (size_t)m.index_count * 4));
+    RT_HIP(ctx, hipMemcpyAsync(m.indices.p, o.indices.p, (size_t)m.index_count * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    DevBuf* dst[6] = {&m.px, &m.py, &m.pz, &m.nx, &m.ny, &m.nz};
+    const DevBuf* src[6] = {&o.px, &o.py, &o.pz, &o.nx, &o.ny, &o.nz};
+    for (int k = 0; k < (normals ? 6 : 3); k++) {
+        RT_TRY(rthip_reserve(ctx, *dst[k], fbytes));
+        RT_HIP(ctx, hipMemcpyAsync(dst[k]->p, src[k]->p, fbytes, hipMemcpyDeviceToDevice, ctx->stream));
+    }
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     m.present = true;
     return RTHIP_OK;

@@ -29,6 +29,7 @@ struct LbvhWorkspace {
     DevBuf vals[2];     // uint32[n]   0-based primitive index, ping-pong
     DevBuf block_hist;  // uint32[256 * tiles] per-tile digit counts, digit-major
     DevBuf scan_tmp;    // uint32[...] block sums of the device-wide scans
+    DevBuf scan_aux;    // the same for scan_inclusive_u32_device
     DevBuf prio;        // uint8[n-1]  split priority of every gap
     DevBuf child;       // ChildInfo[2(n-1)]
     DevBuf flags;       // uint32[n-1] arrival counters
@@ -98,6 +99,18 @@ struct HostMesh {
     DevMesh dev{};
 };
 
+// The mesh of the last rthip_obj_load, in device memory (obj_load.hip)
+struct ObjState {
+    bool loaded = false;
+    uint32_t attrs = 0, vertex_count = 0, index_count = 0;
+    DevBuf cp, cn, ct;          // uint32[corners]: 1-based position / normal / uv index of every face corner
+    DevBuf pos, nrm, uv;        // the file's `v`, `vn`, `vt` records
+    DevBuf head, first, run_first;  // deduplication scratch
+    DevBuf indices;             // uint32[corners]
+    DevBuf px, py, pz, nx, ny, nz;  // SoA vertices
+    DevBuf interleaved;         // the same in the reference's layout, one 16-byte slot per attribute
+};
+
 // launches of the persistent kernels that may be unfinished at one time (each owns a slot of work counters)
 constexpr uint32_t kWorkSlots = 64;
 
@@ -138,6 +151,7 @@ struct rthip_ctx {
     uint32_t inst_batch = 0;     // persistent kernel chosen by name: 0 = enter instances at once, k = park and enter k lanes at a time (RTHIP_INST_BATCH)
     uint32_t refill_lanes = 16;  // lanes with other work that end a traversal phase (RTHIP_REFILL overrides)
     DevBuf scratch_a, scratch_b, scratch_c, scratch_d, scratch_e;  // staging for host <-> device taps
+    ObjState obj;
     DevBuf frame;                // float[3 w h]: the image of the last rthip_cast, kept for rthip_hdr_encode(rgb = NULL)
     int frame_w = 0, frame_h = 0;
     DevBuf hdr_stage, hdr_lengths, hdr_offsets, hdr_out, hdr_size;  // .hdr encoder: coded components, their lengths and file offsets
@@ -184,6 +198,12 @@ void rthip_release(DevBuf& b);
 int lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, float4* d_nodes, hipStream_t stream,
                       uint64_t* d_codes_unsorted, uint64_t* d_keys_sorted, uint32_t* d_ids_sorted);
 
+// Stable LSD radix sort of the n (uint64 key, uint32 value) pairs in ws.keys[*cur] / ws.vals[*cur] (the caller has
+// reserved both ping-pong pairs) by the key's low n_bytes bytes; *cur names the pair that holds the result.
+int radix_sort_workspace_device(rthip_ctx* ctx, uint64_t n, int n_bytes, hipStream_t stream, int* cur);
+// In-place inclusive prefix sum of n uint32.
+int scan_inclusive_u32_device(rthip_ctx* ctx, uint32_t* d, uint64_t n, hipStream_t stream);
+
 // Triangle boxes (+ gathered per-triangle vertex / normal records) from SoA vertex data.
 int mesh_prepare_device(rthip_ctx* ctx, const float* px, const float* py, const float* pz, const float* nx,
                         const float* ny, const float* nz, const uint32_t* indices, uint64_t n_tris,
@@ -212,3 +232,7 @@ int cast_launch(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_settings
 uint64_t hdr_bound(int width, int height);
 int hdr_encode_device(rthip_ctx* ctx, const float* d_rgb, int width, int height, uint8_t* d_out, uint64_t capacity,
                       uint64_t* d_size, hipStream_t stream);
+
+// ---- OBJ loading (obj_load.hip) ------------------------------------------------------
+int obj_load(rthip_ctx* ctx, const char* path, uint32_t attrs, rthip_obj_info* info);
+int obj_read_back(rthip_ctx* ctx, float* out_vertices, uint32_t* out_indices);

@@ -553,3 +553,44 @@ def hdr_test_images(seed: int = 7):
                    np.inf, -np.inf, np.nan, 65504.0, 0.99999994, 2.0 ** -100], np.float32)
     out["special"] = np.stack(np.meshgrid(sp, sp, sp, indexing="ij"), -1).reshape(20, 400, 3).astype(np.float32)
     return out
+
+
+def obj_test_files(seed: int = 3):
+    """OBJ texts for the loader tests -> {name: (text, attrs)}: the four face syntaxes the reference reads
+    (src/mesh/mesh.c:151-172), shared and repeated index triples, a quad (its first three corners count), comments,
+    blank and foreign lines, CRLF line ends, an indented record (not a record for the reference), exponent notation, a
+    position with a missing coordinate; and one file of more than a megabyte, which the loader splits over threads."""
+    rng = np.random.default_rng(seed)
+    out = {}
+    verts, idx = bunny_class_mesh(2)
+    lines = ["# stand-in mesh", "o mesh"]
+    lines += ["v %.9g %.9g %.9g" % (r[0], r[1], r[2]) for r in verts]
+    lines += ["vn %.9g %.9g %.9g" % (r[4], r[5], r[6]) for r in verts]
+    lines += ["f %d//%d %d//%d %d//%d" % (a, a, b, b, c, c) for a, b, c in idx.reshape(-1, 3) + 1]
+    out["pn_mesh"] = ("\n".join(lines) + "\n", 3)
+    cube_v = [(x, y, z) for x in (0, 1) for y in (0, 1) for z in (0, 1)]
+    cube_n = [(1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1)]
+    cube_t = [(0, 0), (1, 0), (1, 1), (0, 1)]
+    quads = [((4, 5, 7, 6), 0), ((0, 2, 3, 1), 1), ((2, 6, 7, 3), 2), ((0, 1, 5, 4), 3), ((1, 3, 7, 5), 4), ((0, 4, 6, 2), 5)]
+    lines = ["mtllib none.mtl", "g cube", ""]
+    lines += ["v %g %g %g" % v for v in cube_v] + ["vt %g %g" % t for t in cube_t] + ["vn %g %g %g" % n for n in cube_n]
+    lines += ["usemtl m", "s off"]
+    for q, n in quads:
+        lines.append("f %d/1/%d %d/2/%d %d/3/%d" % (q[0] + 1, n + 1, q[1] + 1, n + 1, q[2] + 1, n + 1))
+        lines.append("f %d/1/%d %d/3/%d %d/4/%d" % (q[0] + 1, n + 1, q[2] + 1, n + 1, q[3] + 1, n + 1))
+    out["pnt_cube"] = ("\n".join(lines) + "\n", 7)
+    out["pnt_cube_default_attrs"] = (out["pnt_cube"][0], 0)
+    lines = ["v 0 0 0", "v 1e0 0 0", "v 1 1.5e-1 -0", " v 9 9 9", "v 0.25 1", "# a comment", "", "v -1.25E+1 3 4", "vt 0.5 0.5",
+             "f 1 2 3", "f 2 3 4 5", "f 5 4 1", "f 1 2 3", "g tail", "f 3 2 1"]
+    out["p_mixed_crlf"] = ("\r\n".join(lines) + "\r\n", 1)
+    lines = ["v 0 0 0", "v 1 0 0", "v 0 1 0", "v 1 1 0", "vt 0 0", "vt 1 0", "vt 0 1", "f 1/1 2/2 3/3", "f 2/2 4/1 3/3", "f 1/2 2/2 3/3"]
+    out["pt_strip"] = ("\n".join(lines), 5)  # no newline at the end of the file
+    n_v, n_f = 9000, 42000
+    pos = rng.random((n_v, 3)).astype(np.float32)
+    nrm = rng.standard_normal((500, 3)).astype(np.float32)
+    lines = ["v %.9g %.9g %.9g" % tuple(r) for r in pos] + ["vn %.9g %.9g %.9g" % tuple(r) for r in nrm]
+    fp = rng.integers(1, n_v + 1, (n_f, 3))
+    fn = rng.integers(1, 4, (n_f, 3))  # few normals per position: many repeated pairs
+    lines += ["f %d//%d %d//%d %d//%d" % (a, x, b, y, c, z) for (a, b, c), (x, y, z) in zip(fp, fn)]
+    out["pn_random_big"] = ("\n".join(lines) + "\n", 3)
+    return out

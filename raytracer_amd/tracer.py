@@ -7,6 +7,7 @@ raises RTHipError -- there is no CPU path behind these functions.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 
 import numpy as np
@@ -187,6 +188,30 @@ def occluded(tracer: RT_Tracer, origins, directions, tmax: float = 3.402823466e+
 
 
 CAST_KERNELS = {"persistent": 0, "static": 1, "wavefront": 2, "auto": 3, "static-samples": 4}
+
+
+def ms_load_obj(tracer: RT_Tracer, path: str, attrs: int = 0, read_back: bool = True):
+    """ms_load_obj, src/mesh/mesh.c:73-219: (vertices float32 [vertex_count, 4 * attributes], indices uint32, info).
+    attrs: GEO_VertexAttributes bits (P = 1, N = 2, T = 4; 0 = all).  The mesh stays in device memory for
+    blas_add_loaded_obj; read_back=False skips the copy to the host and returns (None, None, info)."""
+    info = np.zeros(1, dtype=abi.OBJ_INFO)
+    tracer.check(tracer.lib.rthip_obj_load(tracer.h, os.fsencode(path), attrs, abi.ptr(info)), "rthip_obj_load")
+    info = {k: info[0][k].item() for k in abi.OBJ_INFO.names}
+    if not read_back:
+        return None, None, info
+    verts = np.zeros((info["vertex_count"], info["vertex_bytes"] // 4), dtype=np.float32)
+    idx = np.zeros(info["index_count"], dtype=np.uint32)
+    tracer.check(tracer.lib.rthip_obj_get(tracer.h, abi.ptr(verts), abi.ptr(idx)), "rthip_obj_get")
+    return verts, idx, info
+
+
+def blas_add_loaded_obj(tracer: RT_Tracer, n_meshes: int = 1, blas_id: int = 0, commit: bool = True) -> None:
+    """The loaded mesh as mesh `blas_id` of a BLAS set of n_meshes, device to device."""
+    if blas_id == 0:
+        tracer.check(tracer.lib.rthip_blas_begin(tracer.h, n_meshes), "rthip_blas_begin")
+    tracer.check(tracer.lib.rthip_blas_add_loaded_obj(tracer.h, blas_id), "rthip_blas_add_loaded_obj")
+    if commit:
+        tracer.check(tracer.lib.rthip_blas_commit(tracer.h), "rthip_blas_commit")
 
 
 def hdr_encode(tracer: RT_Tracer, rgb, width: int, height: int) -> bytes:

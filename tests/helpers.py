@@ -52,3 +52,16 @@ def assert_same_tree_modulo_runs(got, want, sorted_codes, what=""):
         # signed zeros may legitimately differ with leaf order; compare values there
         close = (got[f] == want[f]).all(axis=1)
         assert (same | close)[whole].all(), f"{what}: {f} differs on run-aligned nodes"
+
+
+def obj_written_columns(attrs: int, width: int):
+    """Columns of an ms_load_obj vertex row that an attribute writes (3 of every 16-byte slot, 2 for the uv slot)."""
+    attrs = attrs or 7
+    slots = width // 4
+    cols, slot = [], 0
+    for bit, n in ((1, 3), (2, 3), (4, 2)):
+        if attrs & bit:
+            cols += [4 * slot + k for k in range(n)]
+            slot += 1
+    assert slot == slots
+    return np.array(cols)

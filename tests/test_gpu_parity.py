@@ -635,6 +635,102 @@ def test_animated_instances_rebuild_the_tlas_every_frame(oracle, gpu_tracer):
     assert T.get_tree(gpu_tracer, 0).tobytes() == blas0.tobytes(), "the BLAS must not change"
 
 
+# ---- OBJ files --------------------------------------------------------------------------------
+
+
+def test_obj_loader_matches_reference(gpu_tracer, tmp_path):
+    """rthip_obj_load (host threads parse, the GPU deduplicates) against the reference's ms_load_obj results."""
+    from helpers import obj_written_columns
+
+    g = golden("obj")
+    for name, (text, attrs) in scenes.obj_test_files().items():
+        path = tmp_path / (name + ".obj")
+        path.write_bytes(text.encode())
+        verts, idx, info = T.ms_load_obj(gpu_tracer, str(path), attrs)
+        assert info["vertex_count"] == verts.shape[0] and info["index_count"] == idx.size
+        written = np.ascontiguousarray(verts[:, obj_written_columns(attrs, verts.shape[1])])
+        if name + "_ref_indices" in g.files:
+            assert (idx == g[name + "_ref_indices"]).all(), name
+            assert bits(written).tobytes() == bits(g[name + "_ref_vertices"]).tobytes(), name
+        else:
+            assert info["host_threads"] > 1, "the big file must be split over threads"
+            assert (verts.shape[0], idx.size) == tuple(g[name + "_ref_counts"]), name
+            assert hashlib.sha256(idx.tobytes()).hexdigest() == str(g[name + "_ref_indices_sha"]), name
+            assert hashlib.sha256(written.tobytes()).hexdigest() == str(g[name + "_ref_vertices_sha"]), name
+
+
+def test_obj_loader_against_oracle_on_a_large_file(oracle, gpu_tracer, tmp_path):
+    """300 k faces with heavily repeated index triples, all four syntaxes."""
+    rng = np.random.default_rng(12)
+    n_v, n_n, n_t, n_f = 50_000, 700, 900, 300_000
+    head = ["v %.9g %.9g %.9g" % tuple(r) for r in rng.random((n_v, 3)).astype(np.float32)]
+    head += ["vn %.9g %.9g %.9g" % tuple(r) for r in rng.standard_normal((n_n, 3)).astype(np.float32)]
+    head += ["vt %.9g %.9g" % tuple(r) for r in rng.random((n_t, 2)).astype(np.float32)]
+    fp = rng.integers(1, n_v + 1, (n_f, 3))
+    fn = rng.integers(1, 5, (n_f, 3))
+    ft = rng.integers(1, 4, (n_f, 3))
+    fmt = {1: lambda p, n, t: "%d" % p, 3: lambda p, n, t: "%d//%d" % (p, n), 5: lambda p, n, t: "%d/%d" % (p, t),
+           7: lambda p, n, t: "%d/%d/%d" % (p, t, n)}
+    for attrs in (1, 3, 5, 7):
+        faces = ["f " + " ".join(fmt[attrs](fp[k, c], fn[k, c], ft[k, c]) for c in range(3)) for k in range(n_f)]
+        path = tmp_path / f"big_{attrs}.obj"
+        path.write_text("\n".join(head + faces) + "\n")
+        verts, idx, info = T.ms_load_obj(gpu_tracer, str(path), attrs)
+        overts, oidx = oracle.load_obj(str(path), attrs)
+        assert (idx == oidx).all() and bits(verts).tobytes() == bits(overts).tobytes(), attrs
+        assert idx.size == 3 * (n_f + 1) and verts.shape[0] < idx.size
+
+
+def test_loaded_obj_goes_to_the_blas_on_the_device(oracle, gpu_tracer, tmp_path):
+    """rthip_blas_add_loaded_obj: the mesh built from the device-resident loader result equals the one built from the
+    host arrays the loader returns (and hits equal the oracle's)."""
+    text, attrs = scenes.obj_test_files()["pn_mesh"]
+    path = tmp_path / "mesh.obj"
+    path.write_bytes(text.encode())
+    verts, idx, info = T.ms_load_obj(gpu_tracer, str(path), attrs)
+    gpu_tracer.check(gpu_tracer.lib.rthip_set_tracer(gpu_tracer.h, 3, 1), "set_tracer")
+    T.blas_add_loaded_obj(gpu_tracer)
+    w = world.rt_make_world()
+    m = world.rt_world_add_mesh(w)
+    m.vertices, m.vertices_count, m.indices, m.indices_count, m.attrs = verts, verts.shape[0], idx, idx.size, attrs
+    mat = world.rt_world_add_material(w)
+    mat.type, mat.albedo = abi.MAT_LAMBERTIAN, (np.float32(0.7), np.float32(0.7), np.float32(0.7))
+    it = world.rt_world_add_instance(w)
+    it.type, it.material, it.mesh = abi.INST_MESH, mat, m
+    it.translation, it.rotation, it.scale = (0, 0, 0), scenes.IDENTITY_QUAT, (1, 1, 1)
+    T.rt_tracer_build_tlas(gpu_tracer, w)
+    tree_device = T.get_tree(gpu_tracer, 0).copy()
+    o, d = scenes.random_rays(5000, seed=3, lo=(-2, -1, -2), hi=(2, 3, 2))
+    hits_device = T.trace_rays(gpu_tracer, o, d)
+    T.rt_tracer_build_blas(gpu_tracer, w)  # the same mesh through the host arrays
+    T.rt_tracer_build_tlas(gpu_tracer, w)
+    assert T.get_tree(gpu_tracer, 0).tobytes() == tree_device.tobytes()
+    hits_host = T.trace_rays(gpu_tracer, o, d)
+    for a, b in zip(hits_device, hits_host):
+        assert bits(a).tobytes() == bits(b).tobytes() if a.dtype == np.float32 else (a == b).all()
+    sc = oracle.Scene(world.flatten_world(w), 3, True)
+    oi, ot, ott, _, _, _ = sc.trace(o, d, threads=8)
+    assert (hits_device[0] == oi).all() and (hits_device[1] == ot).all() and (bits(hits_device[2]) == bits(ott)).all()
+    assert int((oi > 0).sum()) > 100
+
+
+def test_obj_loader_errors(gpu_tracer, tmp_path):
+    with pytest.raises(T.RTHipError, match="Failed to open"):
+        T.ms_load_obj(gpu_tracer, str(tmp_path / "missing.obj"), 3)
+    bad = tmp_path / "bad.obj"
+    bad.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3\n")
+    with pytest.raises(T.RTHipError, match="bad.obj:4"):
+        T.ms_load_obj(gpu_tracer, str(bad), 3)  # PN asked for, the face has positions only
+    far = tmp_path / "far.obj"
+    far.write_text("v 0 0 0\nf 1 2 3")
+    with pytest.raises(T.RTHipError, match="does not hold"):
+        T.ms_load_obj(gpu_tracer, str(far), 1)
+    empty = tmp_path / "empty.obj"
+    empty.write_text("")
+    verts, idx, info = T.ms_load_obj(gpu_tracer, str(empty), 1)
+    assert verts.shape[0] == 0 and idx.size == 0
+
+
 # ---- .hdr output ------------------------------------------------------------------------------
 
 

@@ -190,3 +190,28 @@ def test_hdr_encoder_against_reference_when_built(oracle):
         img = (rng.random((h, w, 3), dtype=np.float32) * np.float32(4.0)).astype(np.float32)
         img[:, w // 3: w // 2] = img[:, w // 3: w // 3 + 1]  # a run in every scanline
         assert oracle.hdr_encode(img) == oracle.ref_hdr_encode(img), (w, h)
+
+
+def test_obj_loader_matches_reference(oracle, tmp_path):
+    """The restated ms_load_obj against the reference's results (tests/golden/obj.npz), including the last line that
+    the reference's read loop takes twice when the file ends in a newline."""
+    from helpers import obj_written_columns
+
+    g = golden("obj")
+    files = scenes.obj_test_files()
+    assert len(files) >= 6
+    for name, (text, attrs) in files.items():
+        assert hashlib.sha256(text.encode()).hexdigest() == str(g[name + "_sha"]), f"generator of {name} drifted"
+        path = tmp_path / (name + ".obj")
+        path.write_bytes(text.encode())
+        verts, idx = oracle.load_obj(str(path), attrs)
+        written = np.ascontiguousarray(verts[:, obj_written_columns(attrs, verts.shape[1])])
+        if name + "_ref_indices" in g.files:
+            assert (idx == g[name + "_ref_indices"]).all(), name
+            assert bits(written).tobytes() == bits(g[name + "_ref_vertices"]).tobytes(), name
+        else:
+            assert (verts.shape[0], idx.size) == tuple(g[name + "_ref_counts"]), name
+            assert hashlib.sha256(idx.tobytes()).hexdigest() == str(g[name + "_ref_indices_sha"]), name
+            assert hashlib.sha256(written.tobytes()).hexdigest() == str(g[name + "_ref_vertices_sha"]), name
+    # the trailing face of a file that ends in a newline is a duplicated triangle, without the newline it is not
+    assert g["pnt_cube_ref_indices"].size == 39 and g["pt_strip_ref_indices"].size == 9
