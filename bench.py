@@ -202,6 +202,42 @@ def hdr_output(tr, torch, cast, W, H, steps, want_cpu):
     return res
 
 
+def obj_load_figure(tr, want_cpu):
+    """Loading the workload's mesh from a Wavefront OBJ file (ms_load_obj, src/mesh/mesh.c:73-219; the bunny demo's first
+    step, src/demos/bunny/main.c:41-49): rthip_obj_load (host threads parse, the GPU deduplicates) against the reference's
+    loader (or its CPU restatement) on the same file on this host."""
+    import tempfile
+
+    from raytracer_amd import scenes, tracer as T
+
+    verts, idx = scenes.bunny_class_mesh()
+    path = os.path.join(tempfile.gettempdir(), f"rthip_bench_{os.getpid()}.obj")
+    scenes.write_obj(path, verts, idx)
+    try:
+        best = None
+        for _ in range(3):
+            _, _, info = T.ms_load_obj(tr, path, 3, read_back=False)
+            if best is None or info["total_ms"] < best["total_ms"]:
+                best = info
+        res = {"what": "rthip_obj_load of the workload's mesh as a PN .obj file (v / vn / f a//a)", "file_bytes": os.path.getsize(path),
+               "triangles": best["index_count"] // 3, "vertices": best["vertex_count"], "ms": round(best["total_ms"], 3),
+               "parse_ms": round(best["parse_ms"], 3), "gpu_dedup_ms": round(best["dedup_ms"], 4), "host_threads": best["host_threads"]}
+        if want_cpu:
+            from oracle import oracle as O
+
+            gv, gi, _ = T.ms_load_obj(tr, path, 3)
+            use_ref = O.have_ref("core")
+            t0 = time.perf_counter()
+            cv, ci = O.ref_load_obj(path, 3, gv.shape[0] + 8, gi.size + 8) if use_ref else O.load_obj(path, 3)
+            res["cpu_ms"] = round((time.perf_counter() - t0) * 1e3, 2)
+            res["cpu_kind"] = "reference" if use_ref else "port"
+            cols = [0, 1, 2, 4, 5, 6]
+            res["identical_to_cpu"] = bool((gi == ci).all() and gv[:, cols].tobytes() == cv[:, cols].tobytes())
+        return res
+    finally:
+        os.unlink(path)
+
+
 def recorded_traffic(workload: str, kernel_name: str):
     """HBM bytes per launch of the cast kernel from the PMC passes kept under profiles/ (FETCH_SIZE and
     WRITE_SIZE, separate rocprofv3 runs of this same command; tools/pmc_traffic.py writes the file).
@@ -525,6 +561,7 @@ def main():
             line["lbvh_build_ms_per_1M_triangles"] = line["lbvh_build"][big]["ms_per_1M"]
         if args.workload == "bunny":
             line["shadow_rays"] = shadow_ray_rate(tr, torch, cast, W, H, args.steps)
+            line["obj_load"] = obj_load_figure(tr, not args.no_cpu_baseline and world == 1)
         want_cpu = not args.no_cpu_baseline and world == 1  # the CPU baseline is reported at N = 1 only
         if ray_o is None:
             line["hdr_output"] = hdr_output(tr, torch, cast, W, H, args.steps, want_cpu)

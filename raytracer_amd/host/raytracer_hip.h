@@ -26,3 +26,5 @@ internal RT_Handle      rt_hip_tracer_to_handle(RT_HIP_Tracer* tracer);
 
 // not one of the five hooks: the GPU-side replacement of the stbi_write_hdr call that follows rt_tracer_cast
 internal int rt_hip_write_hdr(RT_Handle handle, const char* path, int width, int height);
+// not a hook either: ms_load_obj's result from rthip_obj_load (parallel parse, GPU deduplication)
+internal MS_LoadResult rt_hip_load_obj(Arena* arena, NTString8 path, MS_LoadSettings settings);
