@@ -327,8 +327,8 @@ def cpu_port_parallel(wl, cast, flat, threads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="bunny")
     ap.add_argument("--samples", type=int, default=0, help="samples per pixel axis (spp = samples^2); 0 = the workload's own")
     ap.add_argument("--shard", default="frames", choices=["frames", "tiles", "samples"],
@@ -342,7 +342,7 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1: nccl = RCCL over xGMI (the product path); gloo = rehearsal "
                          "of the N > 1 code on a box whose ranks share one GPU (framebuffers staged through the host)")
-    ap.add_argument("--streams", type=int, default=8,
+    ap.add_argument("--streams", type=int, default=4,
                     help="HIP streams the steps are dealt to in turn (each with its own framebuffer and accumulator, summed "
                          "inside the timed region): a frame's first waves run while the previous frames' last waves drain.  "
                          "1 = strictly one launch after the other.  Only with --combine end (progressive accumulation) and "
@@ -397,6 +397,17 @@ def main():
     is_rays = "rays" in wl
     n_streams = max(1, args.streams) if (combine == "end" or is_rays) else 1
     main_stream = torch.cuda.current_stream()
+    if n_streams > 1:
+        # HIP binds a stream to one of its hardware queues (4 on this box, GPU_MAX_HW_QUEUES) when the stream is first
+        # used, and the first streams a process uses land beside the default stream and the library's own: measured on
+        # this workload with 4 working streams, 0.215 ms per frame when they are the first streams used, 0.135 ms once
+        # two or more other streams have been used before them.  So four streams are used once and set aside, and the
+        # working streams (a multiple of 4 spreads evenly; 6 measured worse than 4) come after them.
+        aside = [torch.cuda.Stream() for _ in range(4)]
+        for u in aside:
+            with torch.cuda.stream(u):
+                torch.zeros(16, device="cuda").add_(1.0)
+        torch.cuda.synchronize()
     streams = [main_stream] if n_streams == 1 else [torch.cuda.Stream() for _ in range(n_streams)]
     accums = [torch.zeros((H, W, 3), dtype=torch.float32, device="cuda") for _ in streams] if combine == "end" else None
     accum = accums[0] if accums else None
@@ -492,6 +503,7 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(ev[k])
+    host_enqueue_ms = (time.perf_counter() - t0) * 1e3 / args.steps
     pipe.drain()
     finish_image(args.steps)
     torch.cuda.synchronize()
@@ -526,6 +538,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "host_enqueue_ms_per_step": round(host_enqueue_ms, 4),
             "higher_is_better": True,
             "scaling": "weak" if args.shard == "frames" else "strong",
             "vs_baseline": None,

@@ -20,7 +20,7 @@ for name in sys.argv[1:] or ["bunny", "cornell", "instanced"]:
         streams = [torch.cuda.Stream() for _ in range(n_streams)]
         fbs = [torch.zeros((H, W, 3), dtype=torch.float32, device="cuda") for _ in range(n_streams)]
         acc = [torch.zeros((H, W, 3), dtype=torch.float32, device="cuda") for _ in range(n_streams)]
-        K = 40 if rays < 5e7 else 8
+        K = int(os.environ.get('PROBE_K', 40)) if rays < 5e7 else 8
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
         for rep in range(2):
             torch.cuda.synchronize()

@@ -7,7 +7,7 @@ cd $ROOT
 timeout -k 10 400 python3 -u bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err || exit 1
 timeout -k 10 400 python3 -u bench.py --streams 1 --no-cpu-baseline --build-sizes "" > $OUT/bench_default_streams1.json 2> $OUT/bench_default_streams1.err || exit 1
 for w in cornell instanced soup soup-rays instanced-rays cornell-mesh; do
-  timeout -k 10 400 python3 -u bench.py --workload $w --steps 16 --warmup 8 --build-sizes "" > $OUT/bench_$w.json 2> $OUT/bench_$w.err || exit 1
+  timeout -k 10 400 python3 -u bench.py --workload $w --steps 40 --warmup 8 --build-sizes "" > $OUT/bench_$w.json 2> $OUT/bench_$w.err || exit 1
 done
 WORKLOADS="bunny cornell instanced soup cornell-mesh" bash tools/sweep_cast_kernels.sh RTHIP_CAST=static > $OUT/sweep.txt 2>&1 || exit 1
 WORKLOADS="bunny cornell instanced soup cornell-mesh" bash tools/sweep_cast_kernels.sh RTHIP_CAST=persistent RTHIP_REFILL=16 >> $OUT/sweep.txt 2>&1 || exit 1
