@@ -1,0 +1,58 @@
+"""bench.py prints ONE JSON line with the agreed keys; N = 1, short runs (needs the GPU)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def run_bench(*flags):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], cwd=ROOT, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def check_common(d, steps, warmup):
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == steps and d["warmup"] == warmup
+    assert d["unit"] == "Mrays/s" and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert d["value"] > 0 and d["ms_per_step"] > 0
+    # value = rays of all steps / time of the timed region
+    rays = d["config"]["rays_per_frame_per_gpu"]
+    assert abs(d["value"] - rays / (d["ms_per_step"] * 1e-3) / 1e6) < 0.02 * d["value"]
+
+
+def test_default_workload_line():
+    d = run_bench("--steps", "24", "--warmup", "4", "--build-sizes", "81920", "--no-cpu-baseline")
+    check_common(d, 24, 4)
+    assert "1920x1080" in d["config"]["workload"] and "samples=1" in d["config"]["workload"]
+    assert d["config"]["streams"] == 4
+    assert "81920" in d["lbvh_build"] and d["lbvh_build_ms_per_1M_triangles"] > 0
+    assert d["shadow_rays"]["value"] > 0 and d["hdr_output"]["file_bytes"] > 0 and d["obj_load"]["triangles"] == 81921
+    assert "cpu_baseline" not in d
+
+
+def test_cpu_baseline_and_single_stream():
+    d = run_bench("--workload", "cornell", "--streams", "1", "--steps", "5", "--warmup", "1", "--build-sizes", "")
+    check_common(d, 5, 1)
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("reference", "port") and c["cores"] == 1 and c["value"] > 0
+    assert d["hdr_output"]["identical_to_cpu"] is True
+    assert d["roofline"]["concurrent_launches"] == 1
