@@ -20,6 +20,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <charconv>
 #include <chrono>
 #include <thread>
 
@@ -60,71 +61,98 @@ void count_chunk(const char* text, Chunk& c) {
     }
 }
 
-// "%f" of sscanf: strtof on a NUL-terminated copy of the line (the mapping is read-only and need not end in NUL)
-inline void parse_floats(char* line, int skip, float* out, int n) {
-    char* s = line + skip;
-    for (int k = 0; k < n; k++) {
-        char* after = nullptr;
-        const float v = strtof(s, &after);
-        if (after == s) return;  // sscanf stops at the first field that does not convert; the rest stays 0
-        out[k] = v;
-        s = after;
-    }
-}
+inline bool is_blank(char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\v' || c == '\f' || c == '\n'; }
 
-// " %u" of sscanf
-inline bool parse_uint(char*& s, uint32_t& out) {
-    while (*s == ' ' || *s == '\t' || *s == '\r' || *s == '\v' || *s == '\f') s++;
-    if (!((*s >= '0' && *s <= '9') || *s == '+' || *s == '-')) return false;
+// "%f" of sscanf = strtof.  std::from_chars is correctly rounded like strtof and several times faster, but differs at
+// the edges (no leading '+', no hexadecimal floats, out-of-range values reported instead of rounded), so anything
+// unusual goes through strtof itself on a NUL-terminated copy.
+inline bool scan_float(const char*& s, const char* e, float& out) {
+    while (s < e && is_blank(*s)) s++;
+    const char* t = s;
+    if (t < e && *t == '+') t++;
+    if (t < e && !(t != s && (*t == '+' || *t == '-'))) {
+        float v = 0.f;
+        const auto r = std::from_chars(t, e, v);
+        if (r.ec == std::errc() && !(r.ptr < e && (*r.ptr == 'x' || *r.ptr == 'X'))) {
+            out = v;
+            s = r.ptr;
+            return true;
+        }
+    }
+    char buf[256];
+    const size_t len = (size_t)(e - s) < sizeof buf - 1 ? (size_t)(e - s) : sizeof buf - 1;
+    memcpy(buf, s, len);
+    buf[len] = 0;
     char* after = nullptr;
-    const unsigned long v = strtoul(s, &after, 10);
-    if (after == s) return false;
-    out = (uint32_t)v;
-    s = after;
+    const float v = strtof(buf, &after);
+    if (after == buf) return false;
+    out = v;
+    s += after - buf;
     return true;
 }
+
+inline void parse_floats(const char* s, const char* e, float* out, int n) {
+    for (int k = 0; k < n; k++)
+        if (!scan_float(s, e, out[k])) return;  // sscanf stops at the first field that does not convert; the rest stays 0
+}
+
+// " %u" of sscanf = strtoul: plain digit strings directly, signs and overflow through strtoul
+inline bool scan_uint(const char*& s, const char* e, uint32_t& out) {
+    while (s < e && is_blank(*s)) s++;
+    const char* t = s;
+    uint64_t v = 0;
+    while (t < e && *t >= '0' && *t <= '9' && t - s < 10) v = v * 10 + (uint64_t)(*t++ - '0');
+    if (t > s && !(t < e && *t >= '0' && *t <= '9') && v <= 0xffffffffull) {
+        out = (uint32_t)v;
+        s = t;
+        return true;
+    }
+    if (!(s < e && ((*s >= '0' && *s <= '9') || *s == '+' || *s == '-'))) return false;
+    char buf[64];
+    const size_t len = (size_t)(e - s) < sizeof buf - 1 ? (size_t)(e - s) : sizeof buf - 1;
+    memcpy(buf, s, len);
+    buf[len] = 0;
+    char* after = nullptr;
+    const unsigned long v2 = strtoul(buf, &after, 10);
+    if (after == buf) return false;
+    out = (uint32_t)v2;
+    s += after - buf;
+    return true;
+}
+
+inline bool at(const char* s, const char* e, char c) { return s < e && *s == c; }
 
 void parse_chunk(const char* text, Chunk& c, uint32_t attrs, float* pos, float* nrm, float* uv, uint32_t* cp, uint32_t* cn,
                  uint32_t* ct) {
     const char* s = text + c.begin;
     const char* end = text + c.end;
     uint64_t iv = c.ov, ivn = c.ovn, ivt = c.ovt, ifc = c.of, line_no = c.first_line;
-    std::vector<char> buf(4096);
     while (s < end) {
         const char* nl = (const char*)memchr(s, '\n', (size_t)(end - s));
         const char* e = nl ? nl : end;
         line_no++;
-        const bool is_v = begins(s, e, "v ", 2), is_vn = begins(s, e, "vn ", 3), is_vt = begins(s, e, "vt ", 3),
-                   is_f = begins(s, e, "f ", 2);
-        if (is_v || is_vn || is_vt || is_f) {
-            const size_t len = (size_t)(e - s);
-            if (buf.size() < len + 1) buf.resize(len + 1);
-            memcpy(buf.data(), s, len);
-            buf[len] = 0;
-            char* line = buf.data();
-            if (is_v) parse_floats(line, 1, pos + 3 * iv++, 3);
-            else if (is_vn) parse_floats(line, 2, nrm + 3 * ivn++, 3);
-            else if (is_vt) parse_floats(line, 2, uv + 2 * ivt++, 2);
-            else {
-                char* q = line + 1;
-                bool ok = true;
-                for (int k = 0; k < 3 && ok; k++) {  // mesh.c:145-181: the format follows the requested attributes
-                    uint32_t p = 0, n = 0, t = 0;
-                    ok = parse_uint(q, p);
-                    if (ok && attrs == 5u) ok = *q == '/' && (++q, parse_uint(q, t));                       // " %u/%u"
-                    if (ok && attrs == 3u) ok = q[0] == '/' && q[1] == '/' && (q += 2, parse_uint(q, n));    // " %u//%u"
-                    if (ok && attrs == 7u)                                                                   // " %u/%u/%u"
-                        ok = *q == '/' && (++q, parse_uint(q, t)) && *q == '/' && (++q, parse_uint(q, n));
-                    cp[3 * ifc + k] = p;
-                    cn[3 * ifc + k] = n;
-                    ct[3 * ifc + k] = t;
-                    if (p > c.max_p) c.max_p = p;
-                    if (n > c.max_n) c.max_n = n;
-                    if (t > c.max_t) c.max_t = t;
-                }
-                if (!ok && c.bad_line == 0) c.bad_line = line_no;
-                ifc++;
+        if (begins(s, e, "v ", 2)) parse_floats(s + 1, e, pos + 3 * iv++, 3);
+        else if (begins(s, e, "vn ", 3)) parse_floats(s + 2, e, nrm + 3 * ivn++, 3);
+        else if (begins(s, e, "vt ", 3)) parse_floats(s + 2, e, uv + 2 * ivt++, 2);
+        else if (begins(s, e, "f ", 2)) {
+            const char* q = s + 1;
+            bool ok = true;
+            for (int k = 0; k < 3 && ok; k++) {  // mesh.c:145-181: the format follows the requested attributes
+                uint32_t p = 0, n = 0, t = 0;
+                ok = scan_uint(q, e, p);
+                if (ok && attrs == 5u) ok = at(q, e, '/') && (++q, scan_uint(q, e, t));                             // " %u/%u"
+                if (ok && attrs == 3u) ok = at(q, e, '/') && at(q + 1, e, '/') && (q += 2, scan_uint(q, e, n));     // " %u//%u"
+                if (ok && attrs == 7u)                                                                              // " %u/%u/%u"
+                    ok = at(q, e, '/') && (++q, scan_uint(q, e, t)) && at(q, e, '/') && (++q, scan_uint(q, e, n));
+                cp[3 * ifc + k] = p;
+                cn[3 * ifc + k] = n;
+                ct[3 * ifc + k] = t;
+                if (p > c.max_p) c.max_p = p;
+                if (n > c.max_n) c.max_n = n;
+                if (t > c.max_t) c.max_t = t;
             }
+            if (!ok && c.bad_line == 0) c.bad_line = line_no;
+            ifc++;
         }
         s = nl ? nl + 1 : end;
     }

@@ -275,7 +275,7 @@ internal int rt_hip_write_hdr(RT_Handle handle, const char* path, int width, int
 
 
 // ms_load_obj (src/mesh/mesh.c:73-219) with the text parsed on the host's cores and the vertex deduplication on the
-// GPU (rthip_obj_load): same MS_Mesh -- same vertices in the same order, same indices -- in the caller's arena, 18x
+// GPU (rthip_obj_load): same MS_Mesh -- same vertices in the same order, same indices -- in the caller's arena, about 50x
 // faster on a 1 M-triangle file.  The demos load their meshes before they make a tracer (src/demos/bunny/main.c:41-52),
 // so the loader keeps a GPU context of its own, made on first use.  Making it starts the GPU runtime, which draws from
 // rand(); the stream is restarted from its own next value afterwards, so that what rt_make_tracer takes as its seed

@@ -585,6 +585,13 @@ def obj_test_files(seed: int = 3):
     out["p_mixed_crlf"] = ("\r\n".join(lines) + "\r\n", 1)
     lines = ["v 0 0 0", "v 1 0 0", "v 0 1 0", "v 1 1 0", "vt 0 0", "vt 1 0", "vt 0 1", "f 1/1 2/2 3/3", "f 2/2 4/1 3/3", "f 1/2 2/2 3/3"]
     out["pt_strip"] = ("\n".join(lines), 5)  # no newline at the end of the file
+    forms = ["+1.5", "-.5", "5.", "1e3", "1E-2", "0x10", "inf", "-inf", "1e-46", "1e-40", "3.4028236e38", "1e39", "0.1",
+             "16777217", "0.3333333333333333333333333", "-0", "0x1.8p1", "1e+2", "00012", "4.9406564584124654e-324",
+             "1.17549435e-38", "7.00649232e-46", "9007199254740993", "1.00000005960464477539062500001"]
+    lines = ["v %s %s %s" % (forms[k], forms[(k + 5) % len(forms)], forms[(k + 11) % len(forms)]) for k in range(len(forms))]
+    lines += ["f %d %d %d" % (k + 1, (k + 1) % len(forms) + 1, (k + 2) % len(forms) + 1) for k in range(len(forms))]
+    lines += ["f +1 002 3", "f 4294967297 2 3"]  # a sign, leading zeros, a value that wraps to 1 in 32 bits
+    out["p_number_forms"] = ("\n".join(lines) + "\n", 1)
     n_v, n_f = 9000, 42000
     pos = rng.random((n_v, 3)).astype(np.float32)
     nrm = rng.standard_normal((500, 3)).astype(np.float32)
