@@ -298,6 +298,29 @@ int rthip_set_persistent_params(rthip_ctx* ctx, uint32_t refill, uint32_t inst_b
  * *out_count receives the node count; out_nodes (may be NULL) must hold that many. */
 int rthip_get_tree(rthip_ctx* ctx, int which, rthip_node* out_nodes, uint64_t* out_count);
 
+/* ---- ray records (debugging) ---------------------------------------------- */
+
+/* What a BUILD_DEBUG build of the reference appends to ./out.rays for every ray it traces
+ * (rt_cpu_dump_add_ray_hit_record / _miss_record, src/raytracer/cpu/extra/dump.c:11-32, called at
+ * raytracer_cpu.c:260-262 and :355-357; read by extra/blender.py): the ray, and for a hit the position, shading
+ * normal and distance as the intersection routine reports them (before the material turns the normal), for a miss
+ * zeros and t = -1.  `material` is the index into the materials array of rthip_tlas_build (-1: miss, or an instance
+ * without material); the reference writes the material's handle there. */
+typedef struct rthip_ray_record {
+    float origin[3];
+    float direction[3];
+    float p[3];
+    float n[3];
+    float t;
+    int32_t material;
+} rthip_ray_record;
+/* Renders the frame like rthip_cast (same seed -> same paths) and returns the records of all its rays in the
+ * reference's order: pixels row by row, a pixel's samples in sample order, a path's rays from the camera ray on.
+ * out_records == NULL: only *out_count is set.  Fails with RTHIP_E_LIMIT when capacity is too small (and *out_count
+ * tells the number needed).  A debugging aid: one thread per path, nothing tuned. */
+int rthip_cast_ray_records(rthip_ctx* ctx, const rthip_cast_settings* cast, uint64_t seed, int width, int height,
+                           rthip_ray_record* out_records, uint64_t capacity, uint64_t* out_count);
+
 /* ---- mesh files ---------------------------------------------------------- */
 
 /* ms_load_obj, src/mesh/mesh.c:73-219 (the demos load their meshes with it, src/demos/bunny/main.c:44): a Wavefront

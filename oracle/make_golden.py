@@ -228,6 +228,23 @@ def write_hdr():
     np.savez_compressed(os.path.join(OUT, "hdr.npz"), **out)
 
 
+def write_ray_records():
+    """out.rays of the reference's debug build (one 60-byte record per traced ray, src/raytracer/cpu/extra/dump.c:11-32)
+    for small frames of the three demos, with the camera record each run used."""
+    out = {}
+    rec_t = np.dtype([("o", "<f4", 3), ("d", "<f4", 3), ("p", "<f4", 3), ("n", "<f4", 3), ("t", "<f4"), ("m", "<u8")])
+    for name in ("cornell", "tri", "spheres"):
+        for (W, H, smp, b, seed) in ((16, 16, 1, 1, 1), (12, 10, 2, 4, 3)):
+            dbg = O.ref_demo(name + "_debug", W, H, smp, b, seed)
+            rec = np.frombuffer(dbg["ray_records"], dtype=rec_t)
+            key = f"{name}_{W}x{H}_s{smp}_b{b}_seed{seed}"
+            out[key + "_cast"] = dbg["cast"]
+            for f in rec_t.names:
+                out[key + "_" + f] = rec[f].copy()
+            print("ray records", key, len(rec))
+    np.savez_compressed(os.path.join(OUT, "ray_records.npz"), **out)
+
+
 def write_obj():
     """OBJ texts and what the reference's ms_load_obj makes of them (the big file: digests only)."""
     import tempfile
@@ -263,6 +280,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "converged":
         write_converged()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "rays":
+        write_ray_records()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "obj":
         write_obj()
         sys.exit(0)
@@ -280,3 +300,4 @@ if __name__ == "__main__":
     write_converged()
     write_hdr()
     write_obj()
+    write_ray_records()

@@ -93,6 +93,8 @@ def lib() -> C.CDLL:
         L.ora_scene_cast.argtypes = [_P, _P, C.c_uint64, C.c_int, _P, C.c_int, C.c_int, _P, C.c_int, _P]
         L.ora_hdr_encode.restype = C.c_uint64
         L.ora_hdr_encode.argtypes = [_P, C.c_int, C.c_int, _P, C.c_uint64]
+        L.ora_scene_cast_records.restype = C.c_uint64
+        L.ora_scene_cast_records.argtypes = [_P, _P, C.c_uint64, C.c_int, C.c_int, C.c_int, _P, C.c_uint64]
         L.ora_load_obj.restype = C.c_int
         L.ora_load_obj.argtypes = [C.c_char_p, C.c_uint32, _P, _P, _P, _P]
         L.ora_rgbe.restype = None
@@ -301,6 +303,14 @@ class Scene:
         lib().ora_scene_cast(self.h, abi.ptr(cast), int(seed) & (2**64 - 1), rng_mode, abi.ptr(out), width, height,
                              abi.ptr(sh), threads, abi.ptr(cnt))
         return out, {k: int(cnt[0][k]) for k in COUNTERS.names}
+
+    def cast_records(self, cast, seed, width, height, rng_mode=RNG_COUNTER):
+        """The out.rays records of the frame (abi.RAY_RECORD), in the reference's order."""
+        cast = np.ascontiguousarray(cast, dtype=abi.CAST).reshape(1)
+        n = lib().ora_scene_cast_records(self.h, abi.ptr(cast), int(seed) & (2**64 - 1), rng_mode, width, height, None, 0)
+        out = np.zeros(n, dtype=abi.RAY_RECORD)
+        lib().ora_scene_cast_records(self.h, abi.ptr(cast), int(seed) & (2**64 - 1), rng_mode, width, height, abi.ptr(out), n)
+        return out
 
 
 def primary_rays(cast, width, height):

@@ -814,7 +814,11 @@ static inline float env_pow5(const rng_t* g, float x) { /* pow_f32(x, 5.f), rayt
 /* path tracing: rt_cpu_raygen / trace_ray / closest_hit / miss              */
 /* ======================================================================== */
 
-typedef struct { uint8_t ior_count; float ior[ORA_MAX_BOUNCES]; } trace_ctx; /* raytracer_cpu.h:52-56 */
+typedef struct {
+    rthip_ray_record* out; /* NULL: count only */
+    uint64_t cap, n;
+} record_sink;
+typedef struct { uint8_t ior_count; float ior[ORA_MAX_BOUNCES]; record_sink* sink; } trace_ctx; /* raytracer_cpu.h:52-56 */
 
 static v3 trace_ray(const ora_scene* s, trace_ctx* ctx, const ray_t* r, int depth, rng_t* g, ora_counters* cnt);
 
@@ -917,6 +921,26 @@ static v3 closest_hit(const ora_scene* s, trace_ctx* ctx, const ray_t* r, int de
     }
 }
 
+/* rt_cpu_dump_add_ray_hit_record / _miss_record, src/raytracer/cpu/extra/dump.c:11-32 */
+static void sink_add(record_sink* k, const ray_t* r, const hit_record* rec) {
+    if (k->out && k->n < k->cap) {
+        rthip_ray_record* o = &k->out[k->n];
+        memset(o, 0, sizeof *o);
+        o->origin[0] = r->o.x, o->origin[1] = r->o.y, o->origin[2] = r->o.z;
+        o->direction[0] = r->d.x, o->direction[1] = r->d.y, o->direction[2] = r->d.z;
+        if (rec) {
+            o->p[0] = rec->p.x, o->p[1] = rec->p.y, o->p[2] = rec->p.z;
+            o->n[0] = rec->n.x, o->n[1] = rec->n.y, o->n[2] = rec->n.z;
+            o->t = rec->t;
+            o->material = rec->material;
+        } else {
+            o->t = -1.0f;
+            o->material = -1;
+        }
+    }
+    k->n++;
+}
+
 /* rt_cpu_trace_ray, raytracer_cpu.c:244-255 */
 static v3 trace_ray(const ora_scene* s, trace_ctx* ctx, const ray_t* r, int depth, rng_t* g, ora_counters* cnt) {
     if (depth == 0) return V3(0.f, 0.f, 0.f);
@@ -925,14 +949,16 @@ static v3 trace_ray(const ora_scene* s, trace_ctx* ctx, const ray_t* r, int dept
     if (h.hit) {
         hit_record rec;
         finish_hit(s, r, &h, &rec);
+        if (ctx->sink) sink_add(ctx->sink, r, &rec); /* first statement of rt_cpu_closest_hit, :260-262 */
         return closest_hit(s, ctx, r, depth, &rec, g, cnt);
     }
+    if (ctx->sink) sink_add(ctx->sink, r, NULL); /* first statement of rt_cpu_miss, :355-357 */
     return miss(s, r, g);
 }
 
 /* one camera sample of rt_cpu_raygen, raytracer_cpu.c:195-236 */
 static v3 camera_sample(const ora_scene* s, const rthip_cast_settings* c, int width, int height, int x, int y,
-                        int xs, int ys, rng_t* g, ora_counters* cnt, ray_t* out_ray) {
+                        int xs, int ys, rng_t* g, ora_counters* cnt, ray_t* out_ray, record_sink* sink) {
     int samples = (int)c->samples;
     float x_size = 1.f / (float)(width * samples);
     float y_size = 1.f / (float)(height * samples);
@@ -971,6 +997,7 @@ static v3 camera_sample(const ora_scene* s, const rthip_cast_settings* c, int wi
     trace_ctx ctx;
     memset(&ctx, 0, sizeof ctx);
     ctx.ior[0] = c->ior;
+    ctx.sink = sink;
     return trace_ray(s, &ctx, &r, (int)s->max_bounces, g, cnt);
 }
 
@@ -982,7 +1009,7 @@ void ora_primary_rays(const rthip_cast_settings* cast, int width, int height, fl
     for (int y = 0; y < height; y++)
         for (int x = 0; x < width; x++) {
             ray_t r;
-            camera_sample(NULL, &c, width, height, x, y, 0, 0, &g, NULL, &r);
+            camera_sample(NULL, &c, width, height, x, y, 0, 0, &g, NULL, &r, NULL);
             size_t i = (size_t)y * width + x;
             out_o3[3 * i] = r.o.x; out_o3[3 * i + 1] = r.o.y; out_o3[3 * i + 2] = r.o.z;
             out_d3[3 * i] = r.d.x; out_d3[3 * i + 1] = r.d.y; out_d3[3 * i + 2] = r.d.z;
@@ -998,6 +1025,7 @@ typedef struct {
     rthip_shard shard;
     glibc_rng* serial;
     ora_counters cnt;
+    record_sink* sink;
 } cast_job;
 
 static void* cast_worker(void* arg) {
@@ -1022,7 +1050,7 @@ static void* cast_worker(void* arg) {
                     g.serial = j->serial;
                     g.key = counter_key(j->seed, (uint32_t)(y * j->width + x), sidx);
                     g.draw = 0;
-                    c = vadd(c, camera_sample(j->s, j->c, j->width, j->height, x, y, xs, ys, &g, &j->cnt, NULL));
+                    c = vadd(c, camera_sample(j->s, j->c, j->width, j->height, x, y, xs, ys, &g, &j->cnt, NULL, j->sink));
                 }
             if (j->shard.mode != 2) c = vscale(c, inv_sample_count);
             px[0] = c.x; px[1] = c.y; px[2] = c.z;
@@ -1068,6 +1096,24 @@ void ora_scene_cast(const ora_scene* s, const rthip_cast_settings* cast, uint64_
         total.inst_entered += jobs[k].cnt.inst_entered;
     }
     if (counters) *counters = total;
+}
+
+uint64_t ora_scene_cast_records(const ora_scene* s, const rthip_cast_settings* cast, uint64_t seed, int rng_mode,
+                                int width, int height, rthip_ray_record* out, uint64_t cap) {
+    glibc_rng serial;
+    if (rng_mode == ORA_RNG_GLIBC) glibc_seed(&serial, (uint32_t)seed);
+    record_sink sink = {out, cap, 0};
+    float* rgb = (float*)malloc((size_t)width * height * 3 * sizeof(float));
+    cast_job j;
+    memset(&j, 0, sizeof j);
+    j.s = s; j.c = cast; j.seed = seed; j.mode = rng_mode;
+    j.width = width; j.height = height; j.y0 = 0; j.y1 = height;
+    j.out = rgb;
+    j.serial = &serial;
+    j.sink = &sink;
+    cast_worker(&j);
+    free(rgb);
+    return sink.n;
 }
 
 /* get_rt_cast_settings, src/demos/demos_inc.c:104-130 */

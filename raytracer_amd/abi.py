@@ -45,6 +45,10 @@ STATS = np.dtype(
      ("last_encode_ms", "<f4"), ("reserved", "<u4")],
     align=False,
 )
+# rthip_ray_record
+RAY_RECORD = np.dtype([("origin", "<f4", 3), ("direction", "<f4", 3), ("p", "<f4", 3), ("n", "<f4", 3), ("t", "<f4"),
+                       ("material", "<i4")], align=False)
+assert RAY_RECORD.itemsize == 56
 # rthip_obj_info
 OBJ_INFO = np.dtype([("vertex_count", "<u4"), ("index_count", "<u4"), ("attrs", "<u4"), ("vertex_bytes", "<u4"),
                      ("parse_ms", "<f4"), ("dedup_ms", "<f4"), ("total_ms", "<f4"), ("host_threads", "<u4")], align=False)
@@ -83,6 +87,7 @@ SYMBOLS = [
     ("rthip_set_cast_kernel", C.c_int, [_P, C.c_int]),
     ("rthip_set_persistent_params", C.c_int, [_P, C.c_uint32, C.c_uint32]),
     ("rthip_get_tree", C.c_int, [_P, C.c_int, _P, _P]),
+    ("rthip_cast_ray_records", C.c_int, [_P, _P, C.c_uint64, C.c_int, C.c_int, _P, C.c_uint64, _P]),
     ("rthip_obj_load", C.c_int, [_P, C.c_char_p, C.c_uint32, _P]),
     ("rthip_obj_get", C.c_int, [_P, _P, _P]),
     ("rthip_blas_add_loaded_obj", C.c_int, [_P, C.c_uint32]),

@@ -454,6 +454,42 @@ int rthip_cast(rthip_ctx* ctx, const rthip_cast_settings* cast, uint64_t seed, f
     return RTHIP_OK;
 }
 
+// ---- ray records -----------------------------------------------------------------------
+
+int rthip_cast_ray_records(rthip_ctx* ctx, const rthip_cast_settings* cast, uint64_t seed, int width, int height,
+                           rthip_ray_record* out_records, uint64_t capacity, uint64_t* out_count) {
+    RT_TRY(check_ready(ctx, "rthip_cast_ray_records"));
+    RT_TRY(check_cast(ctx, cast, width, height));
+    if (!out_count) return rthip_fail(ctx, RTHIP_E_INVALID, "out_count is NULL");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    const uint64_t n_paths = (uint64_t)width * height * cast->samples * cast->samples;
+    const uint64_t n_slots = n_paths * (ctx->max_bounces ? ctx->max_bounces : 1);
+    if (n_paths >= (1ull << 31) || n_slots * sizeof(rthip_ray_record) > (8ull << 30))
+        return rthip_fail(ctx, RTHIP_E_LIMIT, "ray records of %llu paths x %u bounces exceed 8 GiB: use a smaller frame",
+                          (unsigned long long)n_paths, ctx->max_bounces);
+    *out_count = 0;
+    if (ctx->max_bounces == 0) return RTHIP_OK;
+    RT_TRY(rthip_reserve(ctx, ctx->scratch_a, n_slots * sizeof(rthip_ray_record)));
+    RT_TRY(rthip_reserve(ctx, ctx->scratch_b, n_paths * 4 + 16));
+    const DevScene scene = make_scene(ctx);
+    uint64_t total = 0;
+    // first without an output buffer: the number of records decides the size of the compacted array
+    RT_TRY(cast_records_launch(ctx, scene, *cast, seed, width, height, (rthip_ray_record*)ctx->scratch_a.p,
+                               (uint32_t*)ctx->scratch_b.p, nullptr, &total, ctx->stream));
+    *out_count = total;
+    if (!out_records) return RTHIP_OK;
+    if (total > capacity)
+        return rthip_fail(ctx, RTHIP_E_LIMIT, "the frame has %llu rays, the buffer holds %llu records",
+                          (unsigned long long)total, (unsigned long long)capacity);
+    if (total == 0) return RTHIP_OK;
+    RT_TRY(rthip_reserve(ctx, ctx->scratch_c, total * sizeof(rthip_ray_record)));
+    RT_TRY(cast_records_launch(ctx, scene, *cast, seed, width, height, (rthip_ray_record*)ctx->scratch_a.p,
+                               (uint32_t*)ctx->scratch_b.p, (rthip_ray_record*)ctx->scratch_c.p, &total, ctx->stream));
+    RT_HIP(ctx, hipMemcpyAsync(out_records, ctx->scratch_c.p, total * sizeof(rthip_ray_record), hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RTHIP_OK;
+}
+
 // ---- .hdr output -------------------------------------------------------------------
 
 uint64_t rthip_hdr_bound(int width, int height) { return hdr_bound(width, height); }

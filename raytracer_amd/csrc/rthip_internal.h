@@ -225,6 +225,11 @@ int primary_hits_launch(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_
 int cast_wavefront_launch(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_settings& cast, uint64_t seed,
                           float* d_rgb, int width, int height, rthip_shard shard, uint64_t* d_counters,
                           hipStream_t stream);
+// ray records of a frame: d_slots holds paths x max_bounces records, d_counts paths uint32 (becomes their inclusive
+// scan); with d_out the records are compacted into it in path order; *out_total = number of records.  Synchronises.
+int cast_records_launch(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_settings& cast, uint64_t seed, int width,
+                        int height, rthip_ray_record* d_slots, uint32_t* d_counts, rthip_ray_record* d_out,
+                        uint64_t* out_total, hipStream_t stream);
 int cast_launch(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_settings& cast, uint64_t seed, float* d_rgb,
                 int width, int height, rthip_shard shard, uint64_t* d_counters, hipStream_t stream);
 

@@ -366,6 +366,66 @@ __global__ __launch_bounds__(kBlock, RT_STATIC_WAVES) void cast_samples_kernel(D
     if (COUNT) flush_counters(counters, cnt, rays);
 }
 
+// Debugging aid: the renderer with one thread per path (pixel-major, then sample: the reference's loop order) that
+// also stores what a BUILD_DEBUG build of the reference dumps for every ray (src/raytracer/cpu/extra/dump.c:11-32):
+// path i writes its k-th ray to slots[i * max_bounces + k] and the number of its rays to counts[i].
+__global__ __launch_bounds__(kBlock) void cast_records_kernel(DevScene S, rthip_cast_settings c, uint64_t seed, int width,
+                                                              int height, rthip_ray_record* __restrict__ slots,
+                                                              uint32_t* __restrict__ counts) {
+    extern __shared__ uint32_t bounce_stack[];
+    uint32_t* stack = bounce_stack + threadIdx.x;
+    const uint32_t samples = c.samples, spp = samples * samples;
+    const uint64_t path = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (path >= (uint64_t)width * height * spp) return;
+    const uint32_t pixel = (uint32_t)(path / spp), sidx = (uint32_t)(path % spp);
+    const int x = (int)(pixel % (uint32_t)width), y = (int)(pixel / (uint32_t)width);
+    Counters cnt = {0, 0, 0, 0};
+    PathState P;
+    P.g = rng_make(seed, pixel, sidx);
+    V3 o, d;
+    camera_ray(c, width, height, x, y, (int)(sidx % samples), (int)(sidx / samples), true, P.g, o, d);
+    P.depth = S.max_bounces;
+    P.sp = 0;
+    P.ior_top = P.ior_below = c.ior;
+    uint32_t n = 0;
+    rthip_ray_record* mine = slots + path * S.max_bounces;
+    if (P.depth != 0) {
+        V3 L = mk(0.f, 0.f, 0.f);
+        for (;;) {
+            const Hit h = closest_hit_query<false>(S, o, d, cnt);
+            rthip_ray_record r;
+            r.origin[0] = o.x, r.origin[1] = o.y, r.origin[2] = o.z;
+            r.direction[0] = d.x, r.direction[1] = d.y, r.direction[2] = d.z;
+            r.p[0] = r.p[1] = r.p[2] = 0.f;
+            r.n[0] = r.n[1] = r.n[2] = 0.f;
+            r.t = -1.0f;
+            r.material = -1;
+            if (h.inst != 0) {
+                V3 p, nn;
+                int material;
+                finish_hit(S, o, d, h, p, nn, material);
+                r.p[0] = p.x, r.p[1] = p.y, r.p[2] = p.z;
+                r.n[0] = nn.x, r.n[1] = nn.y, r.n[2] = nn.z;
+                r.t = h.t;
+                r.material = material;
+            }
+            mine[n++] = r;
+            if (path_bounce(S, P, h, o, d, L, stack, kBlock)) break;
+        }
+    }
+    counts[path] = n;
+}
+
+// counts_scan: inclusive prefix sum of the counts; path i's records go to out[counts_scan[i] - count ...]
+__global__ __launch_bounds__(kBlock) void records_compact_kernel(const rthip_ray_record* __restrict__ slots,
+                                                                 const uint32_t* __restrict__ counts_scan, uint64_t n_paths,
+                                                                 uint32_t max_bounces, rthip_ray_record* __restrict__ out) {
+    const uint64_t path = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (path >= n_paths) return;
+    const uint32_t end = counts_scan[path], begin = path ? counts_scan[path - 1] : 0u;
+    for (uint32_t k = 0; k < end - begin; k++) out[begin + k] = slots[path * max_bounces + k];
+}
+
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void primary_hits_kernel(DevScene S, rthip_cast_settings c, int width, int height,
                                                               uint32_t* __restrict__ hits4, uint64_t* counters) {
@@ -571,6 +631,26 @@ int primary_hits_launch(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_
     else
         primary_hits_kernel<false><<<blocks, kBlock, 0, stream>>>(scene, cast, width, height, d_hits4, nullptr);
     RT_HIP(ctx, hipGetLastError());
+    return RTHIP_OK;
+}
+
+int cast_records_launch(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_settings& cast, uint64_t seed, int width,
+                        int height, rthip_ray_record* d_slots, uint32_t* d_counts, rthip_ray_record* d_out,
+                        uint64_t* out_total, hipStream_t stream) {
+    const uint64_t n_paths = (uint64_t)width * height * cast.samples * cast.samples;
+    const size_t lds = (size_t)(scene.max_bounces ? scene.max_bounces : 1) * kBlock * sizeof(uint32_t);
+    const uint32_t blocks = div_up(n_paths, kBlock);
+    cast_records_kernel<<<blocks, kBlock, lds, stream>>>(scene, cast, seed, width, height, d_slots, d_counts);
+    RT_HIP(ctx, hipGetLastError());
+    RT_TRY(scan_inclusive_u32_device(ctx, d_counts, n_paths, stream));
+    uint32_t total = 0;
+    RT_HIP(ctx, hipMemcpyAsync(&total, d_counts + (n_paths - 1), 4, hipMemcpyDeviceToHost, stream));
+    RT_HIP(ctx, hipStreamSynchronize(stream));
+    *out_total = total;
+    if (d_out) {
+        records_compact_kernel<<<blocks, kBlock, 0, stream>>>(d_slots, d_counts, n_paths, scene.max_bounces, d_out);
+        RT_HIP(ctx, hipGetLastError());
+    }
     return RTHIP_OK;
 }
 

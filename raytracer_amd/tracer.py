@@ -190,6 +190,20 @@ def occluded(tracer: RT_Tracer, origins, directions, tmax: float = 3.402823466e+
 CAST_KERNELS = {"persistent": 0, "static": 1, "wavefront": 2, "auto": 3, "static-samples": 4}
 
 
+def cast_ray_records(tracer: RT_Tracer, settings: np.ndarray, width: int, height: int, seed: int = 0) -> np.ndarray:
+    """The out.rays records of the frame rt_tracer_cast renders with the same seed (abi.RAY_RECORD; the dump of the
+    reference's BUILD_DEBUG build, src/raytracer/cpu/extra/dump.c:11-32), in the reference's order."""
+    cast = np.ascontiguousarray(settings, dtype=abi.CAST).reshape(1)
+    n = C.c_uint64(0)
+    tracer.check(tracer.lib.rthip_cast_ray_records(tracer.h, abi.ptr(cast), int(seed) & (2**64 - 1), width, height, None, 0,
+                                                   C.addressof(n)), "rthip_cast_ray_records")
+    out = np.zeros(n.value, dtype=abi.RAY_RECORD)
+    if n.value:
+        tracer.check(tracer.lib.rthip_cast_ray_records(tracer.h, abi.ptr(cast), int(seed) & (2**64 - 1), width, height,
+                                                       abi.ptr(out), n.value, C.addressof(n)), "rthip_cast_ray_records")
+    return out
+
+
 def ms_load_obj(tracer: RT_Tracer, path: str, attrs: int = 0, read_back: bool = True):
     """ms_load_obj, src/mesh/mesh.c:73-219: (vertices float32 [vertex_count, 4 * attributes], indices uint32, info).
     attrs: GEO_VertexAttributes bits (P = 1, N = 2, T = 4; 0 = all).  The mesh stays in device memory for

@@ -32,16 +32,18 @@ def test_struct_layouts_match_the_header(tmp_path):
     src = tmp_path / "sizes.c"
     src.write_text(
         '#include <stdio.h>\n#include <stddef.h>\n#include "rthip.h"\n'
-        "int main(void){printf(\"%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n\", sizeof(rthip_material), sizeof(rthip_instance),"
+        "int main(void){printf(\"%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n\", sizeof(rthip_material), sizeof(rthip_instance),"
         " sizeof(rthip_cast_settings), sizeof(rthip_node), sizeof(rthip_shard), sizeof(rthip_stats),"
-        " offsetof(rthip_instance, rotation), offsetof(rthip_cast_settings, defocus_disk), offsetof(rthip_stats, last_cast_ms));return 0;}\n"
+        " offsetof(rthip_instance, rotation), offsetof(rthip_cast_settings, defocus_disk), offsetof(rthip_stats, last_cast_ms),"
+        " sizeof(rthip_ray_record), offsetof(rthip_ray_record, t), sizeof(rthip_obj_info), offsetof(rthip_obj_info, parse_ms));return 0;}\n"
     )
     exe = tmp_path / "sizes"
     subprocess.check_call(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     want = [abi.MATERIAL.itemsize, abi.INSTANCE.itemsize, abi.CAST.itemsize, abi.NODE.itemsize, abi.SHARD.itemsize,
             abi.STATS.itemsize, abi.INSTANCE.fields["rotation"][1], abi.CAST.fields["defocus_disk"][1],
-            abi.STATS.fields["last_cast_ms"][1]]
+            abi.STATS.fields["last_cast_ms"][1], abi.RAY_RECORD.itemsize, abi.RAY_RECORD.fields["t"][1],
+            abi.OBJ_INFO.itemsize, abi.OBJ_INFO.fields["parse_ms"][1]]
     assert got == want
 
 

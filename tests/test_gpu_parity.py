@@ -635,6 +635,58 @@ def test_animated_instances_rebuild_the_tlas_every_frame(oracle, gpu_tracer):
     assert T.get_tree(gpu_tracer, 0).tobytes() == blas0.tobytes(), "the BLAS must not change"
 
 
+# ---- ray records ------------------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("name", ["cornell", "tri", "spheres"])
+def test_ray_records_primary_rays_match_the_reference_dump(gpu_tracer, name):
+    """rthip_cast_ray_records on a one-bounce, one-sample frame: every record (camera ray, hit point, normal, distance,
+    material grouping) as in the out.rays file the reference's BUILD_DEBUG build wrote (no random numbers involved;
+    the spheres camera has defocus, so only its hit / miss pattern is not compared there)."""
+    from test_oracle_golden import same_ray_records
+
+    g = golden("ray_records")
+    key = f"{name}_16x16_s1_b1_seed1"
+    w, cam, sky = {"cornell": scenes.cornell, "tri": scenes.tri, "spheres": scenes.spheres}[name]()
+    build(gpu_tracer, w, 1, sky)
+    cast = g[key + "_cast"].copy()
+    if name == "spheres":
+        cast["defocus"] = 0  # lens samples come from the generator, which differs from the reference's
+    rec = T.cast_ray_records(gpu_tracer, cast, 16, 16, seed=1)
+    assert rec.size == 256
+    if name != "spheres":
+        same_ray_records(rec, g, key)
+
+
+def test_ray_records_match_the_oracle_over_whole_paths(oracle, gpu_tracer):
+    """Multi-bounce frames: the records of every ray of every path, in the reference's order, bit for bit against the
+    CPU restatement with the same counter-based generator; and the frame they describe is the frame rthip_cast renders."""
+    verts, indices = scenes.bunny_class_mesh(3)
+    for (w, cam, sky), bounces, (wd, ht, smp, seed) in (
+            (scenes.cornell(), 6, (40, 30, 2, 4)), (scenes.spheres(), 8, (33, 21, 2, 9)),
+            (scenes.instanced_grid(6, seed=2, verts=verts, indices=indices), 4, (48, 27, 1, 2))):
+        build(gpu_tracer, w, bounces, sky)
+        sc = oracle.Scene(world.flatten_world(w), bounces, sky)
+        c = cam(wd, ht, smp)
+        rec = T.cast_ray_records(gpu_tracer, c, wd, ht, seed=seed)
+        want = sc.cast_records(c, seed, wd, ht, rng_mode=oracle.RNG_COUNTER)
+        assert rec.size == want.size and rec.size > wd * ht * smp * smp
+        assert rec.tobytes() == want.tobytes()
+        T.set_counting(gpu_tracer, True)
+        T.get_stats(gpu_tracer)
+        img = np.zeros((ht, wd, 3), dtype=np.float32)
+        T.rt_tracer_cast(gpu_tracer, c, img, wd, ht, seed=seed)
+        assert T.get_stats(gpu_tracer)["rays"] == rec.size
+        T.set_counting(gpu_tracer, False)
+    # capacity too small: the count is still reported
+    import ctypes as C
+    n = C.c_uint64(0)
+    small = np.zeros(8, dtype=abi.RAY_RECORD)
+    cc = np.ascontiguousarray(c, dtype=abi.CAST).reshape(1)
+    rc = gpu_tracer.lib.rthip_cast_ray_records(gpu_tracer.h, abi.ptr(cc), seed, wd, ht, abi.ptr(small), 8, C.addressof(n))
+    assert rc == 4 and n.value == rec.size
+
+
 # ---- OBJ files --------------------------------------------------------------------------------
 
 

@@ -215,3 +215,29 @@ def test_obj_loader_matches_reference(oracle, tmp_path):
             assert hashlib.sha256(written.tobytes()).hexdigest() == str(g[name + "_ref_vertices_sha"]), name
     # the trailing face of a file that ends in a newline is a duplicated triangle, without the newline it is not
     assert g["pnt_cube_ref_indices"].size == 39 and g["pt_strip_ref_indices"].size == 9
+
+
+RAY_RECORD_CASES = [(n, c) for n in ("cornell", "tri", "spheres") for c in ((16, 16, 1, 1, 1), (12, 10, 2, 4, 3))]
+
+
+def same_ray_records(mine, g, key):
+    """abi.RAY_RECORD array against the reference's out.rays fields stored under `key`: float fields bit for bit,
+    materials as the same grouping (the reference writes handles, i.e. addresses)."""
+    assert len(mine) == len(g[key + "_t"]), key
+    for a, b in (("o", "origin"), ("d", "direction"), ("p", "p"), ("n", "n"), ("t", "t")):
+        assert bits(np.ascontiguousarray(mine[b])).tobytes() == bits(g[key + "_" + a]).tobytes(), (key, a)
+    pairs = set(zip(g[key + "_m"].tolist(), mine["material"].tolist()))
+    assert len(pairs) == len(set(g[key + "_m"].tolist())) == len(set(mine["material"].tolist())), key
+    assert ((g[key + "_m"] == 0) == (mine["material"] < 0)).all(), key  # misses carry a zero handle
+
+
+@pytest.mark.parametrize("name,case", RAY_RECORD_CASES)
+def test_ray_records_match_the_reference_debug_dump(oracle, name, case):
+    """Every ray of a frame (origin, direction, hit point, normal, distance, material) as the reference's BUILD_DEBUG
+    build dumps it to out.rays, multi-bounce paths included: the restatement with the glibc rand() order."""
+    W, H, smp, b, seed = case
+    g = golden("ray_records")
+    key = f"{name}_{W}x{H}_s{smp}_b{b}_seed{seed}"
+    w, cam, sky = {"cornell": scenes.cornell, "tri": scenes.tri, "spheres": scenes.spheres}[name]()
+    sc = oracle.Scene(world.flatten_world(w), b, sky)
+    same_ray_records(sc.cast_records(g[key + "_cast"], seed, W, H, rng_mode=oracle.RNG_GLIBC), g, key)
