@@ -53,6 +53,29 @@ static void rt_hip_dump_tree(RT_HIP_Tracer* tracer, int which, const char* path)
     fclose(f);
 }
 
+// The reference's ray dump (src/raytracer/cpu/extra/dump.c:1-32): per traced ray origin, direction, hit position,
+// normal, t and the material handle (60 bytes), a miss as zeros with t = -1; rays in the order of the CPU loop.
+static void rt_hip_dump_rays(RT_HIP_Tracer* tracer, const rthip_cast_settings* c, u64 seed, int width, int height, const char* path) {
+    FILE* f = fopen(path, "wb");
+    if (!f) return;
+    u64 count = 0;
+    rt_hip_check(tracer, rthip_cast_ray_records(tracer->ctx, c, seed, width, height, NULL, 0, &count), "rthip_cast_ray_records");
+    rthip_ray_record* rec = (rthip_ray_record*)malloc(sizeof(rthip_ray_record)*(count + 1));
+    if (count) rt_hip_check(tracer, rthip_cast_ray_records(tracer->ctx, c, seed, width, height, rec, count, &count), "rthip_cast_ray_records");
+    for (u64 i = 0; i < count; i++) {
+        u64 material = 0;
+        if (rec[i].material >= 0 && (u32)rec[i].material < tracer->material_count) material = tracer->material_handles[rec[i].material];
+        fwrite(rec[i].origin, sizeof(f32), 3, f);
+        fwrite(rec[i].direction, sizeof(f32), 3, f);
+        fwrite(rec[i].p, sizeof(f32), 3, f);
+        fwrite(rec[i].n, sizeof(f32), 3, f);
+        fwrite(&rec[i].t, sizeof(f32), 1, f);
+        fwrite(&material, sizeof(u64), 1, f);
+    }
+    free(rec);
+    fclose(f);
+}
+
 // rt_make_tracer: one GPU context per tracer.  The device is GPU 0 unless RT_HIP_DEVICE says otherwise.
 //
 // Random numbers: the CPU backend consumes the process-wide rand() stream that the demo seeded with
@@ -137,9 +160,14 @@ rt_hook void rt_tracer_build_tlas(RT_Handle handle, RT_World* world) {
         u64* keys = push_array(scratch.arena, u64, slots);
         u32* vals = push_array(scratch.arena, u32, slots);
 
+        free(tracer->material_handles);
+        tracer->material_handles = (u64*)malloc(sizeof(u64)*(mat_count + 1));
+        tracer->material_count = mat_count;
+
         u32 mi = 0;
         for EachList(node, RT_MaterialNode, world->materials.first) {
             const RT_Material* m = &node->v;
+            tracer->material_handles[mi] = (u64)node;
             rthip_material* o = &mats[mi];
             o->type = (u32)m->type;
             o->albedo[0] = m->albedo.x;     o->albedo[1] = m->albedo.y;     o->albedo[2] = m->albedo.z;
@@ -210,6 +238,7 @@ rt_hook void rt_tracer_build_tlas(RT_Handle handle, RT_World* world) {
 
 rt_hook void rt_tracer_cleanup(RT_Handle handle) {
     RT_HIP_Tracer* tracer = rt_hip_handle_to_tracer(handle);
+    free(tracer->material_handles);
     rthip_destroy(tracer->ctx);
     arena_release(tracer->arena);
 }
@@ -246,6 +275,12 @@ rt_hook void rt_tracer_cast(RT_Handle handle, RT_CastSettings settings, vec3_f32
     }
     const char* hdr = getenv("RT_HIP_HDR");
     if (hdr) rt_hip_write_hdr(handle, hdr, width, height);
+
+    // A BUILD_DEBUG build of the CPU backend leaves every ray of the cast in ./out.rays (raytracer_cpu.c:180-182,
+    // 260-262, 355-357; read by extra/blender.py).  Same file here, from the records of the same frame (same seed).
+    #if BUILD_DEBUG
+    rt_hip_dump_rays(tracer, &c, seed, width, height, "out.rays");
+    #endif
 }
 
 // The image of the last rt_tracer_cast as a Radiance .hdr file, byte for byte the file

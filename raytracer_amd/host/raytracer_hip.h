@@ -19,6 +19,8 @@ struct RT_HIP_Tracer {
     bool sky;
     u64 seed;   // first rand() after the caller's srand(): seeds the GPU generator
     u64 casts;  // casts made with this tracer
+    u64* material_handles;  // handle (node address) of material i of the last rt_tracer_build_tlas, for out.rays
+    u32 material_count;
 };
 
 internal RT_HIP_Tracer* rt_hip_handle_to_tracer(RT_Handle handle);

@@ -107,3 +107,48 @@ def test_bunny_demo_with_gpu_loader_and_gpu_hdr_writer(gpu_tracer, tmp_path):
                           env=dict(os.environ, RT_HIP_DUMP_F32=str(tmp_path / "plain.f32")), timeout=120)
     plain_img = np.fromfile(str(tmp_path / "plain.f32"), dtype=np.float32).reshape(ht, wd, 3)
     assert abs(float(plain_img.mean()) - float(got.mean())) < 0.02 * float(got.mean())
+
+
+@pytest.mark.gpu
+def test_debug_build_of_a_demo_writes_the_reference_ray_dump(gpu_tracer, tmp_path):
+    """The Cornell demo in the reference's debug flavour on top of the backend: ./out.rays must hold, for a one-bounce
+    frame, exactly the records the CPU backend's debug build wrote (tests/golden/ray_records.npz; the material
+    handles are addresses, so they are compared as a grouping), and for a multi-bounce frame the records of
+    rthip_cast_ray_records with the seed the hook derives."""
+    exe = os.path.join(BUILD, "cornell_debug_hip")
+    if not os.path.exists(exe):
+        pytest.skip("demo binaries are only built where the reference checkout exists")
+    from conftest import golden
+    from raytracer_amd import abi, scenes, tracer as T
+    from test_oracle_golden import same_ray_records
+
+    file_t = np.dtype([("origin", "<f4", 3), ("direction", "<f4", 3), ("p", "<f4", 3), ("n", "<f4", 3), ("t", "<f4"),
+                       ("handle", "<u8")])
+    env = dict(os.environ, RT_HIP_NO_DUMP="1")
+    subprocess.check_call([exe, str(tmp_path / "a.hdr"), "--width=16", "--height=16", "--samples=1", "--bounces=1", "--seed=1"],
+                          cwd=str(tmp_path), env=env, timeout=120)
+    rec = np.fromfile(str(tmp_path / "out.rays"), dtype=file_t)
+    mine = np.zeros(rec.size, dtype=abi.RAY_RECORD)
+    for f in ("origin", "direction", "p", "n", "t"):
+        mine[f] = rec[f]
+    handles = {h: k for k, h in enumerate(sorted(set(rec["handle"].tolist()) - {0}))}
+    mine["material"] = [handles.get(h, -1) for h in rec["handle"].tolist()]
+    same_ray_records(mine, golden("ray_records"), "cornell_16x16_s1_b1_seed1")
+
+    wd, ht, seed = 24, 18, 5
+    subprocess.check_call([exe, str(tmp_path / "b.hdr"), f"--width={wd}", f"--height={ht}", "--samples=2", "--bounces=5",
+                           f"--seed={seed}"], cwd=str(tmp_path), env=env, timeout=120)
+    rec = np.fromfile(str(tmp_path / "out.rays"), dtype=file_t)
+    libc = ctypes.CDLL("libc.so.6")
+    libc.srand(seed)
+    first = libc.rand()
+    w, cam, sky = scenes.cornell()
+    gpu_tracer.check(gpu_tracer.lib.rthip_set_tracer(gpu_tracer.h, 5, 1 if sky else 0), "set_tracer")
+    T.rt_tracer_build_blas(gpu_tracer, w)
+    T.rt_tracer_build_tlas(gpu_tracer, w)
+    want = T.cast_ray_records(gpu_tracer, cam(wd, ht, 2), wd, ht, seed=first)
+    assert rec.size == want.size
+    for f in ("origin", "direction", "p", "n", "t"):
+        assert np.ascontiguousarray(rec[f]).tobytes() == np.ascontiguousarray(want[f]).tobytes(), f
+    assert ((rec["handle"] == 0) == (want["material"] < 0)).all()
+    assert len(set(zip(rec["handle"].tolist(), want["material"].tolist()))) == len(set(want["material"].tolist()))
