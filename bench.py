@@ -411,7 +411,6 @@ def main():
     streams = [main_stream] if n_streams == 1 else [torch.cuda.Stream() for _ in range(n_streams)]
     accums = [torch.zeros((H, W, 3), dtype=torch.float32, device="cuda") for _ in streams] if combine == "end" else None
     accum = accums[0] if accums else None
-    fbs = [torch.zeros((H, W, 3), dtype=torch.float32, device="cuda") for _ in streams] if combine == "end" else None
     step_no = [0]
     # --combine every: two framebuffers, the RCCL reduce of frame k overlaps the render of frame k + 1
     pipe = rdist.FramePipeline([torch.zeros((H, W, 3), dtype=torch.float32, device="cuda") for _ in range(2)],
@@ -444,21 +443,27 @@ def main():
                 events[1].record(stream)
             tr.check(rc, "rthip_trace_rays_device")
             return
-        fb = fbs[k] if combine == "end" else pipe.acquire()
-        # progressive accumulation: every step of every rank renders its own sample set
+        # progressive accumulation: every step of every rank renders its own sample set and adds it to the stream's
+        # accumulator (rthip_cast_accumulate_device: no pass of its own for the addition)
         step_seed = seed if combine == "every" else 1 + step_no[0] * world + rank
         step_no[0] += 1
+        if combine == "end":
+            if events:
+                events[0].record(stream)
+            rc = tr.lib.rthip_cast_accumulate_device(tr.h, abi.ptr(cast), step_seed, accums[k].data_ptr(), W, H, abi.ptr(shard),
+                                                     stream.cuda_stream)
+            if events:
+                events[1].record(stream)
+            tr.check(rc, "rthip_cast_accumulate_device")
+            return
+        fb = pipe.acquire()
         if events:
             events[0].record(stream)
         rc = tr.lib.rthip_cast_device(tr.h, abi.ptr(cast), step_seed, fb.data_ptr(), W, H, abi.ptr(shard), stream.cuda_stream)
         if events:
             events[1].record(stream)
         tr.check(rc, "rthip_cast_device")
-        if combine == "end":
-            with torch.cuda.stream(stream):
-                accums[k].add_(fb)
-        else:
-            pipe.submit(fb)
+        pipe.submit(fb)
 
     def finish_image(n_steps):
         """--combine end: the streams' accumulators are added up and the image is exchanged once, inside the timed region."""

@@ -198,6 +198,13 @@ int rthip_cast(rthip_ctx* ctx, const rthip_cast_settings* cast, uint64_t seed, f
  * context's share as described at rthip_shard.  shard == NULL means mode 0. */
 int rthip_cast_device(rthip_ctx* ctx, const rthip_cast_settings* cast, uint64_t seed, float* d_out_rgb, int width,
                       int height, const rthip_shard* shard, void* stream);
+/* Progressive rendering: the same, but the frame is ADDED to what d_accum_rgb holds (pixels of other ranks' tiles are
+ * left alone), so that frames of different seeds sum up in one buffer without a pass of their own; the caller divides
+ * by the number of frames in the end.  The reference gets more samples only through `samples` of one cast
+ * (raytracer_cpu.c:196-236); no counterpart there.  Accumulating casts into ONE buffer must not overlap each other
+ * (use one accumulator per stream). */
+int rthip_cast_accumulate_device(rthip_ctx* ctx, const rthip_cast_settings* cast, uint64_t seed, float* d_accum_rgb,
+                                 int width, int height, const rthip_shard* shard, void* stream);
 
 /* ---- parity and measurement taps -------------------------------------- */
 

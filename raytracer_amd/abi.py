@@ -74,6 +74,7 @@ SYMBOLS = [
     ("rthip_tlas_build", C.c_int, [_P, _P, C.c_uint32, _P, C.c_uint32]),
     ("rthip_cast", C.c_int, [_P, _P, C.c_uint64, _P, C.c_int, C.c_int]),
     ("rthip_cast_device", C.c_int, [_P, _P, C.c_uint64, _P, C.c_int, C.c_int, _P, _P]),
+    ("rthip_cast_accumulate_device", C.c_int, [_P, _P, C.c_uint64, _P, C.c_int, C.c_int, _P, _P]),
     ("rthip_lbvh_build", C.c_int, [_P, _P, C.c_uint64, _P, _P, _P, _P, _P]),
     ("rthip_lbvh_build_device", C.c_int, [_P, _P, C.c_uint64, _P, _P]),
     ("rthip_mesh_build_device", C.c_int, [_P, _P, _P, _P, C.c_uint32, _P, C.c_uint64, _P, _P]),

@@ -152,6 +152,7 @@ void rthip_destroy(rthip_ctx* ctx) {
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     rthip_release(ctx->tune_counters);
+    rthip_release(ctx->tune_frame);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -433,6 +434,15 @@ int rthip_cast_device(rthip_ctx* ctx, const rthip_cast_settings* cast, uint64_t 
     RT_HIP(ctx, hipSetDevice(ctx->device));
     return cast_launch(ctx, make_scene(ctx), *cast, seed, d_out_rgb, width, height, sh, counters_or_null(ctx),
                        (hipStream_t)stream);
+}
+
+int rthip_cast_accumulate_device(rthip_ctx* ctx, const rthip_cast_settings* cast, uint64_t seed, float* d_accum_rgb, int width,
+                                 int height, const rthip_shard* shard, void* stream) {
+    if (!ctx) return RTHIP_E_INVALID;
+    ctx->cast_accumulate = 1;
+    const int rc = rthip_cast_device(ctx, cast, seed, d_accum_rgb, width, height, shard, stream);
+    ctx->cast_accumulate = 0;
+    return rc;
 }
 
 int rthip_cast(rthip_ctx* ctx, const rthip_cast_settings* cast, uint64_t seed, float* out_rgb, int width, int height) {

@@ -165,6 +165,8 @@ struct rthip_ctx {
     // build and tracer setting
     uint64_t scene_generation = 0;
     DevBuf tune_counters;
+    DevBuf tune_frame;           // framebuffer of the probe when the cast itself accumulates
+    uint32_t cast_accumulate = 0;  // set for the duration of rthip_cast_accumulate_device: pixels are added, not stored
     bool tuned = false;
     uint64_t tuned_key[4] = {0, 0, 0, 0};
     int tuned_kernel = 1;

@@ -28,11 +28,25 @@ namespace {
 // prefix; there is no global queue and no lane ever waits for another wave.
 enum : uint32_t { ST_NEED_PIXEL = 0, ST_NEED_SAMPLE = 1, ST_TRAVERSE = 2, ST_SHADE = 3, ST_DONE = 4 };
 
+// A pixel's result goes to the framebuffer, or is added to it (progressive accumulation: rthip_cast_accumulate_device).
+__device__ __forceinline__ void put_pixel(float* __restrict__ out, uint32_t pixel, V3 v, uint32_t accumulate) {
+    float* o3 = out + 3 * (size_t)pixel;
+    if (accumulate) {
+        o3[0] = o3[0] + v.x;
+        o3[1] = o3[1] + v.y;
+        o3[2] = o3[2] + v.z;
+    } else {
+        o3[0] = v.x;
+        o3[1] = v.y;
+        o3[2] = v.z;
+    }
+}
+
 template <bool COUNT, bool DEFER>
 __global__ __launch_bounds__(kBlock, 5) void cast_kernel(DevScene S, rthip_cast_settings c, uint64_t seed,
                                                       float* __restrict__ out, int width, int height,
                                                       rthip_shard shard, uint32_t* work_counters, uint32_t refill, uint32_t inst_batch,
-                                                      uint64_t* counters) {
+                                                      uint32_t accumulate, uint64_t* counters) {
     extern __shared__ uint32_t bounce_stack[];
     uint32_t* stack = bounce_stack + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63;
@@ -70,10 +84,7 @@ __global__ __launch_bounds__(kBlock, 5) void cast_kernel(DevScene S, rthip_cast_
                 while (sidx < spp && (sidx % shard.world) != shard.rank) sidx++;
             if (sidx >= spp) {
                 if (shard.mode != 2) acc = scale(acc, 1.f / ((float)samples * (float)samples));
-                float* o3 = out + 3 * (size_t)pixel;
-                o3[0] = acc.x;
-                o3[1] = acc.y;
-                o3[2] = acc.z;
+                put_pixel(out, pixel, acc, accumulate);
                 state = ST_NEED_PIXEL;
             }
         }
@@ -124,11 +135,8 @@ __global__ __launch_bounds__(kBlock, 5) void cast_kernel(DevScene S, rthip_cast_
                         if (shard.mode == 2)
                             while (sidx < spp && (sidx % shard.world) != shard.rank) sidx++;
                         state = ST_NEED_SAMPLE;
-                    } else {  // another rank's tile: this rank's share of the pixel is 0
-                        float* o3 = out + 3 * (size_t)pixel;
-                        o3[0] = 0.f;
-                        o3[1] = 0.f;
-                        o3[2] = 0.f;
+                    } else if (!accumulate) {  // another rank's tile: this rank's share of the pixel is 0
+                        put_pixel(out, pixel, mk(0.f, 0.f, 0.f), 0u);
                     }
                 }
                 // positions outside the image (partial tiles) and foreign pixels: the lane asks again
@@ -229,7 +237,7 @@ __device__ __forceinline__ bool pixel_of_thread(int width, int height, int& x, i
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock, RT_STATIC_WAVES) void cast_static_kernel(DevScene S, rthip_cast_settings c, uint64_t seed,
                                                              float* __restrict__ out, int width, int height,
-                                                             rthip_shard shard, uint64_t* counters) {
+                                                             rthip_shard shard, uint32_t accumulate, uint64_t* counters) {
     extern __shared__ uint32_t bounce_stack[];
     uint32_t* stack = bounce_stack + threadIdx.x;
     int x, y;
@@ -273,10 +281,7 @@ __global__ __launch_bounds__(kBlock, RT_STATIC_WAVES) void cast_static_kernel(De
                 }
             if (shard.mode != 2) acc = scale(acc, 1.f / ((float)samples * (float)samples));
         }
-        float* o3 = out + 3 * (size_t)pixel;
-        o3[0] = acc.x;
-        o3[1] = acc.y;
-        o3[2] = acc.z;
+        if (mine || !accumulate) put_pixel(out, pixel, acc, accumulate);
     }
 #ifdef RT_STAMP
     {
@@ -308,7 +313,8 @@ __global__ __launch_bounds__(kBlock, RT_STATIC_WAVES) void cast_static_kernel(De
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock, RT_STATIC_WAVES) void cast_samples_kernel(DevScene S, rthip_cast_settings c, uint64_t seed,
                                                               float* __restrict__ out, int width, int height,
-                                                              rthip_shard shard, uint32_t log2_group, uint64_t* counters) {
+                                                              rthip_shard shard, uint32_t log2_group, uint32_t accumulate,
+                                                              uint64_t* counters) {
     extern __shared__ uint32_t bounce_stack[];
     uint32_t* stack = bounce_stack + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -358,10 +364,7 @@ __global__ __launch_bounds__(kBlock, RT_STATIC_WAVES) void cast_samples_kernel(D
     }
     if (inside && sidx == 0) {
         if (mine && shard.mode != 2) acc = scale(acc, 1.f / ((float)samples * (float)samples));
-        float* o3 = out + 3 * (size_t)pixel;
-        o3[0] = acc.x;
-        o3[1] = acc.y;
-        o3[2] = acc.z;
+        if (mine || !accumulate) put_pixel(out, pixel, acc, accumulate);
     }
     if (COUNT) flush_counters(counters, cnt, rays);
 }
@@ -661,9 +664,9 @@ int launch_static(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_settin
     const size_t lds = (size_t)(scene.max_bounces ? scene.max_bounces : 1) * kBlock * sizeof(uint32_t);
     const uint32_t blocks = div_up(width, 16) * div_up(height, 16);
     if (d_counters)
-        cast_static_kernel<true><<<blocks, kBlock, lds, stream>>>(scene, cast, seed, d_rgb, width, height, shard, d_counters);
+        cast_static_kernel<true><<<blocks, kBlock, lds, stream>>>(scene, cast, seed, d_rgb, width, height, shard, ctx->cast_accumulate, d_counters);
     else
-        cast_static_kernel<false><<<blocks, kBlock, lds, stream>>>(scene, cast, seed, d_rgb, width, height, shard, nullptr);
+        cast_static_kernel<false><<<blocks, kBlock, lds, stream>>>(scene, cast, seed, d_rgb, width, height, shard, ctx->cast_accumulate, nullptr);
     RT_HIP(ctx, hipGetLastError());
     return RTHIP_OK;
 }
@@ -676,9 +679,9 @@ int launch_samples(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_setti
     const uint32_t tile = log2_group == 2 ? 8u : (log2_group == 4 ? 4u : 2u);  // pixels a workgroup covers, per side
     const uint32_t blocks = div_up(width, tile) * div_up(height, tile);
     if (d_counters)
-        cast_samples_kernel<true><<<blocks, kBlock, lds, stream>>>(scene, cast, seed, d_rgb, width, height, shard, log2_group, d_counters);
+        cast_samples_kernel<true><<<blocks, kBlock, lds, stream>>>(scene, cast, seed, d_rgb, width, height, shard, log2_group, ctx->cast_accumulate, d_counters);
     else
-        cast_samples_kernel<false><<<blocks, kBlock, lds, stream>>>(scene, cast, seed, d_rgb, width, height, shard, log2_group, nullptr);
+        cast_samples_kernel<false><<<blocks, kBlock, lds, stream>>>(scene, cast, seed, d_rgb, width, height, shard, log2_group, ctx->cast_accumulate, nullptr);
     RT_HIP(ctx, hipGetLastError());
     return RTHIP_OK;
 }
@@ -698,7 +701,7 @@ int launch_persistent(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_se
     const bool defer = inst_batch != 0;
 #define RT_LAUNCH_CAST(COUNT, DEFER, CNT)                                                                              \
     cast_kernel<COUNT, DEFER><<<blocks, kBlock, lds, stream>>>(scene, cast, seed, d_rgb, width, height, shard, work, \
-                                                               refill, inst_batch, CNT)
+                                                               refill, inst_batch, ctx->cast_accumulate, CNT)
     if (d_counters) {
         if (defer) RT_LAUNCH_CAST(true, true, d_counters);
         else RT_LAUNCH_CAST(true, false, d_counters);
@@ -801,7 +804,17 @@ int cast_launch(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_settings
         if (ctx->tuned && memcmp(key, ctx->tuned_key, sizeof key) == 0) {
             choice = {ctx->tuned_kernel, ctx->tuned_refill, ctx->tuned_inst_batch};
         } else if (paths >= (1ull << 20) && capturing == hipStreamCaptureStatusNone) {
-            RT_TRY(tune_cast(ctx, scene, cast, seed, d_rgb, width, height, shard, stream, &choice));
+            // the probe renders into the framebuffer; an accumulating cast gives it a buffer of its own instead
+            float* probe_rgb = d_rgb;
+            const uint32_t accumulate = ctx->cast_accumulate;
+            if (accumulate) {
+                RT_TRY(rthip_reserve(ctx, ctx->tune_frame, (size_t)width * height * 3 * sizeof(float)));
+                probe_rgb = (float*)ctx->tune_frame.p;
+            }
+            ctx->cast_accumulate = 0;
+            const int rc_tune = tune_cast(ctx, scene, cast, seed, probe_rgb, width, height, shard, stream, &choice);
+            ctx->cast_accumulate = accumulate;
+            RT_TRY(rc_tune);
             ctx->tuned = true;
             memcpy(ctx->tuned_key, key, sizeof key);
             ctx->tuned_kernel = choice.kernel;

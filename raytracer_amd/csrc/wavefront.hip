@@ -216,7 +216,8 @@ __global__ __launch_bounds__(kBlock) void wf_shade_kernel(DevScene S, WfArrays A
 // `*c = add(*c, sample)` over the samples in order, then `*c = mul(*c, inv_sample_count)`,
 // raytracer_cpu.c:190-239
 __global__ __launch_bounds__(kBlock) void wf_resolve_kernel(rthip_cast_settings c, int width, int height, rthip_shard shard,
-                                                            WfArrays A, WfBatch B, float* __restrict__ out) {
+                                                            WfArrays A, WfBatch B, float* __restrict__ out,
+                                                            uint32_t accumulate) {
     const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
     if (k >= B.n_paths / B.spp) return;
     uint32_t px, py;
@@ -233,9 +234,15 @@ __global__ __launch_bounds__(kBlock) void wf_resolve_kernel(rthip_cast_settings 
         if (shard.mode != 2) acc = scale(acc, 1.f / ((float)samples * (float)samples));
     }
     float* o3 = out + 3 * ((size_t)py * width + px);
-    o3[0] = acc.x;
-    o3[1] = acc.y;
-    o3[2] = acc.z;
+    if (accumulate) {  // rthip_cast_accumulate_device: the frame is added to what the buffer holds
+        o3[0] = o3[0] + acc.x;
+        o3[1] = o3[1] + acc.y;
+        o3[2] = o3[2] + acc.z;
+    } else {
+        o3[0] = acc.x;
+        o3[1] = acc.y;
+        o3[2] = acc.z;
+    }
 }
 
 inline uint32_t div_up(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
@@ -301,7 +308,7 @@ int cast_wavefront_launch(rthip_ctx* ctx, const DevScene& scene, const rthip_cas
                 wf_trace_kernel<false><<<tblocks, kBlock, 0, stream>>>(scene, A, B.n_paths, wf_refill, nullptr);
             wf_shade_kernel<<<pblocks, kBlock, 0, stream>>>(scene, A, B.n_paths);
         }
-        wf_resolve_kernel<<<div_up(npos, kBlock), kBlock, 0, stream>>>(cast, width, height, shard, A, B, d_rgb);
+        wf_resolve_kernel<<<div_up(npos, kBlock), kBlock, 0, stream>>>(cast, width, height, shard, A, B, d_rgb, ctx->cast_accumulate);
         RT_HIP(ctx, hipGetLastError());
     }
     return RTHIP_OK;

@@ -378,6 +378,44 @@ def test_casts_on_several_streams_overlap_without_changing_a_bit(gpu_tracer, ker
         T.set_cast_kernel(gpu_tracer, "auto")
 
 
+@pytest.mark.parametrize("kernel", ["persistent", "static", "static-samples", "wavefront", "auto"])
+def test_accumulating_cast_adds_the_frame(gpu_tracer, kernel):
+    """rthip_cast_accumulate_device: buffer + frame, pixel by pixel in binary32, for every kernel; under a tile shard the
+    other ranks' pixels keep their value; with the probe of the automatic choice (a frame of >= 2^20 paths)."""
+    import torch
+
+    verts, indices = scenes.bunny_class_mesh(3)
+    w, cam, sky = scenes.cornell(extra_mesh=(verts, indices))
+    build(gpu_tracer, w, 4, sky)
+    stream = torch.cuda.current_stream().cuda_stream
+    T.set_cast_kernel(gpu_tracer, kernel)
+    try:
+        for (wd, ht, smp, shard) in ((90, 70, 2, None), (130, 64, 1, (1, 1, 2)), (40, 40, 2, (2, 0, 3))) + \
+                (((1100, 1000, 1, None),) if kernel == "auto" else ()):
+            c = cam(wd, ht, smp)
+            sh = None
+            if shard:
+                sh = np.zeros(1, dtype=abi.SHARD)
+                sh[0] = shard
+            base = torch.rand((ht, wd, 3), dtype=torch.float32, device="cuda:0") * 3.0
+            want = base.clone()
+            acc = base.clone()
+            for seed in (5, 6, 7):
+                frame = torch.zeros((ht, wd, 3), dtype=torch.float32, device="cuda:0")
+                gpu_tracer.check(gpu_tracer.lib.rthip_cast_device(gpu_tracer.h, abi.ptr(c), seed, frame.data_ptr(), wd, ht,
+                                                                  abi.ptr(sh) if shard else None, stream), "rthip_cast_device")
+                want += frame
+                gpu_tracer.check(gpu_tracer.lib.rthip_cast_accumulate_device(gpu_tracer.h, abi.ptr(c), seed, acc.data_ptr(), wd, ht,
+                                                                             abi.ptr(sh) if shard else None, stream),
+                                 "rthip_cast_accumulate_device")
+            torch.cuda.synchronize()
+            assert torch.equal(acc.view(torch.int32), want.view(torch.int32)), (kernel, wd, ht, shard)
+            if shard and shard[0] == 1:  # pixels of the other rank's 64x64 tiles are untouched
+                assert torch.equal(acc[:, 0:64].view(torch.int32), base[:, 0:64].view(torch.int32))
+    finally:
+        T.set_cast_kernel(gpu_tracer, "auto")
+
+
 def test_cornell_with_mesh_scene(oracle, gpu_tracer):
     """The multi-GPU configuration's scene (Cornell box + a metal PN mesh): trees, radiance and a tile shard."""
     verts, indices = scenes.bunny_class_mesh(3)
