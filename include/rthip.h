@@ -31,7 +31,9 @@
  *     the GPU while another's last waves drain; measured 1.1x to 2.8x the frames
  *     per second of one stream), each into its own framebuffer, at most 64 of them
  *     unfinished at a time, and not with RTHIP_KERNEL_WAVEFRONT or with counting
- *     on, whose buffers belong to the context.
+ *     on, whose buffers belong to the context.  A cast on a stream that is being
+ *     captured becomes graph nodes (kernels only; RTHIP_KERNEL_AUTO skips its probe
+ *     then); the graph may be replayed as long as the scene is not rebuilt.
  */
 #ifndef RTHIP_H
 #define RTHIP_H

@@ -125,7 +125,8 @@ int rthip_create(rthip_ctx** out_ctx, int device_id) {
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
         rthip_reserve(ctx, ctx->counters, 64) != RTHIP_OK || hipMemset(ctx->counters.p, 0, 64) != hipSuccess ||
-        rthip_reserve(ctx, ctx->work_ring, kWorkSlots * 1024) != RTHIP_OK) {
+        rthip_reserve(ctx, ctx->work_ring, kWorkSlots * 1024) != RTHIP_OK ||
+        hipMemset(ctx->work_ring.p, 0, kWorkSlots * 1024) != hipSuccess) {
         rthip_destroy(ctx);
         return RTHIP_E_HIP;
     }

@@ -42,6 +42,19 @@ __device__ __forceinline__ void put_pixel(float* __restrict__ out, uint32_t pixe
     }
 }
 
+// End of a persistent kernel: the slot of work counters is left zeroed for its next user by the last wave to get here
+// (every wave counts itself in word 16 when it has stopped taking work; no barrier, a finished wave leaves at once).
+// No memset between launches, so a launch is one graph node and replays of a captured graph start from zeroed counters.
+__device__ __forceinline__ void work_slot_release(uint32_t* work) {
+    if ((threadIdx.x & 63u) == 0) {
+        const uint32_t arrived = atomicAdd(&work[16], 1u);
+        if (arrived == gridDim.x * (kBlock / 64) - 1u) {
+            for (uint32_t k = 0; k < 8u; k++) atomicExch(&work[k * 32u], 0u);
+            atomicExch(&work[16], 0u);
+        }
+    }
+}
+
 template <bool COUNT, bool DEFER>
 __global__ __launch_bounds__(kBlock, 5) void cast_kernel(DevScene S, rthip_cast_settings c, uint64_t seed,
                                                       float* __restrict__ out, int width, int height,
@@ -211,6 +224,7 @@ __global__ __launch_bounds__(kBlock, 5) void cast_kernel(DevScene S, rthip_cast_
             }
         }
     }
+    work_slot_release(work_counters);
     if (COUNT) flush_counters(counters, cnt, rays);
 }
 
@@ -560,6 +574,7 @@ __global__ __launch_bounds__(kBlock) void trace_rays_persistent_kernel(DevScene 
             if (n_idle == 64u || (!exhausted && n_idle >= refill)) break;
         }
     }
+    work_slot_release(work_counter);
     if (COUNT) flush_counters(counters, cnt, rays);
 }
 
@@ -594,8 +609,7 @@ int trace_rays_launch(rthip_ctx* ctx, const DevScene& scene, const float* d_o, c
     if (n >= (1ull << 18) && n < (1ull << 32) * kRayGrab && resident) {
         uint32_t blocks = div_up(n, kBlock);
         if (blocks > ctx->persistent_blocks) blocks = ctx->persistent_blocks;
-        uint32_t* work = (uint32_t*)ctx->work_ring.p + (size_t)(ctx->work_next++ % kWorkSlots) * 256u;
-        RT_HIP(ctx, hipMemsetAsync(work, 0, 1024, stream));
+        uint32_t* work = (uint32_t*)ctx->work_ring.p + (size_t)(ctx->work_next++ % kWorkSlots) * 256u;  // zeroed: see work_slot_release
         if (d_counters)
             trace_rays_persistent_kernel<true><<<blocks, kBlock, 0, stream>>>(scene, d_o, d_d, n, d_hits4, d_uv, d_normal,
                                                                              work, ctx->refill_lanes, d_counters);
@@ -694,10 +708,10 @@ int launch_persistent(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_se
     uint32_t blocks = div_up(total, kBlock);
     if (blocks > ctx->persistent_blocks) blocks = ctx->persistent_blocks;
     const size_t lds = (size_t)(scene.max_bounces ? scene.max_bounces : 1) * kBlock * sizeof(uint32_t);
-    // every launch gets its own zeroed set of 8 work counters (one 128-byte line each) out of a ring of
-    // kWorkSlots, so that casts enqueued back to back or on several streams do not share them
+    // every launch gets its own set of 8 work counters (one 128-byte line each) out of a ring of kWorkSlots, so that
+    // casts enqueued back to back or on several streams do not share them; a slot is zero when a launch starts (the
+    // ring is zeroed once, and every launch leaves its slot zeroed: work_slot_release)
     uint32_t* work = (uint32_t*)ctx->work_ring.p + (size_t)(ctx->work_next++ % kWorkSlots) * 256u;
-    RT_HIP(ctx, hipMemsetAsync(work, 0, 1024, stream));
     const bool defer = inst_batch != 0;
 #define RT_LAUNCH_CAST(COUNT, DEFER, CNT)                                                                              \
     cast_kernel<COUNT, DEFER><<<blocks, kBlock, lds, stream>>>(scene, cast, seed, d_rgb, width, height, shard, work, \

@@ -416,6 +416,48 @@ def test_accumulating_cast_adds_the_frame(gpu_tracer, kernel):
         T.set_cast_kernel(gpu_tracer, "auto")
 
 
+@pytest.mark.parametrize("kernel", ["static", "persistent", "auto"])
+def test_casts_can_be_captured_in_a_hip_graph(gpu_tracer, kernel):
+    """rthip_cast_device only enqueues work, so a stream capture can record it (the automatic kernel choice skips its
+    probe while capturing); the replayed graph must write the same frames."""
+    import torch
+
+    verts, indices = scenes.bunny_class_mesh(3)
+    w, cam, sky = scenes.cornell(extra_mesh=(verts, indices))
+    build(gpu_tracer, w, 4, sky)
+    wd, ht = 1100, 1000  # >= 2^20 paths: a frame for which the automatic choice would probe outside a capture
+    c = cam(wd, ht, 1)
+    T.set_cast_kernel(gpu_tracer, kernel)
+    try:
+        bufs = [torch.zeros((ht, wd, 3), dtype=torch.float32, device="cuda:0") for _ in range(3)]
+        side = torch.cuda.Stream()
+        graph = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(graph, stream=side):
+            for k, b in enumerate(bufs):
+                gpu_tracer.check(gpu_tracer.lib.rthip_cast_device(gpu_tracer.h, abi.ptr(c), 40 + k, b.data_ptr(), wd, ht, None,
+                                                                  torch.cuda.current_stream().cuda_stream), "rthip_cast_device")
+        for b in bufs:
+            b.fill_(-1.0)
+        graph.replay()
+        torch.cuda.synchronize()
+        first = [b.clone() for b in bufs]
+        for b in bufs:
+            b.fill_(-2.0)
+        graph.replay()
+        torch.cuda.synchronize()
+        T.set_cast_kernel(gpu_tracer, "static")
+        for k, b in enumerate(bufs):
+            want = torch.zeros((ht, wd, 3), dtype=torch.float32, device="cuda:0")
+            gpu_tracer.check(gpu_tracer.lib.rthip_cast_device(gpu_tracer.h, abi.ptr(c), 40 + k, want.data_ptr(), wd, ht, None,
+                                                              torch.cuda.current_stream().cuda_stream), "rthip_cast_device")
+            torch.cuda.synchronize()
+            assert torch.equal(b.view(torch.int32), want.view(torch.int32)), f"replay 2, frame {k}"
+            assert torch.equal(first[k].view(torch.int32), want.view(torch.int32)), f"replay 1, frame {k}"
+    finally:
+        T.set_cast_kernel(gpu_tracer, "auto")
+
+
 def test_cornell_with_mesh_scene(oracle, gpu_tracer):
     """The multi-GPU configuration's scene (Cornell box + a metal PN mesh): trees, radiance and a tile shard."""
     verts, indices = scenes.bunny_class_mesh(3)
