@@ -31,6 +31,10 @@ constexpr int kBlock = 256;
 constexpr int kSortBlock = 1024;                    // threads per workgroup in the radix kernels
 constexpr int kSortItems = 4;                       // keys per thread
 constexpr int kSortTile = kSortBlock * kSortItems;  // 4096 keys per workgroup
+// Sorts of up to 4 tiles (16384 keys) run one kernel per pass.  Measured build time, separate / fused passes: 600
+// boxes 0.119 / 0.096 ms, 4096: 0.160 / 0.130, 8192: 0.168 / 0.151, 20000: 0.180 / 0.173, 40000: 0.187 / 0.196 (the
+// per-workgroup sum over the tiles and the atomics grow with the input, the saved launches do not).
+constexpr uint32_t kFusedTiles = 4;
 constexpr int kScanItems = 8;
 constexpr int kScanTile = kBlock * kScanItems;  // 2048 values per workgroup
 
@@ -283,11 +287,19 @@ __global__ __launch_bounds__(kBlock) void radix_offsets_kernel(uint32_t* __restr
 // Each workgroup ranks its 4096 keys by the current digit (wave-level match-any on
 // ballots, wave-private LDS counters), sorts the tile in LDS and writes every digit
 // bucket to its place in the output with consecutive lanes on consecutive addresses.
+//
+// FUSED (sorts of at most kFusedTiles tiles, where the chain of dependent launches costs more than the work): the
+// kernel is the whole pass.  gbase is then the RAW tile histogram of this pass's digit (every workgroup sums the rows
+// itself: 256 x tiles counters), the keys' NEXT digit is counted into hist_next by the tile the key lands in (global
+// atomics: cheap at these sizes), and hist_zero -- the table of the pass after next -- is cleared on the way.
+template <bool FUSED>
 __global__ __launch_bounds__(kSortBlock) void radix_scatter_kernel(const uint64_t* __restrict__ keys_in,
                                                                    const uint32_t* __restrict__ vals_in,
                                                                    uint64_t* __restrict__ keys_out,
                                                                    uint32_t* __restrict__ vals_out, uint64_t n, int shift,
-                                                                   const uint32_t* __restrict__ gbase, uint32_t tiles) {
+                                                                   const uint32_t* __restrict__ gbase, uint32_t tiles,
+                                                                   uint32_t* __restrict__ hist_next,
+                                                                   uint32_t* __restrict__ hist_zero) {
     // gbase[d * tiles + t]: keys with digit d in the tiles before t; gbase[256 * tiles + d]: keys with digit d
     constexpr int kWaves = kSortBlock / 64;
     __shared__ uint32_t wave_cnt[kWaves][256];
@@ -345,7 +357,19 @@ __global__ __launch_bounds__(kSortBlock) void radix_scatter_kernel(const uint64_
                 run += c;
             }
         }
-        const uint32_t total = owner ? gbase[256ull * tiles + tid] : 0u;
+        uint32_t total = 0, before_tile = 0;
+        if (owner) {
+            if (FUSED) {
+                for (uint32_t t = 0; t < tiles; t++) {
+                    const uint32_t c = gbase[(uint64_t)tid * tiles + t];
+                    before_tile += t < blockIdx.x ? c : 0u;
+                    total += c;
+                }
+            } else {
+                total = gbase[256ull * tiles + tid];
+                before_tile = gbase[(uint64_t)tid * tiles + blockIdx.x];
+            }
+        }
         uint32_t incl = run, dincl = total;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -369,7 +393,7 @@ __global__ __launch_bounds__(kSortBlock) void radix_scatter_kernel(const uint64_
             const uint32_t start = wsum + incl - run;
             bin_start[tid] = start;
             // first output position of digit d = keys with a smaller digit + keys with digit d in earlier tiles
-            out_base[tid] = (dsum + dincl - total) + gbase[(uint64_t)tid * tiles + blockIdx.x] - start;
+            out_base[tid] = (dsum + dincl - total) + before_tile - start;
         }
     }
     __syncthreads();
@@ -395,8 +419,12 @@ __global__ __launch_bounds__(kSortBlock) void radix_scatter_kernel(const uint64_
             uint32_t dst = out_base[d] + p;
             keys_out[dst] = k;
             vals_out[dst] = svals[p];
+            if (FUSED && hist_next)
+                atomicAdd(&hist_next[(uint64_t)((uint32_t)(k >> (shift + 8)) & 255u) * tiles + dst / (uint32_t)kSortTile], 1u);
         }
     }
+    if (FUSED && hist_zero)
+        for (uint32_t k = blockIdx.x * kSortBlock + tid; k < 256u * tiles; k += gridDim.x * kSortBlock) hist_zero[k] = 0u;
 }
 
 // ---- device-wide prefix sums of uint32 ------------------------------------------------
@@ -1000,13 +1028,34 @@ int radix_sort_workspace_device(rthip_ctx* ctx, uint64_t n, int n_bytes, hipStre
     uint64_t* keys[2] = {(uint64_t*)w.keys[0].p, (uint64_t*)w.keys[1].p};
     uint32_t* vals[2] = {(uint32_t*)w.vals[0].p, (uint32_t*)w.vals[1].p};
     int cur = *cur_io;
+    if (tiles <= kFusedTiles) {
+        // three tables in turn: pass p reads table p % 3, counts the next digit into table (p + 1) % 3 and clears
+        // table (p + 2) % 3, which pass p + 1 counts into
+        const size_t table = 256ull * tiles;
+        RT_TRY(rthip_reserve(ctx, w.block_hist, (3 * table + 256) * 4));
+        uint32_t* h = (uint32_t*)w.block_hist.p;
+        RT_HIP(ctx, hipMemsetAsync(h, 0, 3 * table * 4, s));
+        radix_hist_kernel<<<tiles, kSortBlock, 0, s>>>(keys[cur], n, 0, h, tiles);
+        RT_HIP(ctx, hipGetLastError());
+        for (int pass = 0; pass < n_bytes; pass++) {
+            const bool last = pass + 1 == n_bytes;
+            radix_scatter_kernel<true><<<tiles, kSortBlock, 0, s>>>(keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, pass * 8,
+                                                                h + (size_t)(pass % 3) * table, tiles,
+                                                                last ? nullptr : h + (size_t)((pass + 1) % 3) * table,
+                                                                last ? nullptr : h + (size_t)((pass + 2) % 3) * table);
+            RT_HIP(ctx, hipGetLastError());
+            cur ^= 1;
+        }
+        *cur_io = cur;
+        return RTHIP_OK;
+    }
     for (int pass = 0; pass < n_bytes; pass++) {
         const int shift = pass * 8;
         radix_hist_kernel<<<tiles, kSortBlock, 0, s>>>(keys[cur], n, shift, (uint32_t*)w.block_hist.p, tiles);
         RT_HIP(ctx, hipGetLastError());
         radix_offsets_kernel<<<256, kBlock, 0, s>>>((uint32_t*)w.block_hist.p, tiles);
-        radix_scatter_kernel<<<tiles, kSortBlock, 0, s>>>(keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, shift,
-                                                      (const uint32_t*)w.block_hist.p, tiles);
+        radix_scatter_kernel<false><<<tiles, kSortBlock, 0, s>>>(keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, shift,
+                                                             (const uint32_t*)w.block_hist.p, tiles, nullptr, nullptr);
         RT_HIP(ctx, hipGetLastError());
         cur ^= 1;
     }
