@@ -16,7 +16,7 @@ WORKLOADS="bunny cornell instanced soup cornell-mesh" bash tools/sweep_cast_kern
 cd /tmp; export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_default -- python3 $ROOT/bench.py --no-cpu-baseline > $OUT/prof_default.log 2>&1 || exit 1
 cd $ROOT
-bash tools/pmc_traffic.sh bunny instanced soup cornell soup-rays > $OUT/pmc_traffic.log 2>&1 || exit 1
+bash tools/pmc_traffic.sh bunny instanced soup cornell soup-rays instanced-rays cornell-mesh > $OUT/pmc_traffic.log 2>&1 || exit 1
 cp gpurun_out/traffic.json $OUT/traffic.json
 python3 tools/pmc_traffic.py gpurun_out/pmc_traffic $OUT/traffic.json > $OUT/pmc_traffic.txt
 python3 tools/build_breakdown.py $OUT/prof_default/*/*kernel_trace.csv > $OUT/build_10M_breakdown.txt
