@@ -65,3 +65,55 @@ def obj_written_columns(attrs: int, width: int):
             slot += 1
     assert slot == slots
     return np.array(cols)
+
+
+def build_and_check_invariants(gpu_tracer, n, seed=3, builds=2):
+    """Builds the BLAS tree of n seeded random triangles on the GPU (vertices generated there) and checks what holds
+    at any size: a well-formed pre-order tree, every primitive in exactly one leaf with its own box, every inner box
+    the exact merge of its two children, and the same bits from every build.  Returns the last build's milliseconds."""
+    import torch
+
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    cen = torch.rand((n, 1, 3), device="cuda", generator=g)
+    off = (torch.rand((n, 3, 3), device="cuda", generator=g) * 2 - 1) * 0.001
+    p = (cen + off).reshape(3 * n, 3).float()
+    del cen, off
+    px, py, pz = (p[:, k].contiguous() for k in range(3))
+    stream = torch.cuda.current_stream().cuda_stream
+    N = 2 * n - 1
+    first = None
+    for _ in range(builds):
+        nodes = torch.empty((N, 8), dtype=torch.float32, device="cuda")
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        gpu_tracer.check(gpu_tracer.lib.rthip_mesh_build_device(gpu_tracer.h, px.data_ptr(), py.data_ptr(), pz.data_ptr(),
+                                                                3 * n, None, n, nodes.data_ptr(), stream), "build")
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1)
+        if first is None:
+            first = nodes
+        else:
+            assert torch.equal(first.view(torch.int32), nodes.view(torch.int32)), "two builds differ"
+            del nodes
+    nodes = first
+    ints = nodes.view(torch.int32)
+    skip, ids = ints[:, 3].long(), ints[:, 7].long()
+    idx = torch.arange(N, device="cuda")
+    assert int(skip[0]) == N and bool(((skip > idx) & (skip <= N)).all())
+    leaf = ids != 0
+    assert int(leaf.sum()) == n and bool((skip[leaf] == idx[leaf] + 1).all())
+    assert bool((torch.sort(ids[leaf]).values == torch.arange(1, n + 1, device="cuda")).all()), "ids are not a permutation"
+    # leaf boxes are the triangles' own boxes
+    tri = p.reshape(n, 3, 3)
+    prim = ids[leaf] - 1
+    assert torch.equal(nodes[leaf][:, 0:3], tri.min(dim=1).values[prim]) and torch.equal(nodes[leaf][:, 4:7], tri.max(dim=1).values[prim])
+    # inner node i: children i + 1 and skip[i + 1]; box = exact merge
+    inner = idx[~leaf]
+    left = inner + 1
+    right = skip[left]
+    assert bool((right < N).all()) and bool((skip[right] == skip[inner]).all()), "right child does not end where the parent ends"
+    assert torch.equal(nodes[inner][:, 0:3], torch.minimum(nodes[left][:, 0:3], nodes[right][:, 0:3]))
+    assert torch.equal(nodes[inner][:, 4:7], torch.maximum(nodes[left][:, 4:7], nodes[right][:, 4:7]))
+    return ms
