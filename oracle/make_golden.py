@@ -271,6 +271,39 @@ def write_obj():
     np.savez_compressed(os.path.join(OUT, "obj.npz"), **out)
 
 
+WORLD_SEEDS = range(5000, 5048)
+
+
+def nan_free(a):
+    """NaNs replaced by one fixed pattern before hashing (their sign and payload belong to the hardware)."""
+    a = np.array(a, dtype=np.float32, copy=True)
+    a[np.isnan(a)] = np.float32(12345.0)
+    return a
+
+
+def write_worlds():
+    """The reference's answers on seeded random worlds (scenes.random_world without coincident triangles): closest
+    hits of 600 random rays and a small path-traced frame drawn with glibc's rand() after srand(seed)."""
+    out = {"seeds": np.array(list(WORLD_SEEDS), dtype=np.uint32)}
+    hits = 0
+    for seed in WORLD_SEEDS:
+        w, sky, bounces, o, d, cast = scenes.random_world_case(seed)
+        rs = O.RefScene(world.flatten_world(w), bounces, sky)
+        inst, tri, t, uv, nrm, _ = rs.trace(o, d)
+        rgb, _ = rs.cast(cast, seed, 24, 16)
+        rs.close()
+        hits += int((inst > 0).sum())
+        out[f"w{seed}_ref_inst"] = inst
+        out[f"w{seed}_ref_tri"] = tri
+        out[f"w{seed}_ref_t"] = t
+        out[f"w{seed}_ref_uv_sha"] = sha(uv)
+        out[f"w{seed}_ref_normal_sha"] = sha(nan_free(nrm))
+        out[f"w{seed}_ref_rgb"] = rgb
+    print("worlds", len(WORLD_SEEDS), "hits", hits)
+    np.savez_compressed(os.path.join(OUT, "random_worlds.npz"), **out)
+
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     assert O.have_ref("core"), "build oracle/_ref first: make -C oracle ref"
@@ -289,6 +322,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "hdr":
         write_hdr()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "worlds":
+        write_worlds()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "edges":
         write_edges()
         sys.exit(0)
@@ -301,3 +337,4 @@ if __name__ == "__main__":
     write_hdr()
     write_obj()
     write_ray_records()
+    write_worlds()

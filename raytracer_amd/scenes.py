@@ -601,3 +601,110 @@ def obj_test_files(seed: int = 3):
     lines += ["f %d//%d %d//%d %d//%d" % (a, x, b, y, c, z) for (a, b, c), (x, y, z) in zip(fp, fn)]
     out["pn_random_big"] = ("\n".join(lines) + "\n", 3)
     return out
+
+
+def random_world(seed: int, coincident: bool = True):
+    """A seeded random world for fuzzing the parity tests: 1-3 small meshes (indexed or auto-indexed, with or
+    without normals, some triangles degenerate and, with `coincident`, some duplicated or sharing their box --
+    equal Morton codes, whose order the reference's unstable sort leaves open), 2-12 instances (meshes under random rotations,
+    translations and non-uniform scales, and spheres, some overlapping), every material type with random
+    parameters (and a few instances with no material), and a random camera (perspective, orthographic, or with
+    defocus).  Returns (world, cast_settings_fn(width, height, samples), sky, max_bounces)."""
+    rng = np.random.default_rng(seed)
+    w = rt_make_world()
+    meshes = []
+    for _ in range(int(rng.integers(1, 4))):
+        n_verts = int(rng.integers(3, 40))
+        with_normals = bool(rng.integers(0, 2))
+        attrs = GEO_P | (GEO_N if with_normals else 0)
+        pos = rng.uniform(-1, 1, (n_verts, 3)).astype(np.float32)
+        if rng.integers(0, 3) == 0 and coincident:  # quantised positions: coincident vertices, axis-aligned and zero-area triangles
+            pos = (np.round(pos * 2) / 2).astype(np.float32)
+        cols = [np.concatenate([pos, np.zeros((n_verts, 1), np.float32)], axis=1)]
+        if with_normals:
+            nr = rng.normal(size=(n_verts, 3)).astype(np.float32)
+            cols.append(np.concatenate([nr, np.zeros((n_verts, 1), np.float32)], axis=1))
+        verts = np.concatenate(cols, axis=1).astype(np.float32)
+        m = rt_world_add_mesh(w)
+        if rng.integers(0, 3) == 0 and n_verts >= 6:  # auto-indexed: every three vertices are a triangle
+            keep = n_verts - n_verts % 3
+            _set_mesh(m, np.ascontiguousarray(verts[:keep]), None, attrs)
+        else:
+            n_tris = int(rng.integers(1, 60))
+            idx = rng.integers(0, n_verts, (n_tris, 3)).astype(np.uint32)
+            if n_tris > 2 and rng.integers(0, 2) == 0 and coincident:
+                idx[-1] = idx[0]  # a coincident pair: the tie goes to the later leaf
+            if not coincident:  # keep one triangle per bounding box, so that no two share a Morton code by construction
+                corners = pos[idx]
+                boxes = np.concatenate([corners.min(axis=1), corners.max(axis=1)], axis=1)
+                _, keep = np.unique(boxes, axis=0, return_index=True)
+                idx = idx[np.sort(keep)]
+            _set_mesh(m, verts, idx.reshape(-1), attrs)
+        meshes.append(m)
+    mats = []
+    for _ in range(int(rng.integers(2, 7))):
+        m = rt_world_add_material(w)
+        m.type = int(rng.integers(0, 5))
+        m.albedo = v3(*rng.uniform(0, 1, 3))
+        m.emissive = v3(*(rng.uniform(0, 4, 3) if (m.type == abi.MAT_LIGHT or rng.integers(0, 4) == 0) else (0, 0, 0)))
+        m.roughness = float(np.float32(rng.uniform(0, 1))) if rng.integers(0, 3) else 0.0
+        m.ior = float(np.float32(rng.uniform(1.0, 2.5)))
+        m.billboard = bool(rng.integers(0, 4) == 0)
+        mats.append(m)
+    for _ in range(int(rng.integers(2, 13))):
+        it = rt_world_add_instance(w)
+        it.material = None if rng.integers(0, 8) == 0 else mats[int(rng.integers(0, len(mats)))]
+        if rng.integers(0, 3) == 0:
+            it.type = abi.INST_SPHERE
+            it.sphere_center = v3(*rng.uniform(-3, 3, 3))
+            it.sphere_radius = np.float32(rng.uniform(0.2, 1.5))
+        else:
+            it.type = abi.INST_MESH
+            it.mesh = meshes[int(rng.integers(0, len(meshes)))]
+            it.translation = v3(*rng.uniform(-3, 3, 3))
+            if rng.integers(0, 4) == 0:
+                it.rotation = IDENTITY_QUAT
+            else:
+                a, b = rng.normal(size=3), rng.normal(size=3)
+                it.rotation = make_a_to_b_quat(normalize3(v3(*a)), normalize3(v3(*b)))
+            s = rng.uniform(0.3, 3.0, 3) if rng.integers(0, 2) else np.full(3, rng.uniform(0.3, 3.0))
+            if rng.integers(0, 6) == 0:
+                s[int(rng.integers(0, 3))] *= -1  # a mirrored instance
+            it.scale = v3(*s)
+    eye = mul3(normalize3(v3(*rng.normal(size=3))), np.float32(rng.uniform(5, 9)))
+    subject = v3(*rng.uniform(-1, 1, 3))
+    mode = int(rng.integers(0, 3))
+    sky = bool(rng.integers(0, 4) != 0)
+    bounces = int(rng.integers(1, 13))
+
+    vfov = float(np.float32(rng.uniform(0.4, 1.4)))  # radians
+    defocus = float(np.float32(rng.uniform(0.005, 0.05)))
+
+    def camera(width, height, samples):
+        if mode == 0:
+            return get_rt_cast_settings(width, height, samples, eye, subject, vfov=vfov)
+        if mode == 1:
+            return get_rt_cast_settings(width, height, samples, eye, subject, orthographic=True, vfov=vfov)
+        return get_rt_cast_settings(width, height, samples, eye, subject, defocus_angle=defocus, vfov=vfov)
+
+    return w, camera, sky, bounces
+
+
+def aimed_rays(n: int, seed: int, reach: float = 6.0, spread: float = 3.0):
+    """Seeded rays from points in [-reach, reach]^3 towards points in [-spread, spread]^3 (where random_world puts
+    its instances), so that a good share of them hits something.  Returns float32 (origins[n, 3], directions[n, 3])."""
+    rng = np.random.default_rng(seed)
+    o = rng.uniform(-reach, reach, (n, 3)).astype(np.float32)
+    to = rng.uniform(-spread, spread, (n, 3)).astype(np.float32)
+    d = (to - o).astype(np.float32)
+    ln = np.sqrt((d * d).sum(axis=1, dtype=np.float32)).astype(np.float32)
+    ln[ln == 0] = np.float32(1)
+    return o, (d / ln[:, None]).astype(np.float32)
+
+
+def random_world_case(seed: int):
+    """The inputs of one random-world fixture (tests/golden/random_worlds.npz): a world without coincident
+    triangles, 600 aimed rays and the camera of a 24x16 frame.  Returns (world, sky, max_bounces, o, d, cast)."""
+    w, cam, sky, bounces = random_world(seed, coincident=False)
+    o, d = aimed_rays(600, seed)
+    return w, sky, bounces, o, d, cam(24, 16, 1 + seed % 3)

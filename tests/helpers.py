@@ -117,3 +117,54 @@ def build_and_check_invariants(gpu_tracer, n, seed=3, builds=2):
     assert torch.equal(nodes[inner][:, 0:3], torch.minimum(nodes[left][:, 0:3], nodes[right][:, 0:3]))
     assert torch.equal(nodes[inner][:, 4:7], torch.maximum(nodes[left][:, 4:7], nodes[right][:, 4:7]))
     return ms
+
+
+def same_or_both_nan(a, b):
+    """Element-wise: the same bits, or a NaN on both sides (the sign and payload of a NaN are the hardware's)."""
+    a, b = np.asarray(a), np.asarray(b)
+    return (bits(a) == bits(b)) | (np.isnan(a) & np.isnan(b))
+
+
+def check_random_world(oracle, gpu_tracer, seed, kernels=("auto", "static", "persistent", "wavefront", "static-samples")):
+    """One seeded random world (scenes.random_world): trees, closest hits and occlusion of random rays, and whole
+    frames from every cast kernel, against the CPU restatement drawing the same counter-based random numbers."""
+    from raytracer_amd import scenes, world, tracer as T
+
+    w, cam, sky, bounces = scenes.random_world(seed)
+    gpu_tracer.check(gpu_tracer.lib.rthip_set_tracer(gpu_tracer.h, bounces, 1 if sky else 0), "set_tracer")
+    T.rt_tracer_build_blas(gpu_tracer, w)
+    T.rt_tracer_build_tlas(gpu_tracer, w)
+    flat = world.flatten_world(w)
+    sc = oracle.Scene(flat, bounces, sky)
+    try:
+        assert_same_tree(T.get_tree(gpu_tracer, -1), sc.tree(-1), f"seed {seed} TLAS")
+        for k in range(len(flat.meshes)):
+            assert_same_tree(T.get_tree(gpu_tracer, k), sc.tree(k), f"seed {seed} BLAS {k}")
+        o, d = scenes.aimed_rays(3000, seed)
+        inst, tri, t, uv, nrm = T.trace_rays(gpu_tracer, o, d)
+        oi, ot, ott, ouv, onrm, _ = sc.trace(o, d, threads=4)
+        assert (inst == oi).all() and (tri == ot).all() and (bits(t) == bits(ott)).all(), f"closest hits differ ({int((inst != oi).sum())} ids)"
+        assert (bits(uv) == bits(ouv)).all(), "uv differ"
+        assert same_or_both_nan(nrm, onrm).all(), "normals differ"
+        assert (T.occluded(gpu_tracer, o, d, 4.0) == sc.occluded(o, d, 4.0)).all(), "occlusion differs"
+        rng = np.random.default_rng(seed)
+        wd, ht, smp = int(rng.integers(8, 70)), int(rng.integers(8, 50)), int(rng.choice([1, 2, 2, 3, 4]))
+        c = cam(wd, ht, smp)
+        want, _ = sc.cast(c, seed, wd, ht, rng_mode=oracle.RNG_COUNTER, threads=8)
+        for kernel in kernels:
+            T.set_cast_kernel(gpu_tracer, kernel)
+            img = np.full((ht, wd, 3), -1.0, dtype=np.float32)
+            T.rt_tracer_cast(gpu_tracer, c, img, wd, ht, seed=seed)
+            bad = np.nonzero(~same_or_both_nan(img, want).all(axis=2))
+            assert bad[0].size == 0, (f"{kernel} {wd}x{ht} samples {smp} bounces {bounces}: {bad[0].size} pixels differ, "
+                                      f"first (y, x) = {list(zip(bad[0][:3].tolist(), bad[1][:3].tolist()))}")
+    finally:
+        T.set_cast_kernel(gpu_tracer, "auto")
+        sc.close()
+
+
+def nan_free(a):
+    """NaNs replaced by one fixed pattern before hashing (their sign and payload belong to the hardware)."""
+    a = np.array(a, dtype=np.float32, copy=True)
+    a[np.isnan(a)] = np.float32(12345.0)
+    return a
