@@ -708,3 +708,38 @@ def random_world_case(seed: int):
     w, cam, sky, bounces = random_world(seed, coincident=False)
     o, d = aimed_rays(600, seed)
     return w, sky, bounces, o, d, cam(24, 16, 1 + seed % 3)
+
+
+def random_boxes(seed: int):
+    """A seeded box set for fuzzing the LBVH build: a random size (1 ... 20 000) and one of several awkward
+    distributions -- uniform, tight clusters, points on a coarse lattice (many equal Morton codes), a plane or a line
+    (zero extent on one or two axes), wildly different magnitudes, tiny (denormal) coordinates, all boxes equal,
+    negative zeros.  Returns float32[n, 6] (min xyz, max xyz)."""
+    rng = np.random.default_rng(seed)
+    n = int(rng.choice([1, 2, 3, int(rng.integers(4, 64)), int(rng.integers(64, 2000)), int(rng.integers(2000, 20001))]))
+    kind = int(rng.integers(0, 9))
+    cen = rng.uniform(-1, 1, (n, 3))
+    half = rng.uniform(0, 0.05, (n, 3))
+    if kind == 1:
+        cen = rng.integers(0, 4, (n, 1)) * 10.0 + rng.normal(scale=1e-3, size=(n, 3))
+    elif kind == 2:
+        cen = rng.integers(0, 5, (n, 3)) * 0.25
+        half = rng.integers(0, 2, (n, 3)) * 0.125
+    elif kind == 3:
+        cen[:, int(rng.integers(0, 3))] = 0.75
+        half[:] = 0
+    elif kind == 4:
+        cen[:, 1:] = (3.0, -2.0)
+        half[:, 1:] = 0
+    elif kind == 5:
+        cen = cen * 10.0 ** rng.integers(-20, 20, (n, 1))
+    elif kind == 6:
+        cen, half = cen * 1e-41, half * 1e-42
+    elif kind == 7:
+        cen[:] = cen[0]
+        half[:] = half[0]
+    elif kind == 8:
+        cen = np.where(rng.integers(0, 2, (n, 3)) == 0, -0.0, cen)
+        half[:] = 0
+    cen, half = cen.astype(np.float32), half.astype(np.float32)
+    return np.concatenate([cen - half, cen + half], axis=1).astype(np.float32)

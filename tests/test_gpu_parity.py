@@ -43,6 +43,13 @@ def test_lbvh_sizes(oracle, gpu_tracer, n):
     check_lbvh(oracle, gpu_tracer, np.concatenate([cen - half, cen + half], axis=1), f"n={n}")
 
 
+def test_lbvh_random_sets(oracle, gpu_tracer):
+    """Fuzzed box sets (clusters, lattices, planes, lines, 40 decades of magnitude, denormals, identical boxes,
+    negative zeros; 1 ... 20 000 boxes): codes, order and every node against the oracle."""
+    for seed in range(1, 201):
+        check_lbvh(oracle, gpu_tracer, scenes.random_boxes(seed), f"random set {seed}")
+
+
 def test_lbvh_duplicate_heavy_large(oracle, gpu_tracer):
     rng = np.random.default_rng(3)
     n = 200_000

@@ -47,6 +47,19 @@ def test_lbvh_big_digests(oracle):
         assert hashlib.sha256(oracle.dump_bytes(nodes)).hexdigest() == str(g[f"n{n}_dump"])
 
 
+def test_lbvh_random_sets_against_reference_when_built(oracle):
+    """Fuzzed box sets (scenes.random_boxes: clusters, lattices, planes, lines, 40 decades of magnitude, denormals,
+    identical boxes, negative zeros) against lbvh_make of the reference compiled here."""
+    if not oracle.have_ref("core"):
+        pytest.skip("oracle/_ref is not built here")
+    for seed in range(1, 121):
+        boxes = scenes.random_boxes(seed)
+        codes, codes_sorted, ids, nodes = oracle.lbvh_build(boxes)
+        ref_codes, _, ref_dump, _ = oracle.ref_lbvh_build(boxes)
+        assert (codes == ref_codes).all(), f"set {seed}: Morton codes differ from the reference"
+        assert_same_tree_modulo_runs(nodes, oracle.parse_dump(ref_dump), codes_sorted, f"set {seed}")
+
+
 DEMOS = {"cornell": scenes.cornell, "tri": scenes.tri, "spheres": scenes.spheres}
 
 
