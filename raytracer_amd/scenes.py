@@ -743,3 +743,48 @@ def random_boxes(seed: int):
         half[:] = 0
     cen, half = cen.astype(np.float32), half.astype(np.float32)
     return np.concatenate([cen - half, cen + half], axis=1).astype(np.float32)
+
+
+def random_obj_text(seed: int):
+    """A seeded random OBJ text within what the reference's loader reads (src/mesh/mesh.c:73-219) -> (text, attrs):
+    one of the four face syntaxes, numbers in mixed notations, runs of blanks and tabs between fields, trailing
+    blanks, comments, blank and foreign lines in between, faces with more than three corners, many repeated index
+    triples, LF or CRLF line ends, with or without a line end after the last record."""
+    rng = np.random.default_rng(seed)
+    attrs = int(rng.choice([1, 3, 5, 7]))
+    n_v, n_n, n_t = int(rng.integers(3, 60)), int(rng.integers(1, 20)), int(rng.integers(1, 20))
+    n_f = int(rng.integers(1, 200))
+    fmts = ["%.9g", "%g", "%.3f", "%e", "%.1f", "%+.4g"]
+
+    def num(x):
+        return fmts[int(rng.integers(0, len(fmts)))] % x
+
+    def gap():
+        return str(rng.choice([" ", " ", " ", "  ", "\t", " \t "]))
+
+    def tail():
+        return str(rng.choice(["", "", "", " ", "\t", "  "]))
+
+    lines = []
+    records = [("v", 3)] * n_v + ([("vn", 3)] * n_n if attrs & 2 else []) + ([("vt", 2)] * n_t if attrs & 4 else [])
+    for tag, k in records:
+        vals = rng.normal(scale=float(rng.choice([1e-3, 1.0, 100.0])), size=k)
+        lines.append(tag + " " + gap().join(num(v) for v in vals) + tail())
+    if rng.integers(0, 2):
+        order = rng.permutation(len(lines))
+        lines = [lines[k] for k in order]  # positions, normals and texture coordinates interleaved
+    faces = []
+    for _ in range(n_f):
+        corners = int(rng.choice([3, 3, 3, 4, 5]))
+        parts = []
+        for _ in range(corners):
+            p, n, t = int(rng.integers(1, n_v + 1)), int(rng.integers(1, min(n_n, 3) + 1)), int(rng.integers(1, min(n_t, 3) + 1))
+            parts.append({1: "%d" % p, 3: "%d//%d" % (p, n), 5: "%d/%d" % (p, t), 7: "%d/%d/%d" % (p, t, n)}[attrs])
+        faces.append("f " + gap().join(parts) + tail())
+    lines += faces
+    extras = ["# note", "", "g part", "s 1", "usemtl none", "o thing", "#", "   "]
+    for _ in range(int(rng.integers(0, 12))):
+        lines.insert(int(rng.integers(0, len(lines) + 1)), extras[int(rng.integers(0, len(extras)))])
+    end = "\r\n" if rng.integers(0, 4) == 0 else "\n"
+    text = end.join(lines) + (end if rng.integers(0, 3) else "")
+    return text, (0 if attrs == 7 and rng.integers(0, 2) else attrs)

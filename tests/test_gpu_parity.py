@@ -782,6 +782,22 @@ def test_obj_loader_matches_reference(gpu_tracer, tmp_path):
             assert hashlib.sha256(written.tobytes()).hexdigest() == str(g[name + "_ref_vertices_sha"]), name
 
 
+def test_obj_loader_random_texts(oracle, gpu_tracer, tmp_path):
+    """Fuzzed OBJ texts: every face syntax, mixed number notations, blanks and tabs, foreign lines, CRLF, faces with more
+    than three corners, with and without a final line end."""
+    from helpers import obj_written_columns
+
+    path = tmp_path / "fuzz.obj"
+    for seed in range(1, 201):
+        text, attrs = scenes.random_obj_text(seed)
+        path.write_bytes(text.encode())
+        verts, idx, info = T.ms_load_obj(gpu_tracer, str(path), attrs)
+        want_verts, want_idx = oracle.load_obj(str(path), attrs)
+        assert verts.shape == want_verts.shape and (idx == want_idx).all(), f"text {seed}"
+        cols = obj_written_columns(attrs, verts.shape[1])
+        assert (bits(verts[:, cols]) == bits(want_verts[:, cols])).all(), f"text {seed}"
+
+
 def test_obj_loader_against_oracle_on_a_large_file(oracle, gpu_tracer, tmp_path):
     """300 k faces with heavily repeated index triples, all four syntaxes."""
     rng = np.random.default_rng(12)

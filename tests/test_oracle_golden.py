@@ -283,6 +283,23 @@ def same_ray_records(mine, g, key):
     assert ((g[key + "_m"] == 0) == (mine["material"] < 0)).all(), key  # misses carry a zero handle
 
 
+def test_obj_random_texts_against_reference_when_built(oracle, tmp_path):
+    """Fuzzed OBJ texts (scenes.random_obj_text) through the reference's ms_load_obj compiled here."""
+    from helpers import obj_written_columns
+
+    if not oracle.have_ref("core"):
+        pytest.skip("oracle/_ref is not built here")
+    path = tmp_path / "fuzz.obj"
+    for seed in range(1, 151):
+        text, attrs = scenes.random_obj_text(seed)
+        path.write_bytes(text.encode())
+        verts, idx = oracle.load_obj(str(path), attrs)
+        ref_verts, ref_idx = oracle.ref_load_obj(str(path), attrs, len(text) + 16, len(text) + 16)
+        assert verts.shape == ref_verts.shape and (idx == ref_idx).all(), f"text {seed}"
+        cols = obj_written_columns(attrs, verts.shape[1])
+        assert (bits(verts[:, cols]) == bits(ref_verts[:, cols])).all(), f"text {seed}"
+
+
 @pytest.mark.parametrize("name,case", RAY_RECORD_CASES)
 def test_ray_records_match_the_reference_debug_dump(oracle, name, case):
     """Every ray of a frame (origin, direction, hit point, normal, distance, material) as the reference's BUILD_DEBUG
