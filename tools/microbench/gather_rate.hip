@@ -43,6 +43,31 @@ __global__ __launch_bounds__(256) void chase(const uint4* __restrict__ table, ui
     if (acc == 0x12345678u) out[0] = acc;
 }
 
+
+// The same chase through a copy of the table in LDS (16 KB = 512 records per workgroup).
+__global__ __launch_bounds__(256) void chase_lds(const uint4* __restrict__ table, uint32_t steps, uint32_t active_lanes,
+                                                 uint32_t* __restrict__ out) {
+    __shared__ uint4 local[1024];
+    for (uint32_t k = threadIdx.x; k < 1024; k += 256) local[k] = table[k];
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t me = (blockIdx.x * 256u + threadIdx.x) * 2654435761u + 0x9E3779B9u;
+    uint32_t idx = me;
+    uint32_t acc = 0;
+    if (lane < active_lanes) {
+        for (uint32_t s = 0; s < steps; s++) {
+            idx &= 511u;
+            const uint4 a = local[2 * idx];
+            const uint4 b = local[2 * idx + 1];
+            const uint32_t v = a.x ^ b.w;
+            acc += v;
+            idx = ((v ^ me) + s) * 2654435761u;
+            idx ^= idx >> 15;
+        }
+    }
+    if (acc == 0x12345678u) out[0] = acc;
+}
+
 int main() {
     hipDeviceProp_t prop;
     CHECK(hipGetDeviceProperties(&prop, 0));
@@ -53,7 +78,7 @@ int main() {
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
     printf("records_MB loads waves/SIMD lanes  G_records/s  GB/s(32B)\n");
-    for (uint64_t records : {1ull << 17, 1ull << 20, 1ull << 22, 1ull << 24}) {  // 4 MB, 32 MB, 128 MB, 512 MB
+    for (uint64_t records : {1ull << 8, 1ull << 9, 1ull << 11, 1ull << 13, 1ull << 15, 1ull << 17, 1ull << 20, 1ull << 22, 1ull << 24}) {  // 8 KB ... 512 MB
         std::vector<uint32_t> h(records * 8);
         uint32_t x = 12345;
         for (auto& w : h) {
@@ -82,8 +107,26 @@ int main() {
                         if (ms < best) best = ms;
                     }
                     const double n = (double)blocks * 4 * lanes * steps;
-                    printf("%9.0f %5d %10d %5u %12.1f %10.0f\n", records * 32 / 1e6, loads, waves_per_simd, lanes,
+                    printf("%9.3f %5d %10d %5u %12.1f %10.0f\n", records * 32 / 1e6, loads, waves_per_simd, lanes,
                            n / best / 1e6, n * 32 / best / 1e6);
+                }
+        if (records == (1ull << 9))
+            for (int waves_per_simd : {2, 5})
+                for (uint32_t lanes : {64u, 16u}) {
+                    const uint32_t blocks = (uint32_t)cus * waves_per_simd;
+                    const uint32_t steps = 2000;
+                    float best = 1e30f;
+                    for (int rep = 0; rep < 3; rep++) {
+                        CHECK(hipEventRecord(e0));
+                        chase_lds<<<blocks, 256>>>(d_table, steps, lanes, d_out);
+                        CHECK(hipEventRecord(e1));
+                        CHECK(hipEventSynchronize(e1));
+                        float ms;
+                        CHECK(hipEventElapsedTime(&ms, e0, e1));
+                        if (ms < best) best = ms;
+                    }
+                    const double n = (double)blocks * 4 * lanes * steps;
+                    printf("      LDS %5d %10d %5u %12.1f %10.0f\n", 2, waves_per_simd, lanes, n / best / 1e6, n * 32 / best / 1e6);
                 }
         CHECK(hipFree(d_table));
     }
