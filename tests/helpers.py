@@ -158,6 +158,26 @@ def check_random_world(oracle, gpu_tracer, seed, kernels=("auto", "static", "per
             bad = np.nonzero(~same_or_both_nan(img, want).all(axis=2))
             assert bad[0].size == 0, (f"{kernel} {wd}x{ht} samples {smp} bounces {bounces}: {bad[0].size} pixels differ, "
                                       f"first (y, x) = {list(zip(bad[0][:3].tolist(), bad[1][:3].tolist()))}")
+        # the records of every ray of every path, and one shard of the frame (tiles or sample indices)
+        T.set_cast_kernel(gpu_tracer, "auto")
+        rec = T.cast_ray_records(gpu_tracer, c, wd, ht, seed=seed)
+        want_rec = sc.cast_records(c, seed, wd, ht, rng_mode=oracle.RNG_COUNTER)
+        assert rec.size == want_rec.size, f"{rec.size} ray records, the oracle has {want_rec.size}"
+        for f in rec.dtype.names:
+            same = same_or_both_nan(rec[f], want_rec[f]) if rec[f].dtype == np.float32 else rec[f] == want_rec[f]
+            assert same.all(), f"ray records differ in {f}"
+        from raytracer_amd import abi
+        mode, world_size = int(rng.integers(1, 3)), int(rng.integers(2, 5))
+        rank = int(rng.integers(0, world_size))
+        sh = np.zeros(1, dtype=abi.SHARD)
+        sh[0] = (mode, rank, world_size)
+        import torch
+        buf = torch.zeros((ht, wd, 3), dtype=torch.float32, device="cuda:0")
+        gpu_tracer.check(gpu_tracer.lib.rthip_cast_device(gpu_tracer.h, abi.ptr(c), seed, buf.data_ptr(), wd, ht, abi.ptr(sh),
+                                                          torch.cuda.current_stream().cuda_stream), "rthip_cast_device")
+        torch.cuda.synchronize()
+        want_part, _ = sc.cast(c, seed, wd, ht, rng_mode=oracle.RNG_COUNTER, shard=(mode, rank, world_size), threads=8)
+        assert same_or_both_nan(buf.cpu().numpy(), want_part).all(), f"shard mode {mode} rank {rank} of {world_size}"
     finally:
         T.set_cast_kernel(gpu_tracer, "auto")
         sc.close()
