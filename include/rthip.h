@@ -166,6 +166,14 @@ int rthip_abi_version(void);
  * (winding order is never copied there, so it does not exist here). */
 int rthip_set_tracer(rthip_ctx* ctx, uint32_t max_bounces, int sky);
 
+/* Which bounds normalise the centroids before they are quantised to Morton codes, for every tree built afterwards
+ * (BLAS and TLAS): the reference's release builds take the bounds of the centroids (lbvh.c:97-100), its BUILD_DEBUG
+ * builds the bounds of the boxes (lbvh.c:101-104), so the two flavours build different trees from the same input.
+ * Default RTHIP_BOUNDS_CENTROIDS; a backend compiled into a BUILD_DEBUG build selects RTHIP_BOUNDS_BOXES to write the
+ * out.bvh that build writes. */
+enum { RTHIP_BOUNDS_CENTROIDS = 0, RTHIP_BOUNDS_BOXES = 1 };
+int rthip_set_morton_bounds(rthip_ctx* ctx, int mode);
+
 /* ---- acceleration structures ------------------------------------------ */
 
 /* rt_tracer_build_blas -> rt_cpu_build_blas, raytracer_cpu.c:26-31,101-116.

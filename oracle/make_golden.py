@@ -271,6 +271,24 @@ def write_obj():
     np.savez_compressed(os.path.join(OUT, "obj.npz"), **out)
 
 
+def write_debug_flavour():
+    """What a BUILD_DEBUG build of the reference makes of the same box sets (Morton codes normalised by the bounds of
+    the boxes instead of the centroids', lbvh.c:101-104), and the out.bvh its Cornell demo writes."""
+    out = {}
+    names = []
+    for name, boxes in aabb_sets().items():
+        codes, ids, dump, _ = O.ref_lbvh_build(boxes, flavour="core_debug")
+        names.append(name)
+        out[f"{name}_ref_codes"] = codes
+        out[f"{name}_ref_dump"] = np.frombuffer(dump, dtype=np.uint8)
+    out["names"] = np.array(names)
+    out["cornell_demo_tlas_dump"] = np.frombuffer(O.ref_demo("cornell_debug", 16, 16, 1, 1, 1)["tlas_dump"], dtype=np.uint8)
+    release = np.load(os.path.join(OUT, "demo_cornell.npz"))["ref_tlas_dump"].tobytes()
+    print("debug flavour", len(names), "sets; cornell out.bvh differs from the release build's:",
+          out["cornell_demo_tlas_dump"].tobytes() != release)
+    np.savez_compressed(os.path.join(OUT, "debug_flavour.npz"), **out)
+
+
 WORLD_SEEDS = range(5000, 5048)
 
 
@@ -322,6 +340,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "hdr":
         write_hdr()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "debug":
+        write_debug_flavour()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "worlds":
         write_worlds()
         sys.exit(0)
@@ -338,3 +359,4 @@ if __name__ == "__main__":
     write_obj()
     write_ray_records()
     write_worlds()
+    write_debug_flavour()

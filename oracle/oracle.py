@@ -164,6 +164,12 @@ def ref_hdr_encode(rgb: np.ndarray) -> bytes:
 # ---- LBVH ------------------------------------------------------------------------
 
 
+def set_morton_bounds(boxes: bool) -> None:
+    """Centroid bounds (release builds of the reference, the default) or box bounds (its BUILD_DEBUG builds) for
+    every tree the oracle builds from now on (lbvh.c:97-104)."""
+    lib().ora_set_morton_bounds(1 if boxes else 0)
+
+
 def lbvh_build(aabbs: np.ndarray):
     """ora_lbvh_build -> (codes, codes_sorted, ids_sorted, nodes)."""
     aabbs = np.ascontiguousarray(aabbs, dtype=np.float32).reshape(-1, 6)

@@ -194,16 +194,26 @@ static void build_tree(const key_id* a, const float* aabb6, uint64_t n, rthip_no
     free(st);
 }
 
-/* lbvh_make, lbvh.c:92-125 (release build: bounds over centroids, :97-100) */
+/* Which bounds lbvh_make normalises the centroids by: 0 = the centroids' own (release builds, lbvh.c:97-100),
+ * 1 = the boxes' (BUILD_DEBUG builds, lbvh.c:101-104).  Process-wide; every tree built afterwards follows it. */
+static int g_box_bounds = 0;
+void ora_set_morton_bounds(int boxes) { g_box_bounds = boxes ? 1 : 0; }
+
+/* lbvh_make, lbvh.c:92-125 */
 int ora_lbvh_build(const float* aabb6, uint64_t n, uint64_t* out_codes, uint64_t* out_codes_sorted,
                    uint32_t* out_ids_sorted, rthip_node* out_nodes) {
     if (n == 0) return 1;
     v3 mn = V3(ORA_MAXF, ORA_MAXF, ORA_MAXF), mx = V3(-ORA_MAXF, -ORA_MAXF, -ORA_MAXF);
     for (uint64_t i = 0; i < n; i++) {
         const float* b = aabb6 + 6 * i;
-        v3 c = vscale(vadd(V3(b[0], b[1], b[2]), V3(b[3], b[4], b[5])), 0.5f);
-        mn = vmin(mn, c);
-        mx = vmax(mx, c);
+        if (g_box_bounds) {
+            mn = vmin(mn, V3(b[0], b[1], b[2]));
+            mx = vmax(mx, V3(b[3], b[4], b[5]));
+        } else {
+            v3 c = vscale(vadd(V3(b[0], b[1], b[2]), V3(b[3], b[4], b[5])), 0.5f);
+            mn = vmin(mn, c);
+            mx = vmax(mx, c);
+        }
     }
     v3 ext = vsub(mx, mn);
     key_id* keys = (key_id*)malloc(n * sizeof(key_id));

@@ -67,6 +67,7 @@ SYMBOLS = [
     ("rthip_last_error", C.c_char_p, [_P]),
     ("rthip_abi_version", C.c_int, []),
     ("rthip_set_tracer", C.c_int, [_P, C.c_uint32, C.c_int]),
+    ("rthip_set_morton_bounds", C.c_int, [_P, C.c_int]),
     ("rthip_blas_begin", C.c_int, [_P, C.c_uint32]),
     ("rthip_blas_add_mesh", C.c_int,
      [_P, C.c_uint32, _P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32, _P, C.c_uint32]),

@@ -100,7 +100,8 @@ __global__ __launch_bounds__(kBlock) void tri_prepare_kernel(const float* __rest
                                                              const float* __restrict__ ny, const float* __restrict__ nz,
                                                              const uint32_t* __restrict__ indices, uint64_t n_tris,
                                                              float* __restrict__ aabb6, float4* __restrict__ tri_v,
-                                                             float4* __restrict__ tri_n, uint32_t* __restrict__ bounds) {
+                                                             float4* __restrict__ tri_n, uint32_t* __restrict__ bounds,
+                                                             uint32_t box_bounds) {
     float mn[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f};
     float mx[3] = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
     for (uint64_t t = (uint64_t)blockIdx.x * kBlock + threadIdx.x; t < n_tris; t += (uint64_t)gridDim.x * kBlock) {
@@ -130,8 +131,8 @@ __global__ __launch_bounds__(kBlock) void tri_prepare_kernel(const float* __rest
 #pragma unroll
         for (int k = 0; k < 3; k++) {
             const float c = (b[k] + b[k + 3]) * 0.5f;  // mul_3f32(add_3f32(min, max), 0.5f), lbvh.c:98
-            mn[k] = ref_min(mn[k], c);
-            mx[k] = ref_max(mx[k], c);
+            mn[k] = ref_min(mn[k], box_bounds ? b[k] : c);      // a BUILD_DEBUG build bounds the boxes, lbvh.c:101-104
+            mx[k] = ref_max(mx[k], box_bounds ? b[k + 3] : c);
         }
         if (tri_v) {
             tri_v[3 * t + 0] = make_float4(ax, ay, az, 0.f);
@@ -166,7 +167,7 @@ __global__ void bounds_init_kernel(uint32_t* bounds) {
 }
 
 __global__ __launch_bounds__(kBlock) void bounds_kernel(const float* __restrict__ aabb6, uint64_t n,
-                                                        uint32_t* __restrict__ bounds) {
+                                                        uint32_t* __restrict__ bounds, uint32_t box_bounds) {
     float mn[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f};
     float mx[3] = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
     for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
@@ -174,8 +175,8 @@ __global__ __launch_bounds__(kBlock) void bounds_kernel(const float* __restrict_
 #pragma unroll
         for (int k = 0; k < 3; k++) {
             float c = (b[k] + b[k + 3]) * 0.5f;  // mul_3f32(add_3f32(min, max), 0.5f), lbvh.c:98
-            mn[k] = ref_min(mn[k], c);
-            mx[k] = ref_max(mx[k], c);
+            mn[k] = ref_min(mn[k], box_bounds ? b[k] : c);      // a BUILD_DEBUG build bounds the boxes, lbvh.c:101-104
+            mx[k] = ref_max(mx[k], box_bounds ? b[k + 3] : c);
         }
     }
     block_bounds_reduce(mn, mx, bounds);
@@ -857,7 +858,8 @@ __global__ __launch_bounds__(kChunk) void lbvh_small_kernel(uint32_t n, const fl
                                                             ChildRec* __restrict__ child, uint32_t* flags,
                                                             uint32_t* __restrict__ cnt_l, NodeInfo* __restrict__ node_info,
                                                             uint8_t* __restrict__ node_dl, LeafRec* __restrict__ leaf_sorted,
-                                                            uint32_t* __restrict__ starters, float4* __restrict__ nodes) {
+                                                            uint32_t* __restrict__ starters, float4* __restrict__ nodes,
+                                                            uint32_t box_bounds) {
     __shared__ uint64_t skey[kChunk];
     __shared__ uint32_t sidx[kChunk];
     __shared__ uint32_t sbounds[6];
@@ -874,8 +876,8 @@ __global__ __launch_bounds__(kChunk) void lbvh_small_kernel(uint32_t n, const fl
 #pragma unroll
         for (int k = 0; k < 3; k++) {
             c[k] = (b[k] + b[k + 3]) * 0.5f;  // lbvh.c:98
-            atomicMin(&sbounds[k], f2ord(c[k]));
-            atomicMax(&sbounds[k + 3], f2ord(c[k]));
+            atomicMin(&sbounds[k], f2ord(box_bounds ? b[k] : c[k]));  // a BUILD_DEBUG build bounds the boxes, lbvh.c:101-104
+            atomicMax(&sbounds[k + 3], f2ord(box_bounds ? b[k + 3] : c[k]));
         }
     }
     __syncthreads();
@@ -1087,7 +1089,7 @@ int mesh_prepare_device(rthip_ctx* ctx, const float* px, const float* py, const 
     uint32_t blocks = div_up(n_tris, kBlock);
     if (blocks > 4096) blocks = 4096;
     tri_prepare_kernel<<<blocks, kBlock, 0, stream>>>(px, py, pz, nx, ny, nz, indices, n_tris, d_aabb6, d_tri_v, d_tri_n,
-                                                      bounds);
+                                                      bounds, ctx->box_bounds);
     RT_HIP(ctx, hipGetLastError());
     // the centroid bounds of exactly these boxes are now in the workspace: the build that follows on this
     // stream for this array can skip its own pass over them
@@ -1139,7 +1141,7 @@ int lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, float4* 
         lbvh_small_kernel<<<1, kChunk, 0, s>>>((uint32_t)n, d_aabb6, keys[0], keys[1], vals[1], (uint8_t*)w.prio.p,
                                                (ChildRec*)w.child.p, (uint32_t*)w.flags.p, (uint32_t*)w.cnt_l.p,
                                                (NodeInfo*)w.node_info.p, (uint8_t*)w.node_dl.p, (LeafRec*)w.leaf_sorted.p,
-                                               (uint32_t*)w.starters.p, d_nodes);
+                                               (uint32_t*)w.starters.p, d_nodes, ctx->box_bounds);
         RT_HIP(ctx, hipGetLastError());
         if (d_codes_unsorted) RT_HIP(ctx, hipMemcpyAsync(d_codes_unsorted, keys[0], n * 8, hipMemcpyDeviceToDevice, s));
         if (d_keys_sorted) RT_HIP(ctx, hipMemcpyAsync(d_keys_sorted, keys[1], n * 8, hipMemcpyDeviceToDevice, s));
@@ -1150,7 +1152,7 @@ int lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, float4* 
         bounds_init_kernel<<<1, 64, 0, s>>>(bounds);
         uint32_t bblocks = div_up(n, kBlock);
         if (bblocks > 2048) bblocks = 2048;
-        bounds_kernel<<<bblocks, kBlock, 0, s>>>(d_aabb6, n, bounds);
+        bounds_kernel<<<bblocks, kBlock, 0, s>>>(d_aabb6, n, bounds, ctx->box_bounds);
     }
     ctx->bounds_of = nullptr;
     morton_kernel<<<div_up(n, kBlock), kBlock, 0, s>>>(d_aabb6, n, bounds, keys[0], vals[0]);

@@ -168,6 +168,15 @@ int rthip_set_tracer(rthip_ctx* ctx, uint32_t max_bounces, int sky) {
     return RTHIP_OK;
 }
 
+int rthip_set_morton_bounds(rthip_ctx* ctx, int mode) {
+    if (!ctx) return RTHIP_E_INVALID;
+    if (mode != RTHIP_BOUNDS_CENTROIDS && mode != RTHIP_BOUNDS_BOXES)
+        return rthip_fail(ctx, RTHIP_E_INVALID, "morton bounds mode must be 0 (centroids) or 1 (boxes), got %d", mode);
+    ctx->box_bounds = (uint32_t)mode;
+    ctx->bounds_of = nullptr;  // bounds left by a prepare pass were taken in the other mode
+    return RTHIP_OK;
+}
+
 int rthip_set_counting(rthip_ctx* ctx, int enabled) {
     if (!ctx) return RTHIP_E_INVALID;
     ctx->counting = enabled ? 1 : 0;

@@ -156,6 +156,7 @@ struct rthip_ctx {
     int frame_w = 0, frame_h = 0;
     DevBuf hdr_stage, hdr_lengths, hdr_offsets, hdr_out, hdr_size;  // .hdr encoder: coded components, their lengths and file offsets
     // set by mesh_prepare_device: the workspace holds the centroid bounds of this box array (consumed by the next build)
+    uint32_t box_bounds = 0;     // Morton codes normalised by the boxes' bounds (BUILD_DEBUG builds of the reference) instead of the centroids'
     const float* bounds_of = nullptr;
     uint64_t bounds_n = 0;
     hipStream_t bounds_stream = nullptr;

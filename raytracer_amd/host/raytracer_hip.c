@@ -99,6 +99,11 @@ rt_hook RT_Handle rt_make_tracer(RT_TracerSettings settings) {
     if (rc != RTHIP_OK) fprintf(stderr, "rthip: no usable MI355X (gfx950) device; this backend has no CPU path\n");
     AssertAlways(rc == RTHIP_OK);
     rt_hip_check(tracer, rthip_set_tracer(tracer->ctx, settings.max_bounces, settings.sky ? 1 : 0), "rthip_set_tracer");
+    // lbvh_make normalises centroids by the boxes' bounds in a BUILD_DEBUG build and by the centroids' own in a
+    // release build (lbvh.c:97-104): the trees differ, so the backend follows the flavour it is compiled into.
+    #if BUILD_DEBUG
+    rt_hip_check(tracer, rthip_set_morton_bounds(tracer->ctx, RTHIP_BOUNDS_BOXES), "rthip_set_morton_bounds");
+    #endif
     return rt_hip_tracer_to_handle(tracer);
 }
 

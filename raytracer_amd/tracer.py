@@ -259,5 +259,11 @@ def set_persistent_params(tracer: RT_Tracer, refill: int = 16, inst_batch: int =
     tracer.check(tracer.lib.rthip_set_persistent_params(tracer.h, refill, inst_batch), "rthip_set_persistent_params")
 
 
+def set_morton_bounds(tracer: RT_Tracer, boxes: bool) -> None:
+    """Trees built from now on normalise centroids by the centroids' bounds (release builds of the reference, the
+    default) or by the boxes' bounds (its BUILD_DEBUG builds), lbvh.c:97-104."""
+    tracer.check(tracer.lib.rthip_set_morton_bounds(tracer.h, 1 if boxes else 0), "rthip_set_morton_bounds")
+
+
 def set_counting(tracer: RT_Tracer, enabled: bool) -> None:
     tracer.check(tracer.lib.rthip_set_counting(tracer.h, 1 if enabled else 0), "rthip_set_counting")

@@ -50,6 +50,35 @@ def test_lbvh_random_sets(oracle, gpu_tracer):
         check_lbvh(oracle, gpu_tracer, scenes.random_boxes(seed), f"random set {seed}")
 
 
+def test_lbvh_box_bounds_flavour(oracle, gpu_tracer):
+    """RTHIP_BOUNDS_BOXES: the trees of the reference's BUILD_DEBUG builds (centroids normalised by the bounds of the
+    boxes, lbvh.c:101-104) -- against that build's own codes, the oracle in the same mode, and its Cornell out.bvh."""
+    g = golden("debug_flavour")
+    T.set_morton_bounds(gpu_tracer, True)
+    oracle.set_morton_bounds(True)
+    try:
+        for name in g["names"].tolist():
+            codes, _ = check_lbvh(oracle, gpu_tracer, golden("lbvh_" + name)["aabbs"], name + " (box bounds)")
+            assert (codes == g[name + "_ref_codes"]).all(), name
+        for seed in range(300, 360):  # through the one-launch path, the fused sort and the general one
+            check_lbvh(oracle, gpu_tracer, scenes.random_boxes(seed), f"random set {seed} (box bounds)")
+        w, cam, sky = scenes.cornell()
+        build(gpu_tracer, w, 8, sky)
+        assert oracle.dump_bytes(T.get_tree(gpu_tracer, -1)) == g["cornell_demo_tlas_dump"].tobytes()
+        sc = oracle.Scene(world.flatten_world(w), 8, sky)
+        for k in range(2):
+            assert_same_tree(T.get_tree(gpu_tracer, k), sc.tree(k), f"Cornell BLAS {k} (box bounds)")
+        verts, indices = scenes.bunny_class_mesh(4)  # 5120 triangles: bounds from the triangle pass
+        w, cam, sky = scenes.bunny(verts, indices)
+        build(gpu_tracer, w, 2, sky)
+        assert_same_tree(T.get_tree(gpu_tracer, 0), oracle.Scene(world.flatten_world(w), 2, sky).tree(0), "mesh (box bounds)")
+    finally:
+        T.set_morton_bounds(gpu_tracer, False)
+        oracle.set_morton_bounds(False)
+    with pytest.raises(T.RTHipError):
+        gpu_tracer.check(gpu_tracer.lib.rthip_set_morton_bounds(gpu_tracer.h, 2), "rthip_set_morton_bounds")
+
+
 def test_lbvh_duplicate_heavy_large(oracle, gpu_tracer):
     rng = np.random.default_rng(3)
     n = 200_000

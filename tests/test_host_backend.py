@@ -126,7 +126,10 @@ def test_debug_build_of_a_demo_writes_the_reference_ray_dump(gpu_tracer, tmp_pat
                        ("handle", "<u8")])
     env = dict(os.environ, RT_HIP_NO_DUMP="1")
     subprocess.check_call([exe, str(tmp_path / "a.hdr"), "--width=16", "--height=16", "--samples=1", "--bounces=1", "--seed=1"],
-                          cwd=str(tmp_path), env=env, timeout=120)
+                          cwd=str(tmp_path), env=dict(os.environ), timeout=120)
+    # a debug build's trees are not a release build's (lbvh.c:97-104): out.bvh must be the debug flavour's
+    with open(str(tmp_path / "out.bvh"), "rb") as f:
+        assert f.read() == golden("debug_flavour")["cornell_demo_tlas_dump"].tobytes()
     rec = np.fromfile(str(tmp_path / "out.rays"), dtype=file_t)
     mine = np.zeros(rec.size, dtype=abi.RAY_RECORD)
     for f in ("origin", "direction", "p", "n", "t"):

@@ -47,6 +47,29 @@ def test_lbvh_big_digests(oracle):
         assert hashlib.sha256(oracle.dump_bytes(nodes)).hexdigest() == str(g[f"n{n}_dump"])
 
 
+def test_lbvh_debug_flavour_matches_reference(oracle):
+    """A BUILD_DEBUG build of the reference normalises centroids by the bounds of the boxes (lbvh.c:101-104): other
+    codes, other trees.  The oracle's box-bounds mode against that build's answers on the same sets."""
+    g = golden("debug_flavour")
+    oracle.set_morton_bounds(True)
+    try:
+        differs = 0
+        for name in g["names"].tolist():
+            boxes = golden("lbvh_" + name)["aabbs"]
+            codes, codes_sorted, ids, nodes = oracle.lbvh_build(boxes)
+            assert (codes == g[name + "_ref_codes"]).all(), name
+            assert_same_tree_modulo_runs(nodes, oracle.parse_dump(g[name + "_ref_dump"].tobytes()), codes_sorted, name)
+            differs += int((codes != golden("lbvh_" + name)["ref_codes"]).any())
+        assert differs >= 8, "the two flavours should disagree on most sets"
+        # the out.bvh of the reference's Cornell demo, debug build
+        w, cam, sky = scenes.cornell()
+        sc = oracle.Scene(world.flatten_world(w), 8, sky)
+        assert oracle.dump_bytes(sc.tree(-1)) == g["cornell_demo_tlas_dump"].tobytes()
+        assert oracle.dump_bytes(sc.tree(-1)) != golden("demo_cornell")["ref_tlas_dump"].tobytes()
+    finally:
+        oracle.set_morton_bounds(False)
+
+
 def test_lbvh_random_sets_against_reference_when_built(oracle):
     """Fuzzed box sets (scenes.random_boxes: clusters, lattices, planes, lines, 40 decades of magnitude, denormals,
     identical boxes, negative zeros) against lbvh_make of the reference compiled here."""
@@ -54,10 +77,15 @@ def test_lbvh_random_sets_against_reference_when_built(oracle):
         pytest.skip("oracle/_ref is not built here")
     for seed in range(1, 121):
         boxes = scenes.random_boxes(seed)
-        codes, codes_sorted, ids, nodes = oracle.lbvh_build(boxes)
-        ref_codes, _, ref_dump, _ = oracle.ref_lbvh_build(boxes)
-        assert (codes == ref_codes).all(), f"set {seed}: Morton codes differ from the reference"
-        assert_same_tree_modulo_runs(nodes, oracle.parse_dump(ref_dump), codes_sorted, f"set {seed}")
+        for debug in (False, True):  # release and BUILD_DEBUG flavour of lbvh_make
+            oracle.set_morton_bounds(debug)
+            try:
+                codes, codes_sorted, ids, nodes = oracle.lbvh_build(boxes)
+            finally:
+                oracle.set_morton_bounds(False)
+            ref_codes, _, ref_dump, _ = oracle.ref_lbvh_build(boxes, flavour="core_debug" if debug else "core")
+            assert (codes == ref_codes).all(), f"set {seed}: Morton codes differ from the reference"
+            assert_same_tree_modulo_runs(nodes, oracle.parse_dump(ref_dump), codes_sorted, f"set {seed}")
 
 
 DEMOS = {"cornell": scenes.cornell, "tri": scenes.tri, "spheres": scenes.spheres}
