@@ -532,6 +532,10 @@ def main():
     if ray_o is not None:
         kernel_name = "trace_rays_kernel"
     traffic = recorded_traffic(args.workload, kernel_name)
+    if ray_o is not None and traffic is None:  # deep scenes: the library takes the ray stream's persistent kernel
+        traffic = recorded_traffic(args.workload, "trace_rays_persistent_kernel")
+        if traffic is not None:
+            kernel_name = "trace_rays_persistent_kernel"
     if rank == 0:
         value = total_rays * args.steps / elapsed / 1e6
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
