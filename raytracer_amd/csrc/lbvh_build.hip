@@ -816,24 +816,37 @@ __global__ __launch_bounds__(kBlock) void hierarchy_upper_kernel(uint32_t n, con
 // ---- K7: pre-order records ------------------------------------------------------------------
 // Thread t writes leaf t and inner node (gap) t: neighbours in pre-order are written by
 // neighbouring threads, so the 32-byte records combine into full lines on their way to HBM.
+// A record in one of two forms: the documented rthip_node (min.xyz, skip | max.xyz, id), or the walk's own
+// (min.x, max.x, min.y, max.y | min.z, max.z, skip, id), in which the two bounds of an axis sit in neighbouring
+// registers after the load -- what the packed subtract / multiply of the slab test want (node_box / node_links in
+// rt_device.h read it).
+__device__ __forceinline__ void put_node(float4* __restrict__ nodes, uint32_t pre, const float* box, uint32_t skip, uint32_t id,
+                                         uint32_t paired) {
+    if (paired) {
+        nodes[2 * (uint64_t)pre] = make_float4(box[0], box[3], box[1], box[4]);
+        nodes[2 * (uint64_t)pre + 1] = make_float4(box[2], box[5], __uint_as_float(skip), __uint_as_float(id));
+    } else {
+        nodes[2 * (uint64_t)pre] = make_float4(box[0], box[1], box[2], __uint_as_float(skip));
+        nodes[2 * (uint64_t)pre + 1] = make_float4(box[3], box[4], box[5], __uint_as_float(id));
+    }
+}
+
 __device__ __forceinline__ void emit_body(uint64_t t, uint32_t n, const LeafRec* __restrict__ leaf_sorted,
                                           const NodeInfo* __restrict__ node_info, const uint8_t* __restrict__ node_dl,
-                                          const uint32_t* __restrict__ spine_scan, float4* __restrict__ nodes) {
+                                          const uint32_t* __restrict__ spine_scan, float4* __restrict__ nodes, uint32_t paired) {
     if (t >= n) return;
     {
         const uint32_t i = (uint32_t)t;
         const uint32_t pre = i + spine_scan[i];
         const LeafRec lr = leaf_sorted[i];
-        nodes[2 * (uint64_t)pre] = make_float4(lr.box[0], lr.box[1], lr.box[2], __uint_as_float(pre + 1));
-        nodes[2 * (uint64_t)pre + 1] = make_float4(lr.box[3], lr.box[4], lr.box[5], __uint_as_float(lr.id));
+        put_node(nodes, pre, lr.box, pre + 1, lr.id, paired);
     }
     if (t + 1 < n) {
         const NodeInfo ni = node_info[t];
         const uint32_t dl = node_dl[t];
         const uint32_t pre = ni.l + spine_scan[ni.l] - dl;
         const uint32_t size = 2 * (ni.r - ni.l + 1) - 1;
-        nodes[2 * (uint64_t)pre] = make_float4(ni.box[0], ni.box[1], ni.box[2], __uint_as_float(pre + size));
-        nodes[2 * (uint64_t)pre + 1] = make_float4(ni.box[3], ni.box[4], ni.box[5], __uint_as_float(0u));
+        put_node(nodes, pre, ni.box, pre + size, 0u, paired);
     }
 }
 
@@ -841,8 +854,8 @@ __global__ __launch_bounds__(kBlock) void emit_kernel(uint32_t n, const LeafRec*
                                                       const NodeInfo* __restrict__ node_info,
                                                       const uint8_t* __restrict__ node_dl,
                                                       const uint32_t* __restrict__ spine_scan,
-                                                      float4* __restrict__ nodes) {
-    emit_body((uint64_t)blockIdx.x * kBlock + threadIdx.x, n, leaf_sorted, node_info, node_dl, spine_scan, nodes);
+                                                      float4* __restrict__ nodes, uint32_t paired) {
+    emit_body((uint64_t)blockIdx.x * kBlock + threadIdx.x, n, leaf_sorted, node_info, node_dl, spine_scan, nodes, paired);
 }
 
 // ---- the whole build in one workgroup, for n <= kChunk ---------------------------------------
@@ -859,7 +872,7 @@ __global__ __launch_bounds__(kChunk) void lbvh_small_kernel(uint32_t n, const fl
                                                             uint32_t* __restrict__ cnt_l, NodeInfo* __restrict__ node_info,
                                                             uint8_t* __restrict__ node_dl, LeafRec* __restrict__ leaf_sorted,
                                                             uint32_t* __restrict__ starters, float4* __restrict__ nodes,
-                                                            uint32_t box_bounds) {
+                                                            uint32_t box_bounds, uint32_t paired) {
     __shared__ uint64_t skey[kChunk];
     __shared__ uint32_t sidx[kChunk];
     __shared__ uint32_t sbounds[6];
@@ -938,7 +951,7 @@ __global__ __launch_bounds__(kChunk) void lbvh_small_kernel(uint32_t n, const fl
         if (t < n) cnt_l[t] = before + incl;
     }
     __syncthreads();
-    emit_body(t, n, leaf_sorted, node_info, node_dl, cnt_l, nodes);
+    emit_body(t, n, leaf_sorted, node_info, node_dl, cnt_l, nodes, paired);
 }
 
 // ---- K8: world box of every instance, rt_cpu_tlas_node_to_aabb, raytracer_cpu.c:131-147 ------
@@ -971,8 +984,8 @@ __global__ __launch_bounds__(kBlock) void instance_aabb_kernel(const DevInstance
         }
         return;
     }
-    float4 lo = blas[2 * (uint64_t)it.node_base], hi = blas[2 * (uint64_t)it.node_base + 1];
-    float bmin[3] = {lo.x, lo.y, lo.z}, bmax[3] = {hi.x, hi.y, hi.z};
+    const float4 ra = blas[2 * (uint64_t)it.node_base], rb = blas[2 * (uint64_t)it.node_base + 1];  // root record, the walk's form
+    float bmin[3] = {ra.x, ra.z, rb.x}, bmax[3] = {ra.y, ra.w, rb.y};
     float mn[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f};
     float mx[3] = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
     for (int c = 0; c < 8; c++) {  // corner order of rt_cpu_transform_aabb, raytracer_cpu.c:584-593
@@ -1108,7 +1121,7 @@ int instance_aabbs_device(rthip_ctx* ctx, const DevInstance* d_inst, uint32_t n,
 }
 
 int lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, float4* d_nodes, hipStream_t s,
-                      uint64_t* d_codes_unsorted, uint64_t* d_keys_sorted, uint32_t* d_ids_sorted) {
+                      uint64_t* d_codes_unsorted, uint64_t* d_keys_sorted, uint32_t* d_ids_sorted, bool paired) {
     if (n == 0) return rthip_fail(ctx, RTHIP_E_INVALID, "lbvh build needs at least one box");
     if (n > (1ull << 30)) return rthip_fail(ctx, RTHIP_E_LIMIT, "lbvh build is limited to 2^30 boxes (got %llu)",
                                             (unsigned long long)n);
@@ -1141,7 +1154,7 @@ int lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, float4* 
         lbvh_small_kernel<<<1, kChunk, 0, s>>>((uint32_t)n, d_aabb6, keys[0], keys[1], vals[1], (uint8_t*)w.prio.p,
                                                (ChildRec*)w.child.p, (uint32_t*)w.flags.p, (uint32_t*)w.cnt_l.p,
                                                (NodeInfo*)w.node_info.p, (uint8_t*)w.node_dl.p, (LeafRec*)w.leaf_sorted.p,
-                                               (uint32_t*)w.starters.p, d_nodes, ctx->box_bounds);
+                                               (uint32_t*)w.starters.p, d_nodes, ctx->box_bounds, paired ? 1u : 0u);
         RT_HIP(ctx, hipGetLastError());
         if (d_codes_unsorted) RT_HIP(ctx, hipMemcpyAsync(d_codes_unsorted, keys[0], n * 8, hipMemcpyDeviceToDevice, s));
         if (d_keys_sorted) RT_HIP(ctx, hipMemcpyAsync(d_keys_sorted, keys[1], n * 8, hipMemcpyDeviceToDevice, s));
@@ -1194,7 +1207,7 @@ int lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, float4* 
     }
     RT_TRY((scan_u32<true>(ctx, (uint32_t*)w.cnt_l.p, n, scan_tmp + scan_tmp_elems(hist_elems), s)));
     emit_kernel<<<div_up(n, kBlock), kBlock, 0, s>>>(n32, (const LeafRec*)w.leaf_sorted.p, (const NodeInfo*)w.node_info.p,
-                                                    (const uint8_t*)w.node_dl.p, (const uint32_t*)w.cnt_l.p, d_nodes);
+                                                    (const uint8_t*)w.node_dl.p, (const uint32_t*)w.cnt_l.p, d_nodes, paired ? 1u : 0u);
     RT_HIP(ctx, hipGetLastError());
     return RTHIP_OK;
 }

@@ -240,10 +240,13 @@ __device__ __forceinline__ bool trav_step(Trav& T, const DevScene& S, Counters& 
         T.inv = T.winv;
         return false;
     }
-    const float4 lo = T.nodes[2 * (size_t)T.idx], hi = T.nodes[2 * (size_t)T.idx + 1];
+    // the context's trees hold (min.x, max.x, min.y, max.y | min.z, max.z, skip, id): the two bounds of an axis arrive in
+    // neighbouring registers, as the packed subtract / multiply of the slab test take them (put_node, lbvh_build.hip)
+    const float4 ra = T.nodes[2 * (size_t)T.idx], rb = T.nodes[2 * (size_t)T.idx + 1];
+    const float4 lo = make_float4(ra.x, ra.z, rb.x, 0.f), hi = make_float4(ra.y, ra.w, rb.y, 0.f);
     if (COUNT) cnt.nodes++;
-    const uint32_t id = __float_as_uint(hi.w);
-    uint32_t skip = __float_as_uint(lo.w);
+    const uint32_t id = __float_as_uint(rb.w);
+    uint32_t skip = __float_as_uint(rb.z);
     if (skip <= T.idx) skip = T.end;  // a well-formed tree never needs this; it bounds the walk on a corrupt one
     if (!slab(lo, hi, T.o, T.inv, kEps, T.tmax)) {
         T.idx = skip;

@@ -348,7 +348,7 @@ int rthip_blas_commit(rthip_ctx* ctx) {
                                    ctx->stream));
         RT_TRY(lbvh_build_device(ctx, (const float*)ctx->ws.aabb.p, m.n_tris,
                                  (float4*)ctx->blas_nodes.p + 2 * (size_t)m.dev.node_base, ctx->stream, nullptr,
-                                 nullptr, nullptr));
+                                 nullptr, nullptr, true));
         RT_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
         RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
         float ms = 0.f;
@@ -419,7 +419,7 @@ int rthip_tlas_build(rthip_ctx* ctx, const rthip_instance* instances, uint32_t n
         RT_TRY(instance_aabbs_device(ctx, (const DevInstance*)ctx->inst.p, n_instances, (const float4*)ctx->blas_nodes.p,
                                      (float*)ctx->inst_aabb.p, ctx->stream));
         RT_TRY(lbvh_build_device(ctx, (const float*)ctx->inst_aabb.p, n_instances, (float4*)ctx->tlas_nodes.p, ctx->stream,
-                                 nullptr, nullptr, nullptr));
+                                 nullptr, nullptr, nullptr, true));
         RT_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     }
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));  // dev[] must outlive the copy
@@ -750,6 +750,13 @@ int rthip_get_tree(rthip_ctx* ctx, int which, rthip_node* out_nodes, uint64_t* o
     if (out_nodes && n) {
         RT_HIP(ctx, hipDeviceSynchronize());
         RT_HIP(ctx, hipMemcpy(out_nodes, src, n * 32, hipMemcpyDeviceToHost));
+        // the context keeps (min.x, max.x, min.y, max.y | min.z, max.z, skip, id); callers get rthip_node
+        for (uint64_t k = 0; k < n; k++) {
+            uint32_t w[8];
+            memcpy(w, &out_nodes[k], 32);
+            const uint32_t r[8] = {w[0], w[2], w[4], w[6], w[1], w[3], w[5], w[7]};  // min.xyz, skip, max.xyz, id
+            memcpy(&out_nodes[k], r, 32);
+        }
     }
     return RTHIP_OK;
 }

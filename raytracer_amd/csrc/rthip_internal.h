@@ -197,9 +197,11 @@ void rthip_release(DevBuf& b);
 // Builds the pre-order tree of n boxes (d_aabb6: n x 6 floats in HBM) into d_nodes
 // (2n-1 nodes, 2 float4 each).  Enqueues on `stream`; no host synchronisation.
 // When d_codes_unsorted / d_keys_sorted / d_ids_sorted are non-null they receive
-// copies of the intermediate arrays (parity taps).
+// copies of the intermediate arrays (parity taps).  `paired`: records in the walk's own form
+// (min.x, max.x, min.y, max.y | min.z, max.z, skip, id) instead of the documented rthip_node; the
+// context's BLAS and TLAS are kept that way, what leaves through the ABI is rthip_node.
 int lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, float4* d_nodes, hipStream_t stream,
-                      uint64_t* d_codes_unsorted, uint64_t* d_keys_sorted, uint32_t* d_ids_sorted);
+                      uint64_t* d_codes_unsorted, uint64_t* d_keys_sorted, uint32_t* d_ids_sorted, bool paired = false);
 
 // Stable LSD radix sort of the n (uint64 key, uint32 value) pairs in ws.keys[*cur] / ws.vals[*cur] (the caller has
 // reserved both ping-pong pairs) by the key's low n_bytes bytes; *cur names the pair that holds the result.
