@@ -251,6 +251,36 @@ def recorded_traffic(workload: str, kernel_name: str):
     return None if rec is None else rec["hbm_bytes_per_launch"]
 
 
+def recorded_valu_insts(workload: str, kernel_name: str):
+    """Vector-ALU instructions per launch of the cast kernel (SQ_INSTS_VALU, a rocprofv3 pass of its own of this same
+    command, kept in profiles/traffic.json), or None."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        table = json.load(f)
+    return table.get(workload, {}).get(kernel_name.split(" ")[0], {}).get("valu_insts_per_launch")
+
+
+SIMDS = 256 * 4           # compute units x SIMDs
+ENGINE_CLOCK_GHZ = 2.4    # peak engine clock of the MI355X
+
+
+def valu_issue(insts, kernel_ms, ms_per_step, n_streams):
+    """Share of the chip's vector-ALU issue cycles one launch's instructions take: a wave64 instruction holds its SIMD for
+    4 cycles.  `issue_frac` over the launch's own duration when launches run one after the other, `issue_frac_overlapped`
+    over the time a launch costs (timed region / steps) when several overlap."""
+    if not insts:
+        return None
+    busy_ms = insts * 4.0 / (SIMDS * ENGINE_CLOCK_GHZ * 1e9) * 1e3
+    out = {"insts_per_launch": int(insts), "cycles_per_inst": 4, "simds": SIMDS, "clock_ghz": ENGINE_CLOCK_GHZ}
+    if n_streams > 1:
+        out["issue_frac_overlapped"] = round(busy_ms / ms_per_step, 4)
+    else:
+        out["issue_frac"] = round(busy_ms / kernel_ms, 4)
+    return out
+
+
 def cpu_sample_frame(wl, max_paths=1 << 21):
     """The frame the CPU renders: the workload's own when it has at most ~2M paths, otherwise the same scene,
     camera and samples per pixel at a resolution reduced to that many paths (a bounded sample, tens of seconds)."""
@@ -536,6 +566,7 @@ def main():
         traffic = recorded_traffic(args.workload, "trace_rays_persistent_kernel")
         if traffic is not None:
             kernel_name = "trace_rays_persistent_kernel"
+    valu_insts = recorded_valu_insts(args.workload, kernel_name)
     if rank == 0:
         value = total_rays * args.steps / elapsed / 1e6
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
@@ -573,7 +604,11 @@ def main():
                          # launches by the timed region instead
                          "concurrent_launches": n_streams,
                          "achieved_overlapped": round(algo_bytes * args.steps / elapsed / 1e9, 2),
-                         "frac_overlapped": round(algo_bytes * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 5)},
+                         "frac_overlapped": round(algo_bytes * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 5),
+                         # the cache-resident frames are bound by vector-ALU issue, not by bytes: instructions per launch
+                         # (SQ_INSTS_VALU, recorded like `traffic`) x 4 cycles each, over the cycles all SIMDs had in the
+                         # time one launch took on the chip (alone: kernel_ms; overlapped: the timed region / steps)
+                         "valu": valu_issue(valu_insts, kernel_ms, elapsed * 1e3 / args.steps, n_streams)},
             "scene_build_ms": {"blas": round(blas_ms, 4), "tlas": round(tlas_ms, 4), "tlas_rebuild_call": round(tlas_call_ms, 4),
                                "instances": int(flat.instances.size)},
         }

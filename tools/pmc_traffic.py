@@ -1,9 +1,11 @@
-"""Turns the FETCH_SIZE / WRITE_SIZE passes of tools/pmc_traffic.sh into profiles/traffic.json.
+"""Turns the FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU passes of tools/pmc_traffic.sh into profiles/traffic.json.
 
 Per workload and kernel: mean counter value per launch and
     hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024
 FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE tallies the 128-byte read requests of
 the L2's memory side at 64 bytes each, hence the factor 2 on the read side.
+valu_insts_per_launch = SQ_INSTS_VALU: vector-ALU instructions issued, counted per wave (one wave64 instruction
+occupies its SIMD for 4 cycles).
 """
 import csv
 import glob
@@ -21,8 +23,10 @@ def short(name: str) -> str:
 
 def main(src: str, dst: str) -> None:
     table = defaultdict(lambda: defaultdict(lambda: defaultdict(list)))
-    for d in sorted(glob.glob(os.path.join(src, "*_SIZE"))):
-        workload, counter = os.path.basename(d).rsplit("_", 2)[0], "_".join(os.path.basename(d).rsplit("_", 2)[1:])
+    for d in sorted(glob.glob(os.path.join(src, "*_SIZE")) + glob.glob(os.path.join(src, "*_SQ_INSTS_VALU"))):
+        base = os.path.basename(d)
+        counter = "SQ_INSTS_VALU" if base.endswith("_SQ_INSTS_VALU") else "_".join(base.rsplit("_", 2)[1:])
+        workload = base[: -len(counter) - 1]
         for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
             with open(path) as f:
                 for row in csv.DictReader(f):
@@ -47,6 +51,10 @@ def main(src: str, dst: str) -> None:
             fm, wm = sum(f) / len(f), sum(w) / len(w)
             out[workload][k] = dict(launches=len(f), fetch_size_kib=round(fm, 1), write_size_kib=round(wm, 1),
                                     hbm_bytes_per_launch=int((2.0 * fm + wm) * 1024))
+            v = c.get("SQ_INSTS_VALU", [])
+            if v:
+                v = [x for g, x in v if g == max(g for g, _ in v)]
+                out[workload][k]["valu_insts_per_launch"] = int(sum(v) / len(v))
     with open(dst, "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
     for workload in out:
