@@ -295,6 +295,29 @@ __device__ __forceinline__ Hit closest_hit_query(const DevScene& S, V3 wo, V3 wd
     return T.h;
 }
 
+// The same query with the instance entries of a wave run in batches: a lane that reaches an instance parks there
+// (trav_step<COUNT, true>) and the wave runs the entry (two quaternion rotations, nine divisions: the longest branch of
+// the walk) once `batch` lanes wait or no lane is left to step.  Every lane does the same tests in the same order; only
+// how often the wave executes the entry code changes.  Pays where the meshes are a handful of triangles and rays
+// enter instances every few steps (Cornell: +6 %); with real meshes the parked lanes cost more than the entries saved.
+template <bool COUNT>
+__device__ __forceinline__ Hit closest_hit_query_batched(const DevScene& S, V3 wo, V3 wd, Counters& cnt, uint32_t batch) {
+    Trav T;
+    trav_begin(T, S, wo, wd);
+    for (;;) {
+        const uint64_t walking = __ballot(1);  // the lanes still in this loop
+        if (COUNT && (int)(threadIdx.x & 63) == __ffsll((long long)walking) - 1) cnt.wave_steps++;
+        const uint64_t parked = __ballot(T.pend_id != 0);
+        const bool enter_now = parked != 0 && ((uint32_t)__popcll(parked) >= batch || parked == walking);
+        if (T.pend_id != 0) {
+            if (enter_now) trav_enter<COUNT>(T, S, cnt);
+        } else if (trav_step<COUNT, true>(T, S, cnt)) {
+            break;
+        }
+    }
+    return T.h;
+}
+
 // Occlusion: whether the same query over the interval [EPSILON_F32, tmax] would report a hit.  The
 // walk up to the first accepted primitive does not depend on anything after it, so it stops there.
 template <bool COUNT>

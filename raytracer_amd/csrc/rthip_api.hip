@@ -121,6 +121,8 @@ int rthip_create(rthip_ctx** out_ctx, int device_id) {
     const char* ib = getenv("RTHIP_INST_BATCH");
     if (ib && atoi(ib) >= 0 && atoi(ib) <= 64) ctx->inst_batch = (uint32_t)atoi(ib);
     const char* refill = getenv("RTHIP_REFILL");
+    const char* sib = getenv("RTHIP_SAMPLES_INST_BATCH");
+    if (sib && atoi(sib) >= 0 && atoi(sib) <= 64) ctx->samples_inst_batch_env = atoi(sib);
     if (refill && atoi(refill) >= 1 && atoi(refill) <= 64) ctx->refill_lanes = (uint32_t)atoi(refill);
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
@@ -402,6 +404,16 @@ int rthip_tlas_build(rthip_ctx* ctx, const rthip_instance* instances, uint32_t n
         if (materials[k].type > RTHIP_MAT_LIGHT)
             return rthip_fail(ctx, RTHIP_E_INVALID, "material %u: unknown type %u", k, materials[k].type);
 
+    {   // mesh instances of a few triangles each (at most 32 nodes on average): rays enter an instance every few steps
+        uint64_t mesh_instances = 0, nodes = 0;
+        for (const DevInstance& d : dev)
+            if (d.type == RTHIP_INST_MESH) {
+                mesh_instances++;
+                nodes += d.n_nodes;
+            }
+        ctx->samples_inst_batch = (mesh_instances != 0 && nodes <= 32 * mesh_instances) ? 64u : 0u;
+        if (ctx->samples_inst_batch_env >= 0) ctx->samples_inst_batch = (uint32_t)ctx->samples_inst_batch_env;
+    }
     RT_HIP(ctx, hipDeviceSynchronize());  // the previous structure may still be in use by an enqueued cast
     ctx->tlas_built = false;
     ctx->n_inst = n_instances;

@@ -149,6 +149,8 @@ struct rthip_ctx {
     DevBuf wf[11];               // path-state arrays of the wavefront renderer
     uint64_t wf_capacity = 1ull << 23;  // paths per wavefront batch
     uint32_t inst_batch = 0;     // persistent kernel chosen by name: 0 = enter instances at once, k = park and enter k lanes at a time (RTHIP_INST_BATCH)
+    uint32_t samples_inst_batch = 0;  // sample-per-lane kernel: lanes parked at an instance that make the wave enter (0: a lane enters at once); set by rthip_tlas_build from the mesh sizes, RTHIP_SAMPLES_INST_BATCH overrides
+    int samples_inst_batch_env = -1;
     uint32_t refill_lanes = 16;  // lanes with other work that end a traversal phase (RTHIP_REFILL overrides)
     DevBuf scratch_a, scratch_b, scratch_c, scratch_d, scratch_e;  // staging for host <-> device taps
     ObjState obj;

@@ -324,11 +324,11 @@ __global__ __launch_bounds__(kBlock, RT_STATIC_WAVES) void cast_static_kernel(De
 // kernel would hold the frame in a few long-running waves (Cornell 512^2 at 4 spp: 4096 waves, all resident from the
 // start, the slowest 1.5 times the median).  The samples of a pixel are added in the order of the sample loop
 // (raytracer_cpu.c:196-236) by the pixel's first lane, so the sum has the same bits.
-template <bool COUNT>
+template <bool COUNT, bool BATCH>
 __global__ __launch_bounds__(kBlock, RT_STATIC_WAVES) void cast_samples_kernel(DevScene S, rthip_cast_settings c, uint64_t seed,
                                                               float* __restrict__ out, int width, int height,
                                                               rthip_shard shard, uint32_t log2_group, uint32_t accumulate,
-                                                              uint64_t* counters) {
+                                                              uint64_t* counters, uint32_t inst_batch) {
     extern __shared__ uint32_t bounce_stack[];
     uint32_t* stack = bounce_stack + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(kBlock, RT_STATIC_WAVES) void cast_samples_kernel(D
         if (P.depth != 0) {
             for (;;) {
                 rays++;
-                const Hit h = closest_hit_query<COUNT>(S, o, d, cnt);
+                const Hit h = BATCH ? closest_hit_query_batched<COUNT>(S, o, d, cnt, inst_batch) : closest_hit_query<COUNT>(S, o, d, cnt);
                 if (path_bounce(S, P, h, o, d, L, stack, kBlock)) break;
             }
             L = path_fold(S, P, L, stack, kBlock);
@@ -692,10 +692,19 @@ int launch_samples(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_setti
     const uint32_t log2_group = cast.samples == 2 ? 2u : (cast.samples == 4 ? 4u : 6u);
     const uint32_t tile = log2_group == 2 ? 8u : (log2_group == 4 ? 4u : 2u);  // pixels a workgroup covers, per side
     const uint32_t blocks = div_up(width, tile) * div_up(height, tile);
-    if (d_counters)
-        cast_samples_kernel<true><<<blocks, kBlock, lds, stream>>>(scene, cast, seed, d_rgb, width, height, shard, log2_group, ctx->cast_accumulate, d_counters);
-    else
-        cast_samples_kernel<false><<<blocks, kBlock, lds, stream>>>(scene, cast, seed, d_rgb, width, height, shard, log2_group, ctx->cast_accumulate, nullptr);
+    // scenes of small meshes (a few triangles each: rays enter an instance every few steps) run the instance entries in batches
+    const uint32_t ib = ctx->samples_inst_batch;
+#define RT_LAUNCH_SAMPLES(COUNT, BATCH, CNT)                                                                               \
+    cast_samples_kernel<COUNT, BATCH><<<blocks, kBlock, lds, stream>>>(scene, cast, seed, d_rgb, width, height, shard, log2_group, \
+                                                                       ctx->cast_accumulate, CNT, ib)
+    if (d_counters) {
+        if (ib) RT_LAUNCH_SAMPLES(true, true, d_counters);
+        else RT_LAUNCH_SAMPLES(true, false, d_counters);
+    } else {
+        if (ib) RT_LAUNCH_SAMPLES(false, true, nullptr);
+        else RT_LAUNCH_SAMPLES(false, false, nullptr);
+    }
+#undef RT_LAUNCH_SAMPLES
     RT_HIP(ctx, hipGetLastError());
     return RTHIP_OK;
 }
