@@ -248,10 +248,11 @@ __device__ __forceinline__ bool pixel_of_thread(int width, int height, int& x, i
 #ifndef RT_STATIC_WAVES
 #define RT_STATIC_WAVES 5
 #endif
-template <bool COUNT>
+template <bool COUNT, bool BATCH = false>
 __global__ __launch_bounds__(kBlock, RT_STATIC_WAVES) void cast_static_kernel(DevScene S, rthip_cast_settings c, uint64_t seed,
                                                              float* __restrict__ out, int width, int height,
-                                                             rthip_shard shard, uint32_t accumulate, uint64_t* counters) {
+                                                             rthip_shard shard, uint32_t accumulate, uint64_t* counters,
+                                                             uint32_t inst_batch = 0) {
     extern __shared__ uint32_t bounce_stack[];
     uint32_t* stack = bounce_stack + threadIdx.x;
     int x, y;
@@ -286,7 +287,7 @@ __global__ __launch_bounds__(kBlock, RT_STATIC_WAVES) void cast_static_kernel(De
                     if (P.depth != 0) {
                         for (;;) {
                             rays++;
-                            const Hit h = closest_hit_query<COUNT>(S, o, d, cnt);
+                            const Hit h = BATCH ? closest_hit_query_batched<COUNT>(S, o, d, cnt, inst_batch) : closest_hit_query<COUNT>(S, o, d, cnt);
                             if (path_bounce(S, P, h, o, d, L, stack, kBlock)) break;
                         }
                         L = path_fold(S, P, L, stack, kBlock);
@@ -674,10 +675,18 @@ int cast_records_launch(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_
 namespace {
 
 int launch_static(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_settings& cast, uint64_t seed, float* d_rgb,
-                  int width, int height, rthip_shard shard, uint64_t* d_counters, hipStream_t stream) {
+                  int width, int height, rthip_shard shard, uint64_t* d_counters, hipStream_t stream, bool probe = false) {
     const size_t lds = (size_t)(scene.max_bounces ? scene.max_bounces : 1) * kBlock * sizeof(uint32_t);
     const uint32_t blocks = div_up(width, 16) * div_up(height, 16);
-    if (d_counters)
+    // scenes of small meshes: instance entries of a wave run together (launch_samples); the kernel-choice probe counts
+    // the plain walk, which its thresholds were measured on
+    const uint32_t ib = probe ? 0u : ctx->samples_inst_batch;
+    if (ib) {
+        if (d_counters)
+            cast_static_kernel<true, true><<<blocks, kBlock, lds, stream>>>(scene, cast, seed, d_rgb, width, height, shard, ctx->cast_accumulate, d_counters, ib);
+        else
+            cast_static_kernel<false, true><<<blocks, kBlock, lds, stream>>>(scene, cast, seed, d_rgb, width, height, shard, ctx->cast_accumulate, nullptr, ib);
+    } else if (d_counters)
         cast_static_kernel<true><<<blocks, kBlock, lds, stream>>>(scene, cast, seed, d_rgb, width, height, shard, ctx->cast_accumulate, d_counters);
     else
         cast_static_kernel<false><<<blocks, kBlock, lds, stream>>>(scene, cast, seed, d_rgb, width, height, shard, ctx->cast_accumulate, nullptr);
@@ -775,7 +784,7 @@ int tune_cast(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_settings& 
     uint64_t* d_cnt = (uint64_t*)ctx->tune_counters.p;
     uint64_t h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     RT_HIP(ctx, hipMemsetAsync(d_cnt, 0, 64, stream));
-    RT_TRY(launch_static(ctx, scene, pc, seed, d_rgb, width, height, probe, d_cnt, stream));
+    RT_TRY(launch_static(ctx, scene, pc, seed, d_rgb, width, height, probe, d_cnt, stream, true));
     RT_HIP(ctx, hipMemcpyAsync(h, d_cnt, 64, hipMemcpyDeviceToHost, stream));
     RT_HIP(ctx, hipStreamSynchronize(stream));
     const double rays = (double)h[0], nodes = (double)h[1], entries = (double)h[3], steps = (double)h[4];
