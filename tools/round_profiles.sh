@@ -4,6 +4,11 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/round
 mkdir -p $OUT
 cd $ROOT
+# the counter passes first: the bench lines quote the traffic and instruction counts of THIS tree from profiles/traffic.json
+bash tools/pmc_traffic.sh bunny instanced soup cornell soup-rays instanced-rays cornell-mesh > $OUT/pmc_traffic.log 2>&1 || exit 1
+cp gpurun_out/traffic.json $OUT/traffic.json
+python3 tools/pmc_traffic.py gpurun_out/pmc_traffic $OUT/traffic.json > $OUT/pmc_traffic.txt
+cp $OUT/traffic.json profiles/traffic.json
 timeout -k 10 400 python3 -u bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err || exit 1
 timeout -k 10 400 python3 -u bench.py --streams 1 --no-cpu-baseline --build-sizes "" > $OUT/bench_default_streams1.json 2> $OUT/bench_default_streams1.err || exit 1
 for w in cornell instanced soup soup-rays instanced-rays cornell-mesh; do
@@ -16,8 +21,5 @@ WORKLOADS="bunny cornell instanced soup cornell-mesh" bash tools/sweep_cast_kern
 cd /tmp; export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_default -- python3 $ROOT/bench.py --no-cpu-baseline > $OUT/prof_default.log 2>&1 || exit 1
 cd $ROOT
-bash tools/pmc_traffic.sh bunny instanced soup cornell soup-rays instanced-rays cornell-mesh > $OUT/pmc_traffic.log 2>&1 || exit 1
-cp gpurun_out/traffic.json $OUT/traffic.json
-python3 tools/pmc_traffic.py gpurun_out/pmc_traffic $OUT/traffic.json > $OUT/pmc_traffic.txt
 python3 tools/build_breakdown.py $OUT/prof_default/*/*kernel_trace.csv > $OUT/build_10M_breakdown.txt
 echo done
