@@ -15,7 +15,7 @@ acc=collections.defaultdict(list)
 for p in glob.glob("$ROOT/gpurun_out/pmc_${W}_pass*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(p)):
         n=r['Kernel_Name']
-        if ('cast_' in n or 'wf_trace' in n) and '<true>' not in n:
+        if ('cast_' in n or 'wf_trace' in n) and '<true' not in n:
             acc[(n.split('(')[0].split('::')[-1], r['Counter_Name'])].append((float(r['Counter_Value']), int(r['End_Timestamp'])-int(r['Start_Timestamp'])))
 for (k,c),v in sorted(acc.items()):
     print(f"{k:30s} {c:26s} {sum(a for a,_ in v)/len(v):16.0f}   kernel {sum(b for _,b in v)/len(v)/1e6:9.3f} ms")

@@ -11,7 +11,7 @@ acc=collections.defaultdict(list)
 for p in glob.glob("$out/*/*counter_collection.csv"):
     for r in csv.DictReader(open(p)):
         n=r['Kernel_Name']
-        if ('cast_' in n or 'trace_rays' in n) and '<true>' not in n:
+        if ('cast_' in n or 'trace_rays' in n) and '<true' not in n:
             acc[(n.split('(')[0].split('::')[-1], r['Counter_Name'])].append(float(r['Counter_Value']))
 for (k,c),v in sorted(acc.items()):
     print(f"$W {k:30s} {c:32s} {sum(v)/len(v):16.0f}")

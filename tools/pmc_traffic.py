@@ -33,8 +33,8 @@ def main(src: str, dst: str) -> None:
                     if row["Counter_Name"] != counter:
                         continue
                     k = short(row["Kernel_Name"])
-                    if k.startswith("__amd") or "at::" in row["Kernel_Name"] or k.endswith("<true>"):
-                        continue  # runtime fills/copies, torch kernels, the counting launch
+                    if k.startswith("__amd") or "at::" in row["Kernel_Name"] or "<true" in k:
+                        continue  # runtime fills/copies, torch kernels, the counting launches (first template argument)
                     k = k.split("<")[0]
                     table[workload][k][counter].append((int(row["Grid_Size"]), float(row["Counter_Value"])))
     out = {}
