@@ -411,8 +411,7 @@ int rthip_tlas_build(rthip_ctx* ctx, const rthip_instance* instances, uint32_t n
                 mesh_instances++;
                 nodes += d.n_nodes;
             }
-        ctx->samples_inst_batch = (mesh_instances != 0 && nodes <= 32 * mesh_instances) ? 64u : 0u;
-        if (ctx->samples_inst_batch_env >= 0) ctx->samples_inst_batch = (uint32_t)ctx->samples_inst_batch_env;
+        ctx->small_meshes = mesh_instances != 0 && nodes <= 32 * mesh_instances;
     }
     RT_HIP(ctx, hipDeviceSynchronize());  // the previous structure may still be in use by an enqueued cast
     ctx->tlas_built = false;

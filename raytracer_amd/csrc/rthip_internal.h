@@ -149,8 +149,13 @@ struct rthip_ctx {
     DevBuf wf[11];               // path-state arrays of the wavefront renderer
     uint64_t wf_capacity = 1ull << 23;  // paths per wavefront batch
     uint32_t inst_batch = 0;     // persistent kernel chosen by name: 0 = enter instances at once, k = park and enter k lanes at a time (RTHIP_INST_BATCH)
-    uint32_t samples_inst_batch = 0;  // sample-per-lane kernel: lanes parked at an instance that make the wave enter (0: a lane enters at once); set by rthip_tlas_build from the mesh sizes, RTHIP_SAMPLES_INST_BATCH overrides
-    int samples_inst_batch_env = -1;
+    // pixel- / sample-per-lane kernels: instance entries of a wave in batches (entry_batch, trace.hip)
+    bool small_meshes = false;        // set by rthip_tlas_build: the mesh instances average at most 32 nodes
+    int samples_inst_batch_env = -1;  // RTHIP_SAMPLES_INST_BATCH
+    bool batch_known = false;         // the measured decision for batch_key (scene generation, frame size, samples, sharding)
+    uint64_t batch_key[4] = {0, 0, 0, 0};
+    uint32_t batch_value = 0;
+    double probed_entry_ratio = 0.0;  // instance entries per box test of the last kernel-choice probe
     uint32_t refill_lanes = 16;  // lanes with other work that end a traversal phase (RTHIP_REFILL overrides)
     DevBuf scratch_a, scratch_b, scratch_c, scratch_d, scratch_e;  // staging for host <-> device taps
     ObjState obj;

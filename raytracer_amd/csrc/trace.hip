@@ -675,12 +675,10 @@ int cast_records_launch(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_
 namespace {
 
 int launch_static(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_settings& cast, uint64_t seed, float* d_rgb,
-                  int width, int height, rthip_shard shard, uint64_t* d_counters, hipStream_t stream, bool probe = false) {
+                  int width, int height, rthip_shard shard, uint64_t* d_counters, hipStream_t stream, uint32_t ib = 0) {
     const size_t lds = (size_t)(scene.max_bounces ? scene.max_bounces : 1) * kBlock * sizeof(uint32_t);
     const uint32_t blocks = div_up(width, 16) * div_up(height, 16);
-    // scenes of small meshes: instance entries of a wave run together (launch_samples); the kernel-choice probe counts
-    // the plain walk, which its thresholds were measured on
-    const uint32_t ib = probe ? 0u : ctx->samples_inst_batch;
+    // ib != 0: the instance entries of a wave run in batches (closest_hit_query_batched; entry_batch decides)
     if (ib) {
         if (d_counters)
             cast_static_kernel<true, true><<<blocks, kBlock, lds, stream>>>(scene, cast, seed, d_rgb, width, height, shard, ctx->cast_accumulate, d_counters, ib);
@@ -696,13 +694,12 @@ int launch_static(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_settin
 
 // samples = 2, 4 or 8 only (4, 16 or 64 lanes per pixel)
 int launch_samples(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_settings& cast, uint64_t seed, float* d_rgb,
-                   int width, int height, rthip_shard shard, uint64_t* d_counters, hipStream_t stream) {
+                   int width, int height, rthip_shard shard, uint64_t* d_counters, hipStream_t stream, uint32_t ib = 0) {
     const size_t lds = (size_t)(scene.max_bounces ? scene.max_bounces : 1) * kBlock * sizeof(uint32_t);
     const uint32_t log2_group = cast.samples == 2 ? 2u : (cast.samples == 4 ? 4u : 6u);
     const uint32_t tile = log2_group == 2 ? 8u : (log2_group == 4 ? 4u : 2u);  // pixels a workgroup covers, per side
     const uint32_t blocks = div_up(width, tile) * div_up(height, tile);
-    // scenes of small meshes (a few triangles each: rays enter an instance every few steps) run the instance entries in batches
-    const uint32_t ib = ctx->samples_inst_batch;
+    // ib != 0: the instance entries of a wave run in batches (closest_hit_query_batched; entry_batch decides)
 #define RT_LAUNCH_SAMPLES(COUNT, BATCH, CNT)                                                                               \
     cast_samples_kernel<COUNT, BATCH><<<blocks, kBlock, lds, stream>>>(scene, cast, seed, d_rgb, width, height, shard, log2_group, \
                                                                        ctx->cast_accumulate, CNT, ib)
@@ -768,8 +765,17 @@ struct Candidate {
 // soup 0.30 / 145, 10k instances 0.24 / 146, Cornell + mesh at 4K 0.16 / 22 are 25-45 % faster on the
 // persistent one).  The counters are deterministic, so the choice is the same on every run.  The probe
 // waits on the stream, so it is skipped while the stream is being captured.
-int tune_cast(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_settings& cast, uint64_t seed, float* d_rgb, int width,
-              int height, rthip_shard shard, hipStream_t stream, Candidate* best) {
+// The counted probe: a sparse sample of 64x64 tiles, one sample per pixel, pixel-per-thread kernel, plain walk.
+// h = {rays, box tests, triangle tests, instance entries, wave steps}.  Renders into d_rgb (or, for an accumulating
+// cast, into a buffer of its own) and waits on the stream.
+int probe_counters(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_settings& cast, uint64_t seed, float* d_rgb, int width,
+                   int height, rthip_shard shard, hipStream_t stream, uint64_t h[8], uint32_t* stride_out) {
+    float* probe_rgb = d_rgb;
+    const uint32_t accumulate = ctx->cast_accumulate;
+    if (accumulate) {
+        RT_TRY(rthip_reserve(ctx, ctx->tune_frame, (size_t)width * height * 3 * sizeof(float)));
+        probe_rgb = (float*)ctx->tune_frame.p;
+    }
     rthip_cast_settings pc = cast;
     pc.samples = 1;
     const uint32_t tiles64 = div_up(width, 64) * div_up(height, 64);
@@ -782,11 +788,24 @@ int tune_cast(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_settings& 
     }
     RT_TRY(rthip_reserve(ctx, ctx->tune_counters, 64));
     uint64_t* d_cnt = (uint64_t*)ctx->tune_counters.p;
-    uint64_t h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int k = 0; k < 8; k++) h[k] = 0;
     RT_HIP(ctx, hipMemsetAsync(d_cnt, 0, 64, stream));
-    RT_TRY(launch_static(ctx, scene, pc, seed, d_rgb, width, height, probe, d_cnt, stream, true));
+    ctx->cast_accumulate = 0;
+    const int rc = launch_static(ctx, scene, pc, seed, probe_rgb, width, height, probe, d_cnt, stream);
+    ctx->cast_accumulate = accumulate;
+    RT_TRY(rc);
     RT_HIP(ctx, hipMemcpyAsync(h, d_cnt, 64, hipMemcpyDeviceToHost, stream));
     RT_HIP(ctx, hipStreamSynchronize(stream));
+    if (stride_out) *stride_out = stride;
+    return RTHIP_OK;
+}
+
+int tune_cast(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_settings& cast, uint64_t seed, float* d_rgb, int width,
+              int height, rthip_shard shard, hipStream_t stream, Candidate* best) {
+    uint64_t h[8];
+    uint32_t stride = 1;
+    RT_TRY(probe_counters(ctx, scene, cast, seed, d_rgb, width, height, shard, stream, h, &stride));
+    ctx->probed_entry_ratio = h[1] ? (double)h[3] / (double)h[1] : 0.0;
     const double rays = (double)h[0], nodes = (double)h[1], entries = (double)h[3], steps = (double)h[4];
     const double util = steps > 0 ? nodes / (64.0 * steps) : 1.0;
     const double nodes_per_ray = rays > 0 ? nodes / rays : 0.0;
@@ -804,6 +823,41 @@ int tune_cast(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_settings& 
     if (getenv("RTHIP_TUNE_LOG"))
         fprintf(stderr, "rthip tune: 1 tile in %u, %.0f rays, %.1f box tests per ray, lane utilisation %.3f -> kernel %d refill %u instance batch %u\n",
                 stride, rays, nodes_per_ray, util, best->kernel, best->refill, best->inst_batch);
+    return RTHIP_OK;
+}
+
+// Whether the pixel- and sample-per-lane kernels run a wave's instance entries in batches (closest_hit_query_batched).
+// It pays where rays enter an instance every few box tests: measured over grids of 16 ... 10 000 instances of quads, boxes
+// and icosahedra and the Cornell box (tools/probe_entries.py), +10 % where the entries are 4.1 % and 4.8 % of the box
+// tests (16 boxes, Cornell) and -6 ... -40 % where they are 3.2 % or less.  Only scenes whose meshes are a handful of
+// triangles can get there (rthip_tlas_build marks them), and for those the counted probe measures the share once per
+// scene, frame size and sharding.  RTHIP_SAMPLES_INST_BATCH overrides.  Skipped (no batches) while the stream is captured.
+constexpr double kEntryBatchRatio = 0.04;
+
+int entry_batch(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_settings& cast, uint64_t seed, float* d_rgb, int width,
+                int height, rthip_shard shard, hipStream_t stream, uint32_t* batch) {
+    *batch = 0;
+    if (ctx->samples_inst_batch_env >= 0) {
+        *batch = (uint32_t)ctx->samples_inst_batch_env;
+        return RTHIP_OK;
+    }
+    if (!ctx->small_meshes) return RTHIP_OK;
+    const uint64_t key[4] = {ctx->scene_generation, ((uint64_t)(uint32_t)width << 32) | (uint32_t)height,
+                             (uint64_t)cast.samples * cast.samples, ((uint64_t)shard.mode << 32) | shard.world};
+    if (!(ctx->batch_known && memcmp(key, ctx->batch_key, sizeof key) == 0)) {
+        hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+        if (stream) (void)hipStreamIsCapturing(stream, &capturing);
+        if (capturing != hipStreamCaptureStatusNone) return RTHIP_OK;
+        uint64_t h[8];
+        RT_TRY(probe_counters(ctx, scene, cast, seed, d_rgb, width, height, shard, stream, h, nullptr));
+        const double ratio = h[1] ? (double)h[3] / (double)h[1] : 0.0;
+        ctx->batch_known = true;
+        memcpy(ctx->batch_key, key, sizeof key);
+        ctx->batch_value = ratio >= kEntryBatchRatio ? 64u : 0u;
+        if (getenv("RTHIP_TUNE_LOG"))
+            fprintf(stderr, "rthip tune: instance entries are %.1f %% of the box tests -> entry batch %u\n", 100.0 * ratio, ctx->batch_value);
+    }
+    *batch = ctx->batch_value;
     return RTHIP_OK;
 }
 
@@ -836,17 +890,10 @@ int cast_launch(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_settings
         if (ctx->tuned && memcmp(key, ctx->tuned_key, sizeof key) == 0) {
             choice = {ctx->tuned_kernel, ctx->tuned_refill, ctx->tuned_inst_batch};
         } else if (paths >= (1ull << 20) && capturing == hipStreamCaptureStatusNone) {
-            // the probe renders into the framebuffer; an accumulating cast gives it a buffer of its own instead
-            float* probe_rgb = d_rgb;
-            const uint32_t accumulate = ctx->cast_accumulate;
-            if (accumulate) {
-                RT_TRY(rthip_reserve(ctx, ctx->tune_frame, (size_t)width * height * 3 * sizeof(float)));
-                probe_rgb = (float*)ctx->tune_frame.p;
-            }
-            ctx->cast_accumulate = 0;
-            const int rc_tune = tune_cast(ctx, scene, cast, seed, probe_rgb, width, height, shard, stream, &choice);
-            ctx->cast_accumulate = accumulate;
-            RT_TRY(rc_tune);
+            RT_TRY(tune_cast(ctx, scene, cast, seed, d_rgb, width, height, shard, stream, &choice));
+            ctx->batch_known = true;  // the probe has counted the instance entries as well
+            memcpy(ctx->batch_key, key, sizeof key);
+            ctx->batch_value = ctx->probed_entry_ratio >= kEntryBatchRatio ? 64u : 0u;
             ctx->tuned = true;
             memcpy(ctx->tuned_key, key, sizeof key);
             ctx->tuned_kernel = choice.kernel;
@@ -864,8 +911,10 @@ int cast_launch(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_settings
     }
     ctx->last_cast_kernel = (uint32_t)choice.kernel;
     ctx->last_cast_refill = choice.kernel == 0 ? choice.refill : 0u;
-    if (choice.kernel == 4) return launch_samples(ctx, scene, cast, seed, d_rgb, width, height, shard, d_counters, stream);
-    if (choice.kernel == 1) return launch_static(ctx, scene, cast, seed, d_rgb, width, height, shard, d_counters, stream);
+    uint32_t ib = 0;
+    if (choice.kernel == 4 || choice.kernel == 1) RT_TRY(entry_batch(ctx, scene, cast, seed, d_rgb, width, height, shard, stream, &ib));
+    if (choice.kernel == 4) return launch_samples(ctx, scene, cast, seed, d_rgb, width, height, shard, d_counters, stream, ib);
+    if (choice.kernel == 1) return launch_static(ctx, scene, cast, seed, d_rgb, width, height, shard, d_counters, stream, ib);
     return launch_persistent(ctx, scene, cast, seed, d_rgb, width, height, shard, choice.refill, choice.inst_batch, d_counters,
                              stream);
 }
