@@ -679,6 +679,34 @@ def test_random_worlds_every_kernel_against_the_oracle(oracle, gpu_tracer):
         check_random_world(oracle, gpu_tracer, seed)
 
 
+def test_batched_instance_entries_change_no_bit(oracle):
+    """The pixel- and sample-per-lane kernels with a wave's instance entries run in batches (forced on and off through
+    RTHIP_SAMPLES_INST_BATCH, which a context reads when it is made): the Cornell box and a grid of small meshes."""
+    verts, indices = scenes.bunny_class_mesh(0)  # 20 triangles
+    cases = [(scenes.cornell(), 8, (96, 80)), (scenes.instanced_grid(5, seed=3, verts=verts, indices=indices), 6, (80, 45))]
+    wanted = {}
+    for batch in ("0", "7", "64"):
+        os.environ["RTHIP_SAMPLES_INST_BATCH"] = batch
+        try:
+            tr = T.rt_make_tracer(T.RT_TracerSettings(max_bounces=8, sky=True))
+        finally:
+            del os.environ["RTHIP_SAMPLES_INST_BATCH"]
+        try:
+            for k, ((w, cam, sky), bounces, (wd, ht)) in enumerate(cases):
+                build(tr, w, bounces, sky)
+                for kernel, smp in (("static", 1), ("static", 3), ("static-samples", 2), ("static-samples", 4)):
+                    T.set_cast_kernel(tr, kernel)
+                    img = np.zeros((ht, wd, 3), dtype=np.float32)
+                    T.rt_tracer_cast(tr, cam(wd, ht, smp), img, wd, ht, seed=11)
+                    key = (k, smp)
+                    if key not in wanted:
+                        sc = oracle.Scene(world.flatten_world(w), bounces, sky)
+                        wanted[key], _ = sc.cast(cam(wd, ht, smp), 11, wd, ht, rng_mode=oracle.RNG_COUNTER, threads=8)
+                    assert (bits(img) == bits(wanted[key])).all(), f"batch {batch}, scene {k}, {kernel}, samples {smp}"
+        finally:
+            T.rt_tracer_cleanup(tr)
+
+
 def test_errors_are_reported(gpu_tracer):
     lib = gpu_tracer.lib
     assert lib.rthip_set_tracer(gpu_tracer.h, 64, 1) == 4  # RTHIP_E_LIMIT, max_bounces < 64
