@@ -450,13 +450,9 @@ def main():
 
     ray_o = ray_d = ray_hits = None
     if is_rays:  # a ray-stream workload: closest-hit queries for explicit rays instead of a frame
-        g = torch.Generator(device="cuda")
-        g.manual_seed(2 + rank)
+        from raytracer_amd import scenes
         lo, hi = wl.get("ray_box", ((0.0, 0.0, 0.0), (1.0, 1.0, 1.0)))
-        lo, hi = torch.tensor(lo, device="cuda"), torch.tensor(hi, device="cuda")
-        ray_o = (lo + torch.rand((wl["rays"], 3), device="cuda", generator=g) * (hi - lo)).contiguous()
-        v = torch.randn((wl["rays"], 3), device="cuda", generator=g)
-        ray_d = (v / v.norm(dim=1, keepdim=True)).contiguous()
+        ray_o, ray_d = scenes.incoherent_rays_device(torch, wl["rays"], 2 + rank, lo, hi)
         ray_hits = [torch.zeros((wl["rays"], 4), dtype=torch.int32, device="cuda") for _ in streams]
     torch.cuda.synchronize()
 

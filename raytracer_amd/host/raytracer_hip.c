@@ -320,20 +320,25 @@ internal int rt_hip_write_hdr(RT_Handle handle, const char* path, int width, int
 // so the loader keeps a GPU context of its own, made on first use.  Making it starts the GPU runtime, which draws from
 // rand(); the stream is restarted from its own next value afterwards, so that what rt_make_tracer takes as its seed
 // still depends on the demo's srand(--seed) alone.
+static rthip_ctx* rt_hip_loader_ctx = NULL;
+static void rt_hip_loader_release(void) {
+    if (rt_hip_loader_ctx) rthip_destroy(rt_hip_loader_ctx);
+    rt_hip_loader_ctx = NULL;
+}
 internal MS_LoadResult rt_hip_load_obj(Arena* arena, NTString8 path, MS_LoadSettings settings) {
-    static rthip_ctx* loader = NULL;
-    if (!loader) {
+    if (!rt_hip_loader_ctx) {
+        atexit(rt_hip_loader_release);  // the loader's context lives until the program ends
         unsigned keep = (unsigned)rand();
         const char* dev = getenv("RT_HIP_DEVICE");
-        int rc = rthip_create(&loader, dev ? atoi(dev) : 0);
+        int rc = rthip_create(&rt_hip_loader_ctx, dev ? atoi(dev) : 0);
         srand(keep);
         if (rc != RTHIP_OK) fprintf(stderr, "rthip: no usable MI355X (gfx950) device; this backend has no CPU path\n");
         AssertAlways(rc == RTHIP_OK);
     }
     MS_LoadResult result = zero_struct;
     rthip_obj_info info = zero_struct;
-    if (rthip_obj_load(loader, path.cstr, (uint32_t)settings.attrs, &info) != RTHIP_OK) {
-        fprintf(stderr, "rthip: %s\n", rthip_last_error(loader));
+    if (rthip_obj_load(rt_hip_loader_ctx, path.cstr, (uint32_t)settings.attrs, &info) != RTHIP_OK) {
+        fprintf(stderr, "rthip: %s\n", rthip_last_error(rt_hip_loader_ctx));
         result.error = (NTString8)ntstr8_lit_init("Failed to open file");  // the reference's only error, mesh.c:76-78
         return result;
     }
@@ -343,8 +348,8 @@ internal MS_LoadResult rt_hip_load_obj(Arena* arena, NTString8 path, MS_LoadSett
     result.v.indices_count = info.index_count;
     result.v.vertices = arena_push(arena, (u64)info.vertex_bytes*info.vertex_count + 16, 16);
     result.v.indices = push_array(arena, u32, info.index_count + 1);
-    int rc = rthip_obj_get(loader, (float*)result.v.vertices, result.v.indices);
-    if (rc != RTHIP_OK) fprintf(stderr, "rthip: %s\n", rthip_last_error(loader));
+    int rc = rthip_obj_get(rt_hip_loader_ctx, (float*)result.v.vertices, result.v.indices);
+    if (rc != RTHIP_OK) fprintf(stderr, "rthip: %s\n", rthip_last_error(rt_hip_loader_ctx));
     AssertAlways(rc == RTHIP_OK);
     result.error = (NTString8)ntstr8_lit_init("");
     return result;

@@ -474,6 +474,18 @@ def random_rays(n: int, seed: int, lo=(0.0, 0.0, 0.0), hi=(1.0, 1.0, 1.0)):
     return o.astype(np.float32), d
 
 
+def incoherent_rays_device(torch, n: int, seed: int, lo=(0.0, 0.0, 0.0), hi=(1.0, 1.0, 1.0)):
+    """The benchmark's incoherent ray stream, generated on the GPU (torch's generator): origins uniform in the box
+    [lo, hi], directions uniform on the sphere (normalised Gaussians).  Returns two contiguous float32 [n, 3] tensors."""
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    lo_t, hi_t = torch.tensor(lo, device="cuda"), torch.tensor(hi, device="cuda")
+    o = (lo_t + torch.rand((n, 3), device="cuda", generator=g) * (hi_t - lo_t)).contiguous()
+    v = torch.randn((n, 3), device="cuda", generator=g)
+    d = (v / v.norm(dim=1, keepdim=True)).contiguous()
+    return o, d
+
+
 # ---- awkward inputs for the parity tests -----------------------------------------------------
 
 

@@ -602,6 +602,103 @@ def test_long_ray_stream(oracle, gpu_tracer):
     assert (inst2 == oi).all()
 
 
+def test_soup_scene_rays_and_frames(oracle, gpu_tracer):
+    """A 200 000-triangle soup (one deep BLAS, the benchmark's 10 M-triangle scene in small): incoherent rays with
+    their traversal counters and a path-traced frame from every kernel against the oracle."""
+    w, cam, sky = scenes.soup_world(200_000, seed=1)
+    build(gpu_tracer, w, 4, sky)
+    flat = world.flatten_world(w)
+    sc = oracle.Scene(flat, 4, sky)
+    assert_same_tree(T.get_tree(gpu_tracer, 0), sc.tree(0), "soup BLAS")
+    o, d = scenes.random_rays(40_000, seed=2)
+    T.set_counting(gpu_tracer, True)
+    T.get_stats(gpu_tracer)
+    inst, tri, t, uv, nrm = T.trace_rays(gpu_tracer, o, d)
+    st = T.get_stats(gpu_tracer)
+    T.set_counting(gpu_tracer, False)
+    oi, ot, ott, ouv, onrm, cnt = sc.trace(o, d, threads=8)
+    assert (inst == oi).all() and (tri == ot).all() and (bits(t) == bits(ott)).all()
+    assert (bits(uv) == bits(ouv)).all() and (bits(nrm) == bits(onrm)).all()
+    assert 100 < int((inst > 0).sum()) < 40_000
+    for k in ("rays", "nodes_tested", "tris_tested", "inst_entered"):
+        assert st[k] == cnt[k], f"traversal counter {k}: {st[k]} vs {cnt[k]}"
+    assert (T.occluded(gpu_tracer, o, d, 0.25) == sc.occluded(o, d, 0.25)).all()
+    c = cam(96, 54, 2)
+    want, _ = sc.cast(c, 6, 96, 54, rng_mode=oracle.RNG_COUNTER, threads=8)
+    try:
+        for kernel in ("static", "persistent", "static-samples", "wavefront", "auto"):
+            T.set_cast_kernel(gpu_tracer, kernel)
+            img = np.zeros((54, 96, 3), dtype=np.float32)
+            T.rt_tracer_cast(gpu_tracer, c, img, 96, 54, seed=6)
+            assert (bits(img) == bits(want)).all(), kernel
+    finally:
+        T.set_cast_kernel(gpu_tracer, "auto")
+
+
+def test_ten_million_triangle_soup_incoherent_rays(oracle, gpu_tracer):
+    """The benchmark's 10 M-triangle scene and its ray stream (2^24 incoherent rays, seed 2) at full size: the plain
+    ray kernel (the one such a scene takes by default) and the resident-wave kernel must agree on every ray bit for bit,
+    and the first 2^16 rays -- hits, distances and traversal counters -- must be the oracle's on the same scene."""
+    import torch
+
+    w, cam, sky = scenes.soup_world(10_000_000, seed=1)
+    build(gpu_tracer, w, 1, sky)
+    flat = world.flatten_world(w)
+    n = 1 << 24
+    o, d = scenes.incoherent_rays_device(torch, n, 2)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def run(count, counting=False):
+        hits = torch.full((count, 4), -1, dtype=torch.int32, device="cuda")
+        if counting:
+            T.set_counting(gpu_tracer, True)
+            T.get_stats(gpu_tracer)
+        gpu_tracer.check(gpu_tracer.lib.rthip_trace_rays_device(gpu_tracer.h, o.data_ptr(), d.data_ptr(), count, hits.data_ptr(),
+                                                                stream), "rthip_trace_rays_device")
+        torch.cuda.synchronize()
+        st = None
+        if counting:
+            st = T.get_stats(gpu_tracer)
+            T.set_counting(gpu_tracer, False)
+        return hits, st
+
+    try:
+        T.set_cast_kernel(gpu_tracer, "auto")  # a scene of this size takes trace_rays_kernel
+        plain, _ = run(n)
+        T.set_cast_kernel(gpu_tracer, "persistent")  # forces trace_rays_persistent_kernel
+        resident, _ = run(n)
+        assert torch.equal(plain, resident), "plain and resident-wave ray kernels differ"
+        assert bool((plain[:, 3] == 0).all())
+        hit_share = float((plain[:, 0] != 0).float().mean())
+        assert 0.5 < hit_share < 1.0, hit_share
+        T.set_cast_kernel(gpu_tracer, "auto")
+        m = 1 << 16
+        head, st = run(m, counting=True)
+        assert torch.equal(head, plain[:m])
+    finally:
+        T.set_cast_kernel(gpu_tracer, "auto")
+    sc = oracle.Scene(flat, 1, sky)
+    oi, ot, ott, _, _, cnt = sc.trace(o[:m].cpu().numpy(), d[:m].cpu().numpy(), threads=8, want_normal=False)
+    got = head.cpu().numpy().view(np.uint32)
+    assert (got[:, 0] == oi).all() and (got[:, 1] == ot).all(), f"{int((got[:, 0] != oi).sum())} rays hit another instance"
+    assert (got[:, 2] == bits(ott)).all(), "t bits differ"
+    for k in ("rays", "nodes_tested", "tris_tested", "inst_entered"):
+        assert st[k] == cnt[k], f"traversal counter {k}: {st[k]} vs {cnt[k]}"
+    # the camera frame of the same scene (bench workload `soup` in small): static and persistent kernels against the oracle
+    gpu_tracer.check(gpu_tracer.lib.rthip_set_tracer(gpu_tracer.h, 4, 1), "set_tracer")
+    sc4 = oracle.Scene(flat, 4, sky)
+    c = cam(64, 36, 1)
+    want, _ = sc4.cast(c, 3, 64, 36, rng_mode=oracle.RNG_COUNTER, threads=8)
+    try:
+        for kernel in ("static", "persistent"):
+            T.set_cast_kernel(gpu_tracer, kernel)
+            img = np.zeros((36, 64, 3), dtype=np.float32)
+            T.rt_tracer_cast(gpu_tracer, c, img, 64, 36, seed=3)
+            assert (bits(img) == bits(want)).all(), kernel
+    finally:
+        T.set_cast_kernel(gpu_tracer, "auto")
+
+
 def test_occlusion_rays(oracle, gpu_tracer):
     """Shadow rays (any-hit walk) against the reference's interval-limited query, and against the
     oracle on an instanced scene with random rays and several tmax."""
