@@ -233,6 +233,15 @@ int rthip_lbvh_build(rthip_ctx* ctx, const float* aabb6, uint64_t n, uint64_t* o
  * and returns without synchronising. */
 int rthip_lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, rthip_node* d_nodes, void* stream);
 
+/* rthip_lbvh_build_device for callers that cannot allocate device memory: code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc.  No counterpart in the reference.  Same arguments, same tree bit for bit, but
+ * the builder's workspace is a fixed array inside the library (about 23 MB per GPU, held until the process ends) instead
+ * of memory grown on demand: the call makes no hipMalloc / hipFree, and n is limited to RTHIP_NOALLOC_MAX_BOXES
+ * (RTHIP_E_LIMIT beyond).  All contexts on one GPU share that array: calls that overlap on one GPU (other streams,
+ * other contexts, other threads) race; calls on one stream, or ordered by events, do not. */
+#define RTHIP_NOALLOC_MAX_BOXES (1u << 17)
+int rthip_lbvh_build_device_noalloc(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, rthip_node* d_nodes, void* stream);
+
 /* rt_cpu_blas_node_from_mesh, raytracer_cpu.c:57-99, for one mesh whose vertex
  * positions (SoA: d_px, d_py, d_pz) and indices are already in HBM: triangle
  * boxes + lbvh_make.  d_indices == NULL means auto-index.  d_nodes must hold

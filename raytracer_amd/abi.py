@@ -78,6 +78,7 @@ SYMBOLS = [
     ("rthip_cast_accumulate_device", C.c_int, [_P, _P, C.c_uint64, _P, C.c_int, C.c_int, _P, _P]),
     ("rthip_lbvh_build", C.c_int, [_P, _P, C.c_uint64, _P, _P, _P, _P, _P]),
     ("rthip_lbvh_build_device", C.c_int, [_P, _P, C.c_uint64, _P, _P]),
+    ("rthip_lbvh_build_device_noalloc", C.c_int, [_P, _P, C.c_uint64, _P, _P]),
     ("rthip_mesh_build_device", C.c_int, [_P, _P, _P, _P, C.c_uint32, _P, C.c_uint64, _P, _P]),
     ("rthip_primary_hits", C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int]),
     ("rthip_trace_rays", C.c_int, [_P, _P, _P, C.c_uint64, _P, _P, _P, _P, _P]),

@@ -1036,8 +1036,8 @@ size_t scan_tmp_elems(uint64_t n) {
 
 }  // namespace
 
-int radix_sort_workspace_device(rthip_ctx* ctx, uint64_t n, int n_bytes, hipStream_t s, int* cur_io) {
-    LbvhWorkspace& w = ctx->ws;
+int radix_sort_workspace_device(rthip_ctx* ctx, uint64_t n, int n_bytes, hipStream_t s, int* cur_io, LbvhWorkspace* ws) {
+    LbvhWorkspace& w = ws ? *ws : ctx->ws;
     const uint32_t tiles = div_up(n, kSortTile);
     RT_TRY(rthip_reserve(ctx, w.block_hist, (256ull * tiles + 256) * 4));
     uint64_t* keys[2] = {(uint64_t*)w.keys[0].p, (uint64_t*)w.keys[1].p};
@@ -1121,11 +1121,13 @@ int instance_aabbs_device(rthip_ctx* ctx, const DevInstance* d_inst, uint32_t n,
 }
 
 int lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, float4* d_nodes, hipStream_t s,
-                      uint64_t* d_codes_unsorted, uint64_t* d_keys_sorted, uint32_t* d_ids_sorted, bool paired) {
+                      uint64_t* d_codes_unsorted, uint64_t* d_keys_sorted, uint32_t* d_ids_sorted, bool paired,
+                      LbvhWorkspace* ws) {
     if (n == 0) return rthip_fail(ctx, RTHIP_E_INVALID, "lbvh build needs at least one box");
     if (n > (1ull << 30)) return rthip_fail(ctx, RTHIP_E_LIMIT, "lbvh build is limited to 2^30 boxes (got %llu)",
                                             (unsigned long long)n);
-    LbvhWorkspace& w = ctx->ws;
+    LbvhWorkspace& w = ws ? *ws : ctx->ws;
+    if (ws) ctx->bounds_of = nullptr;  // bounds left by a triangle pass are in the context's own workspace
     const uint32_t tiles = div_up(n, kSortTile);
     const uint64_t hist_elems = 256ull * tiles;
     RT_TRY(rthip_reserve(ctx, w.keys[0], n * 8));
@@ -1174,7 +1176,7 @@ int lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, float4* 
         RT_HIP(ctx, hipMemcpyAsync(d_codes_unsorted, keys[0], n * 8, hipMemcpyDeviceToDevice, s));
 
     int cur = 0;
-    if (n > 1) RT_TRY(radix_sort_workspace_device(ctx, n, 8, s, &cur));
+    if (n > 1) RT_TRY(radix_sort_workspace_device(ctx, n, 8, s, &cur, &w));
     if (d_keys_sorted) RT_HIP(ctx, hipMemcpyAsync(d_keys_sorted, keys[cur], n * 8, hipMemcpyDeviceToDevice, s));
     if (d_ids_sorted) RT_HIP(ctx, hipMemcpyAsync(d_ids_sorted, vals[cur], n * 4, hipMemcpyDeviceToDevice, s));
 
@@ -1209,5 +1211,62 @@ int lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, float4* 
     emit_kernel<<<div_up(n, kBlock), kBlock, 0, s>>>(n32, (const LeafRec*)w.leaf_sorted.p, (const NodeInfo*)w.node_info.p,
                                                     (const uint8_t*)w.node_dl.p, (const uint32_t*)w.cnt_l.p, d_nodes, paired ? 1u : 0u);
     RT_HIP(ctx, hipGetLastError());
+    return RTHIP_OK;
+}
+
+// ---- a workspace that is not allocated ------------------------------------------------------------
+// Callers that cannot allocate (code under HIP graph capture, serving loops, harnesses that forbid hipMalloc) build in
+// this file-scope device array instead.  Every GPU the library runs on holds its own copy at its own address until the
+// process ends (about 23 MB); the array's name is only a host-side stand-in, so its device address is looked up once
+// per device with hipGetSymbolAddress and only that pointer is ever handed to kernels and memsets.
+namespace {
+
+constexpr size_t kStaticSlack = 1u << 20;  // block histograms, scan sums, bounds, alignment padding
+constexpr size_t kStaticBytes = kStaticBuildMaxBoxes * 168u + kStaticSlack;
+static __device__ __align__(256) unsigned char scratch[kStaticBytes];
+
+constexpr int kMaxDevices = 64;
+void* g_scratch_ptr[kMaxDevices];  // device address of `scratch` on device d, once looked up
+
+bool carve(DevBuf& b, unsigned char* base, size_t& off, size_t bytes) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (off + bytes > kStaticBytes) return false;
+    b.p = base + off;
+    b.cap = bytes;
+    b.fixed = true;
+    off += bytes;
+    return true;
+}
+
+}  // namespace
+
+int lbvh_static_workspace_init(rthip_ctx* ctx) {
+    if (ctx->ws_static_ready) return RTHIP_OK;
+    if (ctx->device < 0 || ctx->device >= kMaxDevices)
+        return rthip_fail(ctx, RTHIP_E_LIMIT, "device %d is beyond the %d devices the static workspace is kept for", ctx->device, kMaxDevices);
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    if (!g_scratch_ptr[ctx->device]) {
+        void* ptr = nullptr;
+        RT_HIP(ctx, hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+        if (!ptr) return rthip_fail(ctx, RTHIP_E_HIP, "hipGetSymbolAddress returned a null address for the static workspace");
+        g_scratch_ptr[ctx->device] = ptr;
+    }
+    unsigned char* base = (unsigned char*)g_scratch_ptr[ctx->device];
+    const uint64_t n = kStaticBuildMaxBoxes;
+    const uint32_t tiles = div_up(n, kSortTile);
+    const uint64_t hist_elems = 256ull * tiles;
+    const size_t hist_bytes = (hist_elems + 256) * 4, fused_bytes = (3ull * 256 * kFusedTiles + 256) * 4;
+    LbvhWorkspace& w = ctx->ws_static;
+    size_t off = 0;
+    bool ok = carve(w.keys[0], base, off, n * 8) && carve(w.keys[1], base, off, n * 8) && carve(w.vals[0], base, off, n * 4) &&
+              carve(w.vals[1], base, off, n * 4) &&
+              carve(w.block_hist, base, off, hist_bytes > fused_bytes ? hist_bytes : fused_bytes) &&
+              carve(w.scan_tmp, base, off, (scan_tmp_elems(hist_elems) + scan_tmp_elems(n)) * 4) &&
+              carve(w.prio, base, off, n) && carve(w.child, base, off, 2 * n * sizeof(ChildRec)) &&
+              carve(w.node_info, base, off, n * sizeof(NodeInfo)) && carve(w.node_dl, base, off, n) &&
+              carve(w.leaf_sorted, base, off, n * sizeof(LeafRec)) && carve(w.flags, base, off, n * 4) &&
+              carve(w.starters, base, off, n * 4) && carve(w.cnt_l, base, off, n * 4) && carve(w.bounds, base, off, 64);
+    if (!ok) return rthip_fail(ctx, RTHIP_E_LIMIT, "the static workspace of %zu bytes is too small for %llu boxes", kStaticBytes, (unsigned long long)n);
+    ctx->ws_static_ready = true;
     return RTHIP_OK;
 }

@@ -22,6 +22,8 @@ int rthip_fail(rthip_ctx* ctx, int code, const char* fmt, ...) {
 int rthip_reserve(rthip_ctx* ctx, DevBuf& b, size_t bytes) {
     if (bytes == 0) bytes = 256;
     if (b.cap >= bytes) return RTHIP_OK;
+    if (b.fixed)
+        return rthip_fail(ctx, RTHIP_E_LIMIT, "a fixed workspace slice of %zu bytes cannot hold %zu bytes", b.cap, bytes);
     if (b.p) {
         (void)hipFree(b.p);
         b.p = nullptr;
@@ -38,7 +40,7 @@ int rthip_reserve(rthip_ctx* ctx, DevBuf& b, size_t bytes) {
 }
 
 void rthip_release(DevBuf& b) {
-    if (b.p) (void)hipFree(b.p);
+    if (b.p && !b.fixed) (void)hipFree(b.p);
     b.p = nullptr;
     b.cap = 0;
 }
@@ -132,6 +134,10 @@ int rthip_create(rthip_ctx** out_ctx, int device_id) {
         rthip_destroy(ctx);
         return RTHIP_E_HIP;
     }
+    // the address of the static build workspace on this device (used by rthip_lbvh_build_device_noalloc); a failure
+    // here is reported by that entry point, which tries again
+    (void)lbvh_static_workspace_init(ctx);
+    ctx->err.clear();
     *out_ctx = ctx;
     return RTHIP_OK;
 }
@@ -577,6 +583,19 @@ int rthip_lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, rt
     if (!d_aabb6 || !d_nodes) return rthip_fail(ctx, RTHIP_E_INVALID, "NULL device pointer");
     RT_HIP(ctx, hipSetDevice(ctx->device));
     return lbvh_build_device(ctx, d_aabb6, n, (float4*)d_nodes, (hipStream_t)stream, nullptr, nullptr, nullptr);
+}
+
+int rthip_lbvh_build_device_noalloc(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, rthip_node* d_nodes, void* stream) {
+    if (!ctx) return RTHIP_E_INVALID;
+    if (!d_aabb6 || !d_nodes) return rthip_fail(ctx, RTHIP_E_INVALID, "NULL device pointer");
+    if (n == 0) return rthip_fail(ctx, RTHIP_E_INVALID, "lbvh build needs at least one box");
+    if (n > kStaticBuildMaxBoxes)
+        return rthip_fail(ctx, RTHIP_E_LIMIT, "rthip_lbvh_build_device_noalloc builds at most %llu boxes (got %llu): its workspace is a fixed array",
+                          (unsigned long long)kStaticBuildMaxBoxes, (unsigned long long)n);
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_TRY(lbvh_static_workspace_init(ctx));
+    return lbvh_build_device(ctx, d_aabb6, n, (float4*)d_nodes, (hipStream_t)stream, nullptr, nullptr, nullptr, false,
+                             &ctx->ws_static);
 }
 
 int rthip_mesh_build_device(rthip_ctx* ctx, const float* d_px, const float* d_py, const float* d_pz,

@@ -16,6 +16,7 @@
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
+    bool fixed = false;  // a slice of memory the library does not own: never freed, never grown (rthip_reserve fails instead)
 };
 
 // ---------------------------------------------------------------------------
@@ -126,6 +127,8 @@ struct rthip_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
     LbvhWorkspace ws;
+    LbvhWorkspace ws_static;  // the same arrays carved out of the device's static scratch array (lbvh_static_workspace_init)
+    bool ws_static_ready = false;
 
     std::vector<HostMesh> meshes;
     bool blas_committed = false;
@@ -207,12 +210,20 @@ void rthip_release(DevBuf& b);
 // copies of the intermediate arrays (parity taps).  `paired`: records in the walk's own form
 // (min.x, max.x, min.y, max.y | min.z, max.z, skip, id) instead of the documented rthip_node; the
 // context's BLAS and TLAS are kept that way, what leaves through the ABI is rthip_node.
+// `ws`: the workspace to use (nullptr: the context's own, grown on demand).
 int lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, float4* d_nodes, hipStream_t stream,
-                      uint64_t* d_codes_unsorted, uint64_t* d_keys_sorted, uint32_t* d_ids_sorted, bool paired = false);
+                      uint64_t* d_codes_unsorted, uint64_t* d_keys_sorted, uint32_t* d_ids_sorted, bool paired = false,
+                      LbvhWorkspace* ws = nullptr);
+
+// Builds of at most kStaticBuildMaxBoxes boxes can run in a workspace that is a file-scope device array instead of
+// allocated memory.  lbvh_static_workspace_init looks the array's address up on the context's device (once per device)
+// and carves ctx->ws_static out of it; no allocation.
+constexpr uint64_t kStaticBuildMaxBoxes = 1ull << 17;
+int lbvh_static_workspace_init(rthip_ctx* ctx);
 
 // Stable LSD radix sort of the n (uint64 key, uint32 value) pairs in ws.keys[*cur] / ws.vals[*cur] (the caller has
 // reserved both ping-pong pairs) by the key's low n_bytes bytes; *cur names the pair that holds the result.
-int radix_sort_workspace_device(rthip_ctx* ctx, uint64_t n, int n_bytes, hipStream_t stream, int* cur);
+int radix_sort_workspace_device(rthip_ctx* ctx, uint64_t n, int n_bytes, hipStream_t stream, int* cur, LbvhWorkspace* ws = nullptr);
 // In-place inclusive prefix sum of n uint32.
 int scan_inclusive_u32_device(rthip_ctx* ctx, uint32_t* d, uint64_t n, hipStream_t stream);
 
