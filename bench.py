@@ -294,12 +294,12 @@ def cpu_sample_frame(wl, max_paths=1 << 21):
     return Ws, Hs, wl["cam"](Ws, Hs, smp), what
 
 
-def cpu_baseline(wl, cast, flat, budget_s=20.0):
+def cpu_baseline(wl, cast, flat, budget_s=20.0, max_paths=1 << 21):
     """The CPU path on this box's host cores: the unmodified reference when oracle/_ref travelled
     with the tree (kind 'reference'), otherwise the repo's CPU restatement (kind 'port')."""
     from oracle import oracle as O
 
-    W, H, cast, what = cpu_sample_frame(wl)
+    W, H, cast, what = cpu_sample_frame(wl, max_paths)
     ora = O.Scene(flat, wl["bounces"], wl["sky"])
     # the oracle in glibc-rand mode reproduces the reference's paths exactly, so its ray count is the reference's
     t0 = time.time()
@@ -309,7 +309,8 @@ def cpu_baseline(wl, cast, flat, budget_s=20.0):
     if O.have_ref("core"):
         rs = O.RefScene(flat, wl["bounces"], wl["sky"])
         reps, spent, best = 0, 0.0, None
-        while reps < 3 or (spent < budget_s and reps < 10):
+        min_reps = 3 if budget_s >= 20.0 else 1
+        while reps < min_reps or (spent < budget_s and reps < 10):
             _, sec = rs.cast(cast, 1, W, H)
             spent += sec
             best = sec if best is None else min(best, sec)
@@ -354,7 +355,7 @@ def cpu_port_parallel(wl, cast, flat, threads):
                 sample=f"{what}, one pass, rows dealt to {threads} threads")
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -378,32 +379,118 @@ def main():
                          "1 = strictly one launch after the other.  Only with --combine end (progressive accumulation) and "
                          "for ray streams; --combine every delivers frames in order on one stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-workloads", action="store_true",
+                    help="default workload at N = 1 only: skip the `workloads` object (the other BASELINE configurations, the "
+                         "one-stream figure and the host-buffer rthip_cast figure, each a short run of its own)")
+    ap.add_argument("--width", type=int, default=0, help="frame width instead of the workload's own (rehearsals and tests)")
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--launch-check", action="store_true",
+                    help="N ranks only join the process group, add up their ranks and rank 0 prints one JSON line: a test of "
+                         "the launch path that needs no GPU with --backend gloo")
     ap.add_argument("--build-sizes", default="81920,1000000,10000000")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
+
+def self_launch(args, argv):
+    """`bench.py --gpus N` started without a launcher: this process starts the N ranks itself (one process per GPU,
+    torch.distributed.run on 127.0.0.1) before it has touched the GPU, lets rank 0's JSON line through and returns the
+    launcher's exit code."""
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.run(cmd, env=env, cwd=ROOT).returncode
+
+
+def launch_check(args, rank, world):
     import torch
     import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N")
-    device_index = local_rank % max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(device_index)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
+            device_index = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
+            torch.cuda.set_device(device_index)
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
+            t = torch.tensor([float(rank)], device="cuda")
         else:
             dist.init_process_group(backend="gloo")
+            t = torch.tensor([float(rank)])
+        dist.all_reduce(t)
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        t = torch.tensor([0.0])
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "backend": args.backend, "rank_sum": float(t.item())}), flush=True)
 
-    from raytracer_amd import abi, dist as rdist, tracer as T, world as Wd
 
-    wl = make_workload(args.workload)
+def ceilings(algo_bytes, traffic, valu_insts, kernel_ms, ms_per_step, n_streams):
+    """What bounds a launch.  `cost_ms` is the time one launch costs on the chip: its own duration when launches run one
+    after the other, the timed region / steps when several overlap.  HBM is the bounding ceiling only when the measured
+    traffic is of the order of the algorithmic bytes (the scene does not fit the caches); cache-resident scenes are priced
+    against vector-ALU issue instead, and an HBM fraction is not printed for more bytes than HBM moved."""
+    cost_ms = ms_per_step if n_streams > 1 else kernel_ms
+    out = {"cost_ms_per_launch": round(cost_ms, 4), "hbm_algorithmic_frac": round(algo_bytes / (cost_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    measured = None
+    if traffic:
+        measured = traffic / (cost_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        out["hbm_measured_frac"] = round(measured, 4)
+        out["traffic_over_algorithmic"] = round(traffic / max(algo_bytes, 1), 3)
+    issue = None
+    if valu_insts:
+        issue = valu_insts * 4.0 / (SIMDS * ENGINE_CLOCK_GHZ * 1e9) * 1e3 / cost_ms
+        out["valu_issue_frac"] = round(issue, 4)
+    if measured is not None and traffic >= 0.7 * algo_bytes:
+        out["bounding"] = "hbm"
+        out["frac_of_bounding"] = round(measured, 4)
+    elif issue is not None:
+        out["bounding"] = "valu-issue"
+        out["frac_of_bounding"] = round(issue, 4)
+    elif measured is not None:
+        out["bounding"] = "caches (L2 / Infinity Cache) and valu issue: HBM moved a fraction of the algorithmic bytes; no SQ_INSTS_VALU pass recorded"
+        out["frac_of_bounding"] = None
+    else:
+        out["bounding"] = "unknown: no counter pass recorded for this workload (profiles/traffic.json)"
+        out["frac_of_bounding"] = None
+    return out
+
+
+_WORKLOAD_CACHE = {}
+
+
+def cached_workload(name):
+    if name not in _WORKLOAD_CACHE:
+        key = {"soup-rays": "soup", "instanced-rays": "instanced"}.get(name)
+        wl = make_workload(name)
+        if key and key in _WORKLOAD_CACHE:  # the same scene: keep one copy of the world
+            wl["world"] = _WORKLOAD_CACHE[key]["world"]
+        _WORKLOAD_CACHE[name] = wl
+    return dict(_WORKLOAD_CACHE[name])
+
+
+def measure(args, name, steps, warmup, n_streams_arg, rank, world, device_index, want_cpu, cpu_budget_s=20.0, cpu_max_paths=1 << 21,
+            extras=True):
+    """One workload: scene build, counted launches, warm-up, the timed steps, and the figures derived from them."""
+    import torch
+    import torch.distributed as dist
+
+    from raytracer_amd import abi, dist as rdist, scenes, tracer as T, world as Wd
+
+    wl = cached_workload(name)
     if args.samples > 0:
         wl["samples"] = args.samples
+    if args.width > 0 and args.height > 0:
+        wl["width"], wl["height"] = args.width, args.height
+        wl["label"] += f" [frame overridden: {args.width}x{args.height}]"
     wl["label"] += f", samples={wl['samples']}" if "samples=" not in wl["label"] else ""
     W, H = wl["width"], wl["height"]
     tr = T.rt_make_tracer(T.RT_TracerSettings(max_bounces=wl["bounces"], sky=wl["sky"]), device_id=device_index)
@@ -425,7 +512,7 @@ def main():
     if combine == "end" and args.shard != "frames":
         raise SystemExit("--combine end accumulates independent sample sets: it needs --shard frames")
     is_rays = "rays" in wl
-    n_streams = max(1, args.streams) if (combine == "end" or is_rays) else 1
+    n_streams = max(1, n_streams_arg) if (combine == "end" or is_rays) else 1
     main_stream = torch.cuda.current_stream()
     if n_streams > 1:
         # HIP binds a stream to one of its hardware queues (4 on this box, GPU_MAX_HW_QUEUES) when the stream is first
@@ -450,7 +537,6 @@ def main():
 
     ray_o = ray_d = ray_hits = None
     if is_rays:  # a ray-stream workload: closest-hit queries for explicit rays instead of a frame
-        from raytracer_amd import scenes
         lo, hi = wl.get("ray_box", ((0.0, 0.0, 0.0), (1.0, 1.0, 1.0)))
         ray_o, ray_d = scenes.incoherent_rays_device(torch, wl["rays"], 2 + rank, lo, hi)
         ray_hits = [torch.zeros((wl["rays"], 4), dtype=torch.int32, device="cuda") for _ in streams]
@@ -509,34 +595,42 @@ def main():
         if rank == 0:
             accum.mul_(1.0 / float(n_steps * world))
 
-    # traversal counters of this rank's frame (untimed launch with counting on)
+    # Traversal counters of this rank's frames: untimed launches with counting on, one per seed of the first timed steps
+    # (at most 4; the steps of a progressive image differ only in their sample sets, so their ray counts differ by a
+    # fraction of a per cent -- the mean over the counted seeds stands for every step; a 1-bounce-deep frame and a ray
+    # stream have the same count for every seed).
+    counted = 1 if (is_rays or combine == "every") else max(1, min(4, steps))
     T.set_counting(tr, True)
     T.get_stats(tr)
-    step()
+    for _ in range(counted):
+        step()
     pipe.drain()
     torch.cuda.synchronize()
     st = T.get_stats(tr)
     T.set_counting(tr, False)
+    step_no[0] = 0
+    st = {k: (v / counted if k in ("rays", "nodes_tested", "tris_tested", "inst_entered", "wave_steps") else v) for k, v in st.items()}
     rays = st["rays"]
     algo_bytes = 48 * st["rays"] + 32 * st["nodes_tested"] + 48 * st["tris_tested"] + 64 * st["inst_entered"]
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     pipe.drain()
-    finish_image(args.warmup + 1)
+    finish_image(warmup + 1)
     if accums is not None:
         for a in accums:
             a.zero_()
+    step_no[0] = 0
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     t0 = time.perf_counter()
-    for k in range(args.steps):
+    for k in range(steps):
         step(ev[k])
-    host_enqueue_ms = (time.perf_counter() - t0) * 1e3 / args.steps
+    host_enqueue_ms = (time.perf_counter() - t0) * 1e3 / steps
     pipe.drain()
-    finish_image(args.steps)
+    finish_image(steps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -547,6 +641,8 @@ def main():
     t_all = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     r_all = torch.tensor([float(rays)], dtype=torch.float64, device="cuda")
     if world > 1:
+        if dist.get_backend() == "gloo":
+            t_all, r_all = t_all.cpu(), r_all.cpu()
         dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
         dist.all_reduce(r_all, op=dist.ReduceOp.SUM)
     elapsed = float(t_all.item())
@@ -557,30 +653,35 @@ def main():
                    2: "wf_trace_kernel + wf_shade_kernel (wavefront)"}[last["last_cast_kernel"]]
     if ray_o is not None:
         kernel_name = "trace_rays_kernel"
-    traffic = recorded_traffic(args.workload, kernel_name)
+    traffic = recorded_traffic(name, kernel_name)
     if ray_o is not None and traffic is None:  # deep scenes: the library takes the ray stream's persistent kernel
-        traffic = recorded_traffic(args.workload, "trace_rays_persistent_kernel")
+        traffic = recorded_traffic(name, "trace_rays_persistent_kernel")
         if traffic is not None:
             kernel_name = "trace_rays_persistent_kernel"
-    valu_insts = recorded_valu_insts(args.workload, kernel_name)
+    valu_insts = recorded_valu_insts(name, kernel_name)
+    line = None
     if rank == 0:
-        value = total_rays * args.steps / elapsed / 1e6
+        value = total_rays * steps / elapsed / 1e6
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+        ms_per_step = elapsed / steps * 1e3
+        overlapped = algo_bytes * steps / elapsed / 1e9
+        bound = ceilings(algo_bytes, traffic, valu_insts, kernel_ms, ms_per_step, n_streams)
         line = {
             "metric": "Mrays/sec (whole node); LBVH build ms per 1M triangles",
             "value": round(value, 2),
             "unit": "Mrays/s",
             "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "steps": steps,
+            "warmup": warmup,
+            "ms_per_step": round(ms_per_step, 4),
             "host_enqueue_ms_per_step": round(host_enqueue_ms, 4),
             "higher_is_better": True,
             "scaling": "weak" if args.shard == "frames" else "strong",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": wl["label"], "rays_per_frame_per_gpu": int(rays), "streams": n_streams,
+            "config": {"workload": wl["label"], "rays_per_frame_per_gpu": int(round(rays)), "streams": n_streams,
+                       "rays_counted_over_seeds": counted,
                        "sharding": "none" if world == 1 else {
                            "frames": "every rank renders the frame with its own sample set; " + (
                                "framebuffers summed onto rank 0 with RCCL every step" if combine == "every" else
@@ -588,6 +689,9 @@ def main():
                                "of the timed steps (inside the timed region)"),
                            "tiles": "ranks render interleaved 64x64 tiles of one frame; shares summed onto rank 0 with RCCL",
                            "samples": "ranks render sample indices s % N == rank of one frame; sums added onto rank 0 with RCCL"}[args.shard]},
+            # `achieved` / `frac`: ALGORITHMIC bytes of one launch over the mean duration of one launch (HIP events on its
+            # stream; with --streams > 1 other launches run beside it, as rocprofv3 reports it).  Whether HBM is the ceiling
+            # that binds is said by `bounding` (see ceilings()): `traffic` far below the algorithmic bytes = cache-resident.
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "kernel": kernel_name,
                          "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": int(algo_bytes),
@@ -595,40 +699,125 @@ def main():
                                      "triangles": round(st["tris_tested"] / max(rays, 1), 3),
                                      "instances": round(st["inst_entered"] / max(rays, 1), 3)},
                          "lane_utilisation": round(st["nodes_tested"] / max(64 * st["wave_steps"], 1), 4),
-                         # with --streams > 1 launches overlap: kernel_ms is the mean duration of ONE launch while others
-                         # run beside it (what rocprofv3 reports per launch); the overlapped figures divide the bytes of all
-                         # launches by the timed region instead
                          "concurrent_launches": n_streams,
-                         "achieved_overlapped": round(algo_bytes * args.steps / elapsed / 1e9, 2),
-                         "frac_overlapped": round(algo_bytes * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 5),
-                         # the cache-resident frames are bound by vector-ALU issue, not by bytes: instructions per launch
-                         # (SQ_INSTS_VALU, recorded like `traffic`) x 4 cycles each, over the cycles all SIMDs had in the
-                         # time one launch took on the chip (alone: kernel_ms; overlapped: the timed region / steps)
-                         "valu": valu_issue(valu_insts, kernel_ms, elapsed * 1e3 / args.steps, n_streams)},
+                         "algorithmic_rate_overlapped_gbs": round(overlapped, 2),
+                         # a fraction of the HBM peak only where that is a statement about HBM: never above 1
+                         "frac_overlapped": round(overlapped / HBM_PEAK_GBS, 5) if overlapped <= HBM_PEAK_GBS else None,
+                         "ceilings": bound, "bounding": bound["bounding"], "frac_of_bounding": bound["frac_of_bounding"],
+                         "valu": valu_issue(valu_insts, kernel_ms, ms_per_step, n_streams)},
             "scene_build_ms": {"blas": round(blas_ms, 4), "tlas": round(tlas_ms, 4), "tlas_rebuild_call": round(tlas_call_ms, 4),
                                "instances": int(flat.instances.size)},
         }
-        if args.build_sizes:
-            line["lbvh_build"] = build_times(tr, torch, [int(s) for s in args.build_sizes.split(",") if s])
-            big = max(line["lbvh_build"], key=lambda k: int(k))
-            line["lbvh_build_ms_per_1M_triangles"] = line["lbvh_build"][big]["ms_per_1M"]
-        if args.workload == "bunny":
-            line["shadow_rays"] = shadow_ray_rate(tr, torch, cast, W, H, args.steps)
-            line["obj_load"] = obj_load_figure(tr, not args.no_cpu_baseline and world == 1)
-        want_cpu = not args.no_cpu_baseline and world == 1  # the CPU baseline is reported at N = 1 only
-        if ray_o is None:
-            line["hdr_output"] = hdr_output(tr, torch, cast, W, H, args.steps, want_cpu)
+        if extras:
+            if args.build_sizes:
+                line["lbvh_build"] = build_times(tr, torch, [int(s) for s in args.build_sizes.split(",") if s])
+                big = max(line["lbvh_build"], key=lambda k: int(k))
+                line["lbvh_build_ms_per_1M_triangles"] = line["lbvh_build"][big]["ms_per_1M"]
+            if name == "bunny":
+                line["shadow_rays"] = shadow_ray_rate(tr, torch, cast, W, H, steps)
+                line["obj_load"] = obj_load_figure(tr, want_cpu)
+            if ray_o is None:
+                line["hdr_output"] = hdr_output(tr, torch, cast, W, H, steps, want_cpu)
+                line["host_cast"] = host_cast_figure(tr, cast, W, H, rays)
         if want_cpu and ray_o is not None:
-            line["cpu_baseline"] = cpu_baseline_rays(wl, flat, ray_o[: 1 << 16].cpu().numpy(), ray_d[: 1 << 16].cpu().numpy())
+            line["cpu_baseline"] = cpu_baseline_rays(wl, flat, ray_o[: 1 << 16].cpu().numpy(), ray_d[: 1 << 16].cpu().numpy(),
+                                                     sample=(1 << 16) if cpu_budget_s >= 20 else (1 << 14))
         if want_cpu and ray_o is None:
-            line["cpu_baseline"] = cpu_baseline(wl, cast, flat)
-            threads = min(16, os.cpu_count() or 1)  # the box's CPU share for one GPU
-            line["cpu_port_all_cores"] = cpu_port_parallel(wl, cast, flat, threads)
+            line["cpu_baseline"] = cpu_baseline(wl, cast, flat, budget_s=cpu_budget_s, max_paths=cpu_max_paths)
+            if extras:
+                threads = min(16, os.cpu_count() or 1)  # the box's CPU share for one GPU
+                line["cpu_port_all_cores"] = cpu_port_parallel(wl, cast, flat, threads)
+    T.rt_tracer_cleanup(tr)
+    del accums, accum, pipe, ray_o, ray_d, ray_hits
+    torch.cuda.empty_cache()
+    return line
+
+
+def host_cast_figure(tr, cast, W, H, rays, reps=8):
+    """rt_tracer_cast as the reference's callers use it: rthip_cast renders and copies the frame into the caller's
+    ordinary (pageable) host buffer, one frame after the other.  The PCIe-inclusive figure; never the headline."""
+    from raytracer_amd import tracer as T
+
+    img = np.zeros((H, W, 3), dtype=np.float32)
+    times = []
+    for k in range(reps + 2):
+        t0 = time.perf_counter()
+        T.rt_tracer_cast(tr, cast, img, W, H, seed=1 + k)
+        times.append((time.perf_counter() - t0) * 1e3)
+    ms = float(np.median(times[2:]))
+    return {"what": "rthip_cast into the caller's pageable host buffer (render + device-to-host copy of the frame), one call "
+                    "after the other: the rate a drop-in rt_tracer_cast delivers", "ms_per_call": round(ms, 4),
+            "value": round(rays / ms / 1e3, 2), "unit": "Mrays/s", "frame_bytes": int(W) * int(H) * 12}
+
+
+# The other BASELINE configurations and views of the default one, each a short run of its own inside the default
+# `python bench.py` so that the driver's record holds them: (key, workload, streams, steps, warm-up)
+EXTRA_RUNS = [
+    ("bunny_one_stream", "bunny", 1, 40, 5),
+    ("instanced", "instanced", 4, 12, 2),
+    ("instanced_one_stream", "instanced", 1, 6, 1),
+    ("soup", "soup", 4, 12, 2),
+    ("soup_rays", "soup-rays", 1, 3, 1),
+    ("instanced_rays", "instanced-rays", 4, 8, 2),
+    ("cornell", "cornell", 4, 40, 5),
+    ("cornell_mesh_4k", "cornell-mesh", 1, 4, 1),
+]
+
+
+def compact(line):
+    r = line["roofline"]
+    out = {"workload": line["config"]["workload"], "value": line["value"], "unit": line["unit"], "ms_per_step": line["ms_per_step"],
+           "steps": line["steps"], "streams": line["config"]["streams"], "rays_per_frame": line["config"]["rays_per_frame_per_gpu"],
+           "kernel": r["kernel"], "kernel_ms": r["kernel_ms"], "per_ray": r["per_ray"], "lane_utilisation": r["lane_utilisation"],
+           "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_launch"], "traffic": r["traffic"], "ceilings": r["ceilings"],
+           "bounding": r["bounding"], "frac_of_bounding": r["frac_of_bounding"], "scene_build_ms": line["scene_build_ms"]}
+    if "cpu_baseline" in line:
+        out["cpu_baseline"] = line["cpu_baseline"]
+    return out
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args, argv))  # nothing in this process has touched the GPU yet
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks")
+    if args.launch_check:
+        launch_check(args, rank, world)
+        return
+
+    import torch
+    import torch.distributed as dist
+
+    device_index = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(device_index)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend="gloo")
+
+    want_cpu = not args.no_cpu_baseline and world == 1  # the CPU baseline is reported at N = 1 only
+    line = measure(args, args.workload, args.steps, args.warmup, args.streams, rank, world, device_index, want_cpu)
+    default_run = args.workload == "bunny" and world == 1 and not args.no_workloads and args.samples == 0 and args.width == 0
+    if rank == 0 and default_run:
+        others = {}
+        for key, name, n_streams, steps, warmup in EXTRA_RUNS:
+            sub = measure(args, name, steps, warmup, n_streams, rank, world, device_index, want_cpu, cpu_budget_s=4.0,
+                          cpu_max_paths=1 << 17, extras=False)
+            others[key] = compact(sub)
+        line["workloads"] = others
+    if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    T.rt_tracer_cleanup(tr)
 
 
 if __name__ == "__main__":

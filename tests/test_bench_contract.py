@@ -38,8 +38,12 @@ def check_common(d, steps, warmup):
 
 
 def test_default_workload_line():
-    d = run_bench("--steps", "24", "--warmup", "4", "--build-sizes", "81920", "--no-cpu-baseline")
+    d = run_bench("--steps", "24", "--warmup", "4", "--build-sizes", "81920", "--no-cpu-baseline", "--no-workloads")
     check_common(d, 24, 4)
+    assert "workloads" not in d and d["host_cast"]["value"] > 0
+    r = d["roofline"]
+    assert r["frac_overlapped"] is None or r["frac_overlapped"] <= 1.0
+    assert r["bounding"] and "hbm_algorithmic_frac" in r["ceilings"]
     assert "1920x1080" in d["config"]["workload"] and "samples=1" in d["config"]["workload"]
     assert d["config"]["streams"] == 4
     assert "81920" in d["lbvh_build"] and d["lbvh_build_ms_per_1M_triangles"] > 0
@@ -56,3 +60,26 @@ def test_cpu_baseline_and_single_stream():
     assert c["kind"] in ("reference", "port") and c["cores"] == 1 and c["value"] > 0
     assert d["hdr_output"]["identical_to_cpu"] is True
     assert d["roofline"]["concurrent_launches"] == 1
+
+
+def test_default_run_carries_every_configuration():
+    """The driver's plain `python bench.py`: the line also holds the other BASELINE configurations, each with its
+    counters per ray and the ceiling that bounds it."""
+    d = run_bench("--steps", "8", "--warmup", "2", "--build-sizes", "", "--no-cpu-baseline")
+    check_common(d, 8, 2)
+    w = d["workloads"]
+    for key in ("bunny_one_stream", "instanced", "instanced_one_stream", "soup", "soup_rays", "instanced_rays", "cornell", "cornell_mesh_4k"):
+        assert key in w, key
+        for k in ("workload", "value", "ms_per_step", "kernel", "kernel_ms", "per_ray", "traffic", "bounding", "ceilings"):
+            assert k in w[key], (key, k)
+        assert w[key]["value"] > 0
+    assert w["bunny_one_stream"]["streams"] == 1 and w["soup_rays"]["rays_per_frame"] == 1 << 24
+    assert w["soup_rays"]["per_ray"]["nodes"] > 100
+
+
+def test_two_ranks_start_themselves():
+    """`python bench.py --gpus 2` without a launcher starts its own ranks (here both on the one GPU, gloo) and prints
+    rank 0's line."""
+    d = run_bench("--gpus", "2", "--backend", "gloo", "--steps", "3", "--warmup", "1", "--width", "256", "--height", "144",
+                  "--no-cpu-baseline", "--build-sizes", "")
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and d["scaling"] == "weak"

@@ -102,3 +102,26 @@ def test_frame_pipeline_keeps_frames_apart(tmp_path):
     got = np.load(os.path.join(str(tmp_path), "pipe.npy"))
     # mean over the two ranks of 10 * frame + rank = 10 * frame + 0.5, for frames 0, 1, 2 and the last one (4)
     assert np.allclose(got, [0.5, 10.5, 20.5, 40.5])
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset must launch the two ranks itself and pass rank 0's JSON line and
+    the exit code on (checked here without a GPU: the ranks only join the gloo group and add up their ranks)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--launch-check"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rank_sum"] == 1.0
+    # a launcher that started another number of ranks than --gpus says is an error, not a silent run
+    env2 = dict(env, WORLD_SIZE="1", RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"], capture_output=True,
+                       text=True, timeout=120, env=env2, cwd=root)
+    assert r.returncode != 0
