@@ -745,9 +745,21 @@ def host_cast_figure(tr, cast, W, H, rays, reps=8):
         T.rt_tracer_cast(tr, cast, img, W, H, seed=1 + k)
         times.append((time.perf_counter() - t0) * 1e3)
     ms = float(np.median(times[2:]))
+    pimg = T.host_alloc(tr, (H, W, 3))  # the same into page-locked memory from rthip_host_alloc: DMA at the link's rate
+    pinned = []
+    for k in range(reps + 2):
+        t0 = time.perf_counter()
+        T.rt_tracer_cast(tr, cast, pimg, W, H, seed=1 + k)
+        pinned.append((time.perf_counter() - t0) * 1e3)
+    same = bool(pimg.tobytes() == img.tobytes())
+    T.host_free(tr, pimg)
+    del pimg
+    pms = float(np.median(pinned[2:]))
     return {"what": "rthip_cast into the caller's pageable host buffer (render + device-to-host copy of the frame), one call "
                     "after the other: the rate a drop-in rt_tracer_cast delivers", "ms_per_call": round(ms, 4),
-            "value": round(rays / ms / 1e3, 2), "unit": "Mrays/s", "frame_bytes": int(W) * int(H) * 12}
+            "value": round(rays / ms / 1e3, 2), "unit": "Mrays/s", "frame_bytes": int(W) * int(H) * 12,
+            "pinned": {"what": "the same into a page-locked buffer from rthip_host_alloc", "ms_per_call": round(pms, 4),
+                       "value": round(rays / pms / 1e3, 2), "unit": "Mrays/s", "same_bits": same}}
 
 
 # The other BASELINE configurations and views of the default one, each a short run of its own inside the default

@@ -29,11 +29,16 @@
  *     streams of one context must not overlap.  Casts and ray queries may: frames
  *     enqueued on different streams run concurrently (one frame's first waves fill
  *     the GPU while another's last waves drain; measured 1.1x to 2.8x the frames
- *     per second of one stream), each into its own framebuffer, at most 64 of them
- *     unfinished at a time, and not with RTHIP_KERNEL_WAVEFRONT or with counting
- *     on, whose buffers belong to the context.  A cast on a stream that is being
- *     captured becomes graph nodes (kernels only; RTHIP_KERNEL_AUTO skips its probe
- *     then); the graph may be replayed as long as the scene is not rebuilt.
+ *     per second of one stream), each into its own framebuffer, and not with
+ *     RTHIP_KERNEL_WAVEFRONT or with counting on, whose buffers belong to the
+ *     context.  At most 64 launches of the persistent kernels (RTHIP_KERNEL_PERSISTENT,
+ *     long ray streams) may be unfinished at a time: the 65th returns RTHIP_E_LIMIT
+ *     (each owns a slot of work counters, reused only after an event recorded behind
+ *     its launch has completed).  A cast on a stream that is being captured becomes
+ *     graph nodes (kernels only; RTHIP_KERNEL_AUTO skips its probe then); the graph
+ *     may be replayed as long as the scene is not rebuilt, beside eager casts (captured
+ *     launches of the persistent kernels get work-counter slots of their own, at most
+ *     192 per scene build), but two replays of one graph must not overlap each other.
  */
 #ifndef RTHIP_H
 #define RTHIP_H
@@ -203,6 +208,15 @@ int rthip_tlas_build(rthip_ctx* ctx, const rthip_instance* instances, uint32_t n
  * sample, draw index), so the image does not depend on scheduling or GPU count. */
 int rthip_cast(rthip_ctx* ctx, const rthip_cast_settings* cast, uint64_t seed, float* out_rgb, int width, int height);
 
+/* Optional: page-locked host memory for the framebuffer (hipHostMalloc).  rthip_cast copies the frame into ordinary
+ * (pageable) memory through the runtime's staging copies; into a buffer from rthip_host_alloc it goes by DMA at the
+ * link's rate (1920x1080 floats: 1.4 ms -> 0.45 ms for the copy).  Free with rthip_host_free, or implicitly by
+ * rthip_destroy.  No counterpart in the reference (its framebuffer is arena memory and never leaves the CPU,
+ * src/demos/cornell/main.c:214, raytracer_cpu.c:190-192); page-locking the caller's own allocation (hipHostRegister)
+ * is not offered because not every host allows it. */
+int rthip_host_alloc(rthip_ctx* ctx, uint64_t bytes, void** out_ptr);
+int rthip_host_free(rthip_ctx* ctx, void* ptr);
+
 /* Same work with the framebuffer in HBM and no host synchronisation: the call
  * only enqueues on `stream`.  With shard->mode != 0 the buffer holds this
  * context's share as described at rthip_shard.  shard == NULL means mode 0. */
@@ -230,8 +244,15 @@ int rthip_lbvh_build(rthip_ctx* ctx, const float* aabb6, uint64_t n, uint64_t* o
 
 /* The same build with the boxes already in HBM and the tree left in HBM: what the
  * build benchmark times.  d_nodes must hold 2n-1 records.  Enqueues on `stream`
- * and returns without synchronising. */
+ * and returns without synchronising, except that a build larger than any before it first grows the
+ * context's workspace (see rthip_lbvh_reserve). */
 int rthip_lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, rthip_node* d_nodes, void* stream);
+
+/* Grows the builder's workspace to what builds of up to n boxes (or triangles) need.  rthip_lbvh_build_device and
+ * rthip_mesh_build_device grow it themselves when a build is larger than any before it -- a hipFree / hipMalloc inside
+ * the call, which waits for the device and is not allowed while a stream is being captured; after rthip_lbvh_reserve(n)
+ * builds of at most n boxes only enqueue.  No counterpart in the reference (its arenas grow on demand, lbvh.c:48). */
+int rthip_lbvh_reserve(rthip_ctx* ctx, uint64_t n);
 
 /* rthip_lbvh_build_device for callers that cannot allocate device memory: code under HIP graph capture, tight serving
  * loops, harnesses that forbid hipMalloc.  No counterpart in the reference.  Same arguments, same tree bit for bit, but
@@ -297,7 +318,7 @@ int rthip_set_counting(rthip_ctx* ctx, int enabled);
  *                            skipped under stream capture).  Smaller frames: static for small scenes,
  *                            persistent for deep ones
  *   RTHIP_KERNEL_PERSISTENT  resident waves, lanes take a new path as soon as theirs ends
- *   RTHIP_KERNEL_STATIC      one pixel per thread
+ *   RTHIP_KERNEL_STATIC      one pixel per thread (a kernel selected by name never probes: the call only enqueues)
  *   RTHIP_KERNEL_STATIC_SAMPLES  one SAMPLE per thread, the samples of a pixel in neighbouring lanes and summed
  *                            in sample order (samples = 2, 4 or 8; any other count runs RTHIP_KERNEL_STATIC).
  *                            AUTO uses it wherever it would run STATIC, and without a probe for frames of

@@ -74,10 +74,13 @@ SYMBOLS = [
     ("rthip_blas_commit", C.c_int, [_P]),
     ("rthip_tlas_build", C.c_int, [_P, _P, C.c_uint32, _P, C.c_uint32]),
     ("rthip_cast", C.c_int, [_P, _P, C.c_uint64, _P, C.c_int, C.c_int]),
+    ("rthip_host_alloc", C.c_int, [_P, C.c_uint64, C.POINTER(_P)]),
+    ("rthip_host_free", C.c_int, [_P, _P]),
     ("rthip_cast_device", C.c_int, [_P, _P, C.c_uint64, _P, C.c_int, C.c_int, _P, _P]),
     ("rthip_cast_accumulate_device", C.c_int, [_P, _P, C.c_uint64, _P, C.c_int, C.c_int, _P, _P]),
     ("rthip_lbvh_build", C.c_int, [_P, _P, C.c_uint64, _P, _P, _P, _P, _P]),
     ("rthip_lbvh_build_device", C.c_int, [_P, _P, C.c_uint64, _P, _P]),
+    ("rthip_lbvh_reserve", C.c_int, [_P, C.c_uint64]),
     ("rthip_lbvh_build_device_noalloc", C.c_int, [_P, _P, C.c_uint64, _P, _P]),
     ("rthip_mesh_build_device", C.c_int, [_P, _P, _P, _P, C.c_uint32, _P, C.c_uint64, _P, _P]),
     ("rthip_primary_hits", C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int]),

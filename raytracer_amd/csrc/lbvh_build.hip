@@ -535,12 +535,15 @@ __global__ __launch_bounds__(kBlock) void gap_priority_kernel(const uint64_t* __
 // is not local stores its record in HBM, counts itself at the parent (+1) and is done.
 // hierarchy_upper_kernel finishes the nodes that span chunks (a few per cent of all): one
 // thread per gap; the gaps whose two children both arrived in the first kernel start climbing,
-// with the hand-off through HBM: the record is written with device-scope (write-through)
-// stores, the wave drains them (s_waitcnt vmcnt(0)) before its device-scope counter add (+16,
-// so the starting condition "two arrivals from the first kernel" stays readable), and the
-// sibling is read with device-scope loads only after the add has returned.  FENCE = true
-// replaces that with plain accesses bracketed by __threadfence() (diagnostic switch
-// RTHIP_REFIT_FENCE=1).
+// with the hand-off through HBM (MODE 0, the default): the record is written with device-scope
+// stores, the counter add (+16, so the starting condition "two arrivals from the first kernel"
+// stays readable) is a device-scope release read-modify-write, and the second child to arrive
+// passes a device-scope acquire fence before it reads the sibling's record -- a release /
+// acquire pair through the counter in the HIP memory model (the first child to arrive reads
+// nothing and needs no acquire).  MODE 1 (RTHIP_REFIT_FENCE=1, diagnostic): plain accesses bracketed by
+// __threadfence().  MODE 2 (RTHIP_REFIT_FENCE=2): relaxed accesses ordered only by draining the
+// wave's stores (s_waitcnt vmcnt(0)) before a relaxed add; correct on gfx950, where device-scope
+// stores write through, but not by the memory model -- kept to measure what the model costs.
 constexpr int kChunk = 512;  // sorted leaves per workgroup, one per thread
 
 struct alignas(16) NodeInfo {  // a finished inner node, indexed by its gap
@@ -599,8 +602,20 @@ __device__ __forceinline__ void merge_sibling(float* box, const float* sbox, boo
     }
 }
 
+// STREAM: write-through stores that leave no dirty line behind in the L2 (the upper kernel's release operations write
+// the L2's dirty lines back; its own node records need not be among them)
+template <bool STREAM = false>
 __device__ __forceinline__ void node_store(NodeInfo* node_info, uint8_t* node_dl, uint32_t gap, const float* box,
                                            uint32_t l, uint32_t r, uint32_t dl) {
+    if (STREAM) {
+        typedef float vfloat4 __attribute__((ext_vector_type(4)));
+        vfloat4* p = (vfloat4*)&node_info[gap];
+        const vfloat4 a = {box[0], box[1], box[2], box[3]}, b = {box[4], box[5], __uint_as_float(l), __uint_as_float(r)};
+        __builtin_nontemporal_store(a, p);
+        __builtin_nontemporal_store(b, p + 1);
+        __builtin_nontemporal_store((uint8_t)dl, &node_dl[gap]);
+        return;
+    }
     NodeInfo ni;
 #pragma unroll
     for (int k = 0; k < 6; k++) ni.box[k] = box[k];
@@ -755,7 +770,7 @@ __global__ __launch_bounds__(kChunk) void hierarchy_local_kernel(uint32_t n, con
                          leaf_sorted, starters, start_count);
 }
 
-template <bool FENCE>
+template <int MODE>
 __global__ __launch_bounds__(kBlock) void hierarchy_upper_kernel(uint32_t n, const uint8_t* __restrict__ prio,
                                                                  ChildRec* child, uint32_t* flags,
                                                                  uint32_t* __restrict__ cnt_l,
@@ -778,7 +793,7 @@ __global__ __launch_bounds__(kBlock) void hierarchy_upper_kernel(uint32_t n, con
         l = a.far_end;
         r = b.far_end;
         dl = a.dl + 1;
-        node_store(node_info, node_dl, parent, box, l, r, dl);
+        node_store<MODE == 0>(node_info, node_dl, parent, box, l, r, dl);
     }
     for (;;) {
         if (l == 0 && r == n - 1) {
@@ -790,16 +805,22 @@ __global__ __launch_bounds__(kBlock) void hierarchy_upper_kernel(uint32_t n, con
         const bool parent_right = (l == 0) || (r != n - 1 && pr_r > pr_l);
         parent = parent_right ? r : l - 1;
         const uint32_t side = parent_right ? 0u : 1u;
-        if (side == 1) cnt_l[l] = dl;
-        child_store<FENCE>(&child[2 * (uint64_t)parent + side], box, parent_right ? l : r, dl);
-        if (FENCE) __threadfence();
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const uint32_t old = atomicAdd(&flags[parent], 16u);
+        if (side == 1) { if (MODE == 0) __builtin_nontemporal_store(dl, &cnt_l[l]); else cnt_l[l] = dl; }
+        child_store<MODE == 1>(&child[2 * (uint64_t)parent + side], box, parent_right ? l : r, dl);
+        uint32_t old;
+        if (MODE == 0) {  // release: the record is visible device-wide before the count
+            old = __hip_atomic_fetch_add(&flags[parent], 16u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (MODE == 1) __threadfence();
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            old = atomicAdd(&flags[parent], 16u);
+        }
         if ((old & 15u) + (old >> 4) == 0u) break;  // first to arrive: the sibling carries on from here
-        if (FENCE) __threadfence();
+        if (MODE == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the sibling's record, released before its count
+        if (MODE == 1) __threadfence();
         float sbox[6];
         uint32_t s_far, s_dl;
-        child_load<FENCE>(&child[2 * (uint64_t)parent + (1u - side)], sbox, &s_far, &s_dl);
+        child_load<MODE == 1>(&child[2 * (uint64_t)parent + (1u - side)], sbox, &s_far, &s_dl);
         merge_sibling(box, sbox, side == 0);
         if (side == 0) {
             r = s_far;
@@ -808,7 +829,7 @@ __global__ __launch_bounds__(kBlock) void hierarchy_upper_kernel(uint32_t n, con
             l = s_far;
             dl = s_dl + 1;
         }
-        node_store(node_info, node_dl, parent, box, l, r, dl);
+        node_store<MODE == 0>(node_info, node_dl, parent, box, l, r, dl);
     }
     }
 }
@@ -1120,21 +1141,18 @@ int instance_aabbs_device(rthip_ctx* ctx, const DevInstance* d_inst, uint32_t n,
     return RTHIP_OK;
 }
 
-int lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, float4* d_nodes, hipStream_t s,
-                      uint64_t* d_codes_unsorted, uint64_t* d_keys_sorted, uint32_t* d_ids_sorted, bool paired,
-                      LbvhWorkspace* ws) {
-    if (n == 0) return rthip_fail(ctx, RTHIP_E_INVALID, "lbvh build needs at least one box");
-    if (n > (1ull << 30)) return rthip_fail(ctx, RTHIP_E_LIMIT, "lbvh build is limited to 2^30 boxes (got %llu)",
-                                            (unsigned long long)n);
+int lbvh_reserve_workspace(rthip_ctx* ctx, uint64_t n, LbvhWorkspace* ws) {
     LbvhWorkspace& w = ws ? *ws : ctx->ws;
-    if (ws) ctx->bounds_of = nullptr;  // bounds left by a triangle pass are in the context's own workspace
     const uint32_t tiles = div_up(n, kSortTile);
     const uint64_t hist_elems = 256ull * tiles;
     RT_TRY(rthip_reserve(ctx, w.keys[0], n * 8));
+
     RT_TRY(rthip_reserve(ctx, w.keys[1], n * 8));
     RT_TRY(rthip_reserve(ctx, w.vals[0], n * 4));
     RT_TRY(rthip_reserve(ctx, w.vals[1], n * 4));
-    RT_TRY(rthip_reserve(ctx, w.block_hist, (hist_elems + 256) * 4));
+    // the one-kernel-per-pass sort of small inputs keeps three histogram tables (radix_sort_workspace_device)
+    const uint64_t fused_elems = tiles <= kFusedTiles ? 3ull * 256 * tiles : 0;
+    RT_TRY(rthip_reserve(ctx, w.block_hist, ((hist_elems > fused_elems ? hist_elems : fused_elems) + 256) * 4));
     RT_TRY(rthip_reserve(ctx, w.scan_tmp, (scan_tmp_elems(hist_elems) + scan_tmp_elems(n)) * 4));
     RT_TRY(rthip_reserve(ctx, w.prio, n));
     RT_TRY(rthip_reserve(ctx, w.child, 2 * n * sizeof(ChildRec)));
@@ -1145,6 +1163,20 @@ int lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, float4* 
     RT_TRY(rthip_reserve(ctx, w.starters, n * 4));
     RT_TRY(rthip_reserve(ctx, w.cnt_l, n * 4));
     RT_TRY(rthip_reserve(ctx, w.bounds, 64));
+    return RTHIP_OK;
+}
+
+int lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, float4* d_nodes, hipStream_t s,
+                      uint64_t* d_codes_unsorted, uint64_t* d_keys_sorted, uint32_t* d_ids_sorted, bool paired,
+                      LbvhWorkspace* ws) {
+    if (n == 0) return rthip_fail(ctx, RTHIP_E_INVALID, "lbvh build needs at least one box");
+    if (n > (1ull << 30)) return rthip_fail(ctx, RTHIP_E_LIMIT, "lbvh build is limited to 2^30 boxes (got %llu)",
+                                            (unsigned long long)n);
+    LbvhWorkspace& w = ws ? *ws : ctx->ws;
+    if (ws) ctx->bounds_of = nullptr;  // bounds left by a triangle pass are in the context's own workspace
+    const uint32_t tiles = div_up(n, kSortTile);
+    const uint64_t hist_elems = 256ull * tiles;
+    RT_TRY(lbvh_reserve_workspace(ctx, n, &w));
 
     uint32_t* bounds = (uint32_t*)w.bounds.p;
     uint64_t* keys[2] = {(uint64_t*)w.keys[0].p, (uint64_t*)w.keys[1].p};
@@ -1195,16 +1227,14 @@ int lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, float4* 
     if (n > 1) {
         uint32_t ublocks = div_up(n - 1, kBlock);
         if (ublocks > 2048) ublocks = 2048;
-        if (ctx->refit_fence)
-            hierarchy_upper_kernel<true><<<ublocks, kBlock, 0, s>>>(
-                n32, (const uint8_t*)w.prio.p, (ChildRec*)w.child.p, (uint32_t*)w.flags.p, (uint32_t*)w.cnt_l.p,
-                (NodeInfo*)w.node_info.p, (uint8_t*)w.node_dl.p, (const uint32_t*)w.starters.p,
-                (const uint32_t*)w.flags.p + (n - 1));
-        else
-            hierarchy_upper_kernel<false><<<ublocks, kBlock, 0, s>>>(
-                n32, (const uint8_t*)w.prio.p, (ChildRec*)w.child.p, (uint32_t*)w.flags.p, (uint32_t*)w.cnt_l.p,
-                (NodeInfo*)w.node_info.p, (uint8_t*)w.node_dl.p, (const uint32_t*)w.starters.p,
-                (const uint32_t*)w.flags.p + (n - 1));
+#define RT_UPPER(MODE)                                                                                                 \
+    hierarchy_upper_kernel<MODE><<<ublocks, kBlock, 0, s>>>(                                                          \
+        n32, (const uint8_t*)w.prio.p, (ChildRec*)w.child.p, (uint32_t*)w.flags.p, (uint32_t*)w.cnt_l.p,              \
+        (NodeInfo*)w.node_info.p, (uint8_t*)w.node_dl.p, (const uint32_t*)w.starters.p, (const uint32_t*)w.flags.p + (n - 1))
+        if (ctx->refit_fence == 1) RT_UPPER(1);
+        else if (ctx->refit_fence == 2) RT_UPPER(2);
+        else RT_UPPER(0);
+#undef RT_UPPER
         RT_HIP(ctx, hipGetLastError());
     }
     RT_TRY((scan_u32<true>(ctx, (uint32_t*)w.cnt_l.p, n, scan_tmp + scan_tmp_elems(hist_elems), s)));

@@ -112,7 +112,7 @@ int rthip_create(rthip_ctx** out_ctx, int device_id) {
     rthip_ctx* ctx = new rthip_ctx();
     ctx->device = device_id;
     const char* fence = getenv("RTHIP_REFIT_FENCE");
-    ctx->refit_fence = (fence && fence[0] == '1') ? 1 : 0;
+    ctx->refit_fence = (fence && (fence[0] == '1' || fence[0] == '2')) ? fence[0] - '0' : 0;
     const char* mode = getenv("RTHIP_CAST");
     if (mode && strcmp(mode, "static") == 0) ctx->cast_mode = 1;
     if (mode && strcmp(mode, "static-samples") == 0) ctx->cast_mode = 4;
@@ -146,6 +146,7 @@ void rthip_destroy(rthip_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
+    for (const auto& r : ctx->pinned) (void)hipHostFree(r.p);
     for (auto& m : ctx->meshes) release_mesh(m);
     LbvhWorkspace& w = ctx->ws;
     DevBuf* all[] = {&w.aabb, &w.keys[0], &w.keys[1], &w.vals[0], &w.vals[1], &w.block_hist, &w.scan_tmp, &w.scan_aux, &w.prio,
@@ -158,6 +159,8 @@ void rthip_destroy(rthip_ctx* ctx) {
                      &ctx->obj.interleaved};
     for (DevBuf* b : all) rthip_release(*b);
     for (DevBuf& b : ctx->wf) rthip_release(b);
+    for (hipEvent_t e : ctx->slot_done)
+        if (e) (void)hipEventDestroy(e);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     rthip_release(ctx->tune_counters);
@@ -324,6 +327,7 @@ int rthip_blas_add_loaded_obj(rthip_ctx* ctx, uint32_t blas_id) {
 int rthip_blas_commit(rthip_ctx* ctx) {
     if (!ctx) return RTHIP_E_INVALID;
     RT_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->blas_committed) return rthip_fail(ctx, RTHIP_E_INVALID, "rthip_blas_commit: this mesh set is already committed (start another with rthip_blas_begin)");
     uint64_t nodes = 0, tris = 0;
     bool any_normals = false;
     for (size_t k = 0; k < ctx->meshes.size(); k++) {
@@ -344,10 +348,15 @@ int rthip_blas_commit(rthip_ctx* ctx) {
     RT_TRY(rthip_reserve(ctx, ctx->blas_nodes, nodes * 32));
     RT_TRY(rthip_reserve(ctx, ctx->tri_v, tris * 48));
     if (any_normals) RT_TRY(rthip_reserve(ctx, ctx->tri_n, tris * 48));
-    float total_ms = 0.f;
+    // all meshes are enqueued on the context's stream (the builds share the workspace, so they run one after the other
+    // there anyway) and the host waits once; the workspace is sized for the largest mesh first so that no build
+    // reallocates under an earlier one
+    uint32_t largest = 0;
+    for (const HostMesh& m : ctx->meshes) largest = m.n_tris > largest ? m.n_tris : largest;
+    RT_TRY(rthip_reserve(ctx, ctx->ws.aabb, (size_t)largest * 24));
+    RT_TRY(lbvh_reserve_workspace(ctx, largest));
+    RT_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     for (HostMesh& m : ctx->meshes) {
-        RT_TRY(rthip_reserve(ctx, ctx->ws.aabb, (size_t)m.n_tris * 24));
-        RT_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
         RT_TRY(mesh_prepare_device(ctx, (const float*)m.px.p, (const float*)m.py.p, (const float*)m.pz.p,
                                    (const float*)m.nx.p, (const float*)m.ny.p, (const float*)m.nz.p,
                                    m.index_count ? (const uint32_t*)m.indices.p : nullptr, m.n_tris,
@@ -357,15 +366,21 @@ int rthip_blas_commit(rthip_ctx* ctx) {
         RT_TRY(lbvh_build_device(ctx, (const float*)ctx->ws.aabb.p, m.n_tris,
                                  (float4*)ctx->blas_nodes.p + 2 * (size_t)m.dev.node_base, ctx->stream, nullptr,
                                  nullptr, nullptr, true));
-        RT_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-        RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        float ms = 0.f;
-        RT_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
-        total_ms += ms;
+    }
+    RT_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    float total_ms = 0.f;
+    RT_HIP(ctx, hipEventElapsedTime(&total_ms, ctx->ev0, ctx->ev1));
+    // the staging copies (the caller's interleaved buffer, SoA attributes, indices) are not read after this: the walk
+    // uses the per-triangle records and the nodes only
+    for (HostMesh& m : ctx->meshes) {
+        DevBuf* staging[] = {&m.interleaved, &m.indices, &m.px, &m.py, &m.pz, &m.nx, &m.ny, &m.nz};
+        for (DevBuf* b : staging) rthip_release(*b);
     }
     ctx->last_build_ms = total_ms;
     ctx->blas_committed = true;
     ctx->scene_generation++;
+    ctx->capture_next = 0;  // graphs captured over the previous scene are void
     return RTHIP_OK;
 }
 
@@ -423,6 +438,7 @@ int rthip_tlas_build(rthip_ctx* ctx, const rthip_instance* instances, uint32_t n
     ctx->tlas_built = false;
     ctx->n_inst = n_instances;
     ctx->scene_generation++;
+    ctx->capture_next = 0;  // graphs captured over the previous scene are void
     ctx->n_mats = n_materials;
     RT_TRY(rthip_reserve(ctx, ctx->inst, (size_t)n_instances * sizeof(DevInstance)));
     RT_TRY(rthip_reserve(ctx, ctx->mats, (size_t)n_materials * sizeof(rthip_material)));
@@ -470,6 +486,32 @@ int rthip_cast_accumulate_device(rthip_ctx* ctx, const rthip_cast_settings* cast
     const int rc = rthip_cast_device(ctx, cast, seed, d_accum_rgb, width, height, shard, stream);
     ctx->cast_accumulate = 0;
     return rc;
+}
+
+int rthip_host_alloc(rthip_ctx* ctx, uint64_t bytes, void** out_ptr) {
+    if (!ctx) return RTHIP_E_INVALID;
+    if (!out_ptr || bytes == 0) return rthip_fail(ctx, RTHIP_E_INVALID, "rthip_host_alloc: empty request");
+    *out_ptr = nullptr;
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    void* p = nullptr;
+    const hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+    if (e != hipSuccess || !p) return rthip_fail(ctx, RTHIP_E_NOMEM, "hipHostMalloc(%llu bytes) failed: %s", (unsigned long long)bytes, hipGetErrorString(e));
+    ctx->pinned.push_back({p, (size_t)bytes});
+    *out_ptr = p;
+    return RTHIP_OK;
+}
+
+int rthip_host_free(rthip_ctx* ctx, void* ptr) {
+    if (!ctx) return RTHIP_E_INVALID;
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    for (size_t k = 0; k < ctx->pinned.size(); k++)
+        if (ctx->pinned[k].p == ptr) {
+            RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            RT_HIP(ctx, hipHostFree(ptr));
+            ctx->pinned.erase(ctx->pinned.begin() + (long)k);
+            return RTHIP_OK;
+        }
+    return rthip_fail(ctx, RTHIP_E_INVALID, "rthip_host_free: %p does not come from rthip_host_alloc of this context", ptr);
 }
 
 int rthip_cast(rthip_ctx* ctx, const rthip_cast_settings* cast, uint64_t seed, float* out_rgb, int width, int height) {
@@ -585,6 +627,14 @@ int rthip_lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, rt
     return lbvh_build_device(ctx, d_aabb6, n, (float4*)d_nodes, (hipStream_t)stream, nullptr, nullptr, nullptr);
 }
 
+int rthip_lbvh_reserve(rthip_ctx* ctx, uint64_t n) {
+    if (!ctx) return RTHIP_E_INVALID;
+    if (n == 0 || n > (1ull << 30)) return rthip_fail(ctx, RTHIP_E_LIMIT, "box count %llu outside 1..2^30", (unsigned long long)n);
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_TRY(rthip_reserve(ctx, ctx->ws.aabb, n * 24));
+    return lbvh_reserve_workspace(ctx, n);
+}
+
 int rthip_lbvh_build_device_noalloc(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, rthip_node* d_nodes, void* stream) {
     if (!ctx) return RTHIP_E_INVALID;
     if (!d_aabb6 || !d_nodes) return rthip_fail(ctx, RTHIP_E_INVALID, "NULL device pointer");
@@ -677,6 +727,7 @@ int rthip_trace_rays_device(rthip_ctx* ctx, const float* d_origins, const float*
                             uint32_t* d_hits, void* stream) {
     RT_TRY(check_ready(ctx, "rthip_trace_rays_device"));
     if (n && (!d_origins || !d_directions || !d_hits)) return rthip_fail(ctx, RTHIP_E_INVALID, "NULL device pointer");
+    if (n >= (1ull << 32)) return rthip_fail(ctx, RTHIP_E_LIMIT, "at most 2^32 - 1 rays in one call (got %llu)", (unsigned long long)n);
     RT_HIP(ctx, hipSetDevice(ctx->device));
     return trace_rays_launch(ctx, make_scene(ctx), d_origins, d_directions, n, d_hits, nullptr, nullptr,
                              counters_or_null(ctx), (hipStream_t)stream);
@@ -687,6 +738,7 @@ int rthip_trace_rays(rthip_ctx* ctx, const float* origins, const float* directio
     RT_TRY(check_ready(ctx, "rthip_trace_rays"));
     if (n == 0) return RTHIP_OK;
     if (!origins || !directions) return rthip_fail(ctx, RTHIP_E_INVALID, "ray arrays are NULL");
+    if (n >= (1ull << 32)) return rthip_fail(ctx, RTHIP_E_LIMIT, "at most 2^32 - 1 rays in one call (got %llu)", (unsigned long long)n);
     RT_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     RT_TRY(rthip_reserve(ctx, ctx->scratch_a, n * 16));
@@ -712,7 +764,7 @@ int rthip_occluded_device(rthip_ctx* ctx, const float* d_origins, const float* d
                           uint8_t* d_out, void* stream) {
     RT_TRY(check_ready(ctx, "rthip_occluded_device"));
     if (n && (!d_origins || !d_directions || !d_out)) return rthip_fail(ctx, RTHIP_E_INVALID, "NULL device pointer");
-    if (n > (1ull << 40)) return rthip_fail(ctx, RTHIP_E_LIMIT, "more than 2^40 rays in one call");
+    if (n >= (1ull << 32)) return rthip_fail(ctx, RTHIP_E_LIMIT, "at most 2^32 - 1 rays in one call (got %llu)", (unsigned long long)n);
     RT_HIP(ctx, hipSetDevice(ctx->device));
     return occlusion_launch(ctx, make_scene(ctx), d_origins, d_directions, n, tmax, d_out, counters_or_null(ctx),
                             (hipStream_t)stream);

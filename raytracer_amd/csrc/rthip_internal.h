@@ -112,8 +112,14 @@ struct ObjState {
     DevBuf interleaved;         // the same in the reference's layout, one 16-byte slot per attribute
 };
 
-// launches of the persistent kernels that may be unfinished at one time (each owns a slot of work counters)
-constexpr uint32_t kWorkSlots = 64;
+// Every launch of a persistent kernel owns a slot of work counters (1 KiB: eight 128-byte-spaced counters and an arrival
+// word) from the moment it is enqueued until its last wave has left.  The first kEagerSlots slots serve ordinary
+// launches: a slot is taken only when the event recorded behind its previous launch has completed.  Launches that are
+// captured into a HIP graph bake the slot's address into the graph, so each takes one of the remaining slots for good
+// (until the scene is rebuilt, which invalidates such graphs anyway).
+constexpr uint32_t kEagerSlots = 64;
+constexpr uint32_t kCaptureSlots = 192;
+constexpr uint32_t kWorkSlots = kEagerSlots + kCaptureSlots;
 
 struct rthip_ctx {
     int device = 0;
@@ -121,8 +127,10 @@ struct rthip_ctx {
     uint32_t max_bounces = 8;
     int sky = 1;
     int counting = 0;
-    int refit_fence = 0;  // 1: use __threadfence() hand-offs in the hierarchy kernel (diagnostic)
+    int refit_fence = 0;  // hand-offs of the upper hierarchy kernel: 0 acquire-release counter, 1 __threadfence(), 2 relaxed + s_waitcnt
 
+    struct Pinned { void* p; size_t bytes; };
+    std::vector<Pinned> pinned;    // page-locked host memory handed out by rthip_host_alloc
     hipStream_t stream = nullptr;  // the context's own stream for host-blocking entry points
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
@@ -147,6 +155,9 @@ struct rthip_ctx {
     DevBuf counters;  // uint64[4]
     DevBuf work_ring;  // kWorkSlots x 1 KiB: eight 128-byte-spaced work counters per launch of a persistent kernel
     uint32_t work_next = 0;
+    hipEvent_t slot_done[kEagerSlots] = {};  // recorded behind the last launch that used the slot (created on first use)
+    bool slot_used[kEagerSlots] = {};
+    uint32_t capture_next = 0;               // capture slots handed out since the last scene build
     int cast_mode = 3;           // 0: persistent kernel, 1: fixed pixel per thread, 2: wavefront, 3: 0 or 1 by scene size (RTHIP_CAST=...)
     uint32_t persistent_blocks = 256u * 5u;  // resident workgroups of the persistent kernel (CUs x 5)
     DevBuf wf[11];               // path-state arrays of the wavefront renderer
@@ -215,6 +226,9 @@ int lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, float4* 
                       uint64_t* d_codes_unsorted, uint64_t* d_keys_sorted, uint32_t* d_ids_sorted, bool paired = false,
                       LbvhWorkspace* ws = nullptr);
 
+// Grows the context's workspace to what a build of n boxes needs (lbvh_build_device does so itself on demand).
+int lbvh_reserve_workspace(rthip_ctx* ctx, uint64_t n, LbvhWorkspace* ws = nullptr);
+
 // Builds of at most kStaticBuildMaxBoxes boxes can run in a workspace that is a file-scope device array instead of
 // allocated memory.  lbvh_static_workspace_init looks the array's address up on the context's device (once per device)
 // and carves ctx->ws_static out of it; no allocation.
@@ -239,6 +253,10 @@ int instance_aabbs_device(rthip_ctx* ctx, const DevInstance* d_inst, uint32_t n,
                           float* d_aabb6, hipStream_t stream);
 
 // ---- tracing (trace.hip) ----------------------------------------------------------
+// Work-counter slot for one launch of a persistent kernel on `stream` (see kEagerSlots); RTHIP_E_LIMIT when every slot
+// is held by an unfinished launch.  work_slot_launched records the launch behind the slot (not for captured launches).
+int work_slot_take(rthip_ctx* ctx, hipStream_t stream, uint32_t** out_work, int* out_slot);
+int work_slot_launched(rthip_ctx* ctx, int slot, hipStream_t stream);
 int trace_rays_launch(rthip_ctx* ctx, const DevScene& scene, const float* d_o, const float* d_d, uint64_t n,
                       uint32_t* d_hits4, float* d_uv, float* d_normal, uint64_t* d_counters, hipStream_t stream);
 int occlusion_launch(rthip_ctx* ctx, const DevScene& scene, const float* d_o, const float* d_d, uint64_t n, float tmax,

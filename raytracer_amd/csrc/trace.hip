@@ -599,6 +599,40 @@ inline uint32_t div_up(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) /
 
 }  // namespace
 
+int work_slot_take(rthip_ctx* ctx, hipStream_t stream, uint32_t** out_work, int* out_slot) {
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    if (stream) (void)hipStreamIsCapturing(stream, &capturing);
+    if (capturing != hipStreamCaptureStatusNone) {
+        if (ctx->capture_next >= kCaptureSlots)
+            return rthip_fail(ctx, RTHIP_E_LIMIT, "more than %u launches of a persistent kernel captured into HIP graphs since the last scene build", kCaptureSlots);
+        *out_slot = -1;
+        *out_work = (uint32_t*)ctx->work_ring.p + (size_t)(kEagerSlots + ctx->capture_next++) * 256u;
+        return RTHIP_OK;
+    }
+    for (uint32_t tried = 0; tried < kEagerSlots; tried++) {
+        const uint32_t k = (ctx->work_next + tried) % kEagerSlots;
+        if (ctx->slot_used[k]) {
+            const hipError_t e = hipEventQuery(ctx->slot_done[k]);
+            if (e == hipErrorNotReady) continue;  // its launch has not finished: the slot's counters are live
+            if (e != hipSuccess) return rthip_fail(ctx, RTHIP_E_HIP, "hipEventQuery failed: %s", hipGetErrorString(e));
+            ctx->slot_used[k] = false;
+        }
+        ctx->work_next = (k + 1) % kEagerSlots;
+        *out_slot = (int)k;
+        *out_work = (uint32_t*)ctx->work_ring.p + (size_t)k * 256u;
+        return RTHIP_OK;
+    }
+    return rthip_fail(ctx, RTHIP_E_LIMIT, "%u launches of a persistent kernel are unfinished: wait for some of them before enqueueing more", kEagerSlots);
+}
+
+int work_slot_launched(rthip_ctx* ctx, int slot, hipStream_t stream) {
+    if (slot < 0) return RTHIP_OK;  // a captured launch keeps its slot
+    if (!ctx->slot_done[slot]) RT_HIP(ctx, hipEventCreateWithFlags(&ctx->slot_done[slot], hipEventDisableTiming));
+    RT_HIP(ctx, hipEventRecord(ctx->slot_done[slot], stream));
+    ctx->slot_used[slot] = true;
+    return RTHIP_OK;
+}
+
 int trace_rays_launch(rthip_ctx* ctx, const DevScene& scene, const float* d_o, const float* d_d, uint64_t n,
                       uint32_t* d_hits4, float* d_uv, float* d_normal, uint64_t* d_counters, hipStream_t stream) {
     if (n == 0) return RTHIP_OK;
@@ -610,7 +644,9 @@ int trace_rays_launch(rthip_ctx* ctx, const DevScene& scene, const float* d_o, c
     if (n >= (1ull << 18) && n < (1ull << 32) * kRayGrab && resident) {
         uint32_t blocks = div_up(n, kBlock);
         if (blocks > ctx->persistent_blocks) blocks = ctx->persistent_blocks;
-        uint32_t* work = (uint32_t*)ctx->work_ring.p + (size_t)(ctx->work_next++ % kWorkSlots) * 256u;  // zeroed: see work_slot_release
+        uint32_t* work = nullptr;  // a slot of zeroed counters: see work_slot_release
+        int slot = -1;
+        RT_TRY(work_slot_take(ctx, stream, &work, &slot));
         if (d_counters)
             trace_rays_persistent_kernel<true><<<blocks, kBlock, 0, stream>>>(scene, d_o, d_d, n, d_hits4, d_uv, d_normal,
                                                                              work, ctx->refill_lanes, d_counters);
@@ -618,7 +654,7 @@ int trace_rays_launch(rthip_ctx* ctx, const DevScene& scene, const float* d_o, c
             trace_rays_persistent_kernel<false><<<blocks, kBlock, 0, stream>>>(scene, d_o, d_d, n, d_hits4, d_uv, d_normal,
                                                                               work, ctx->refill_lanes, nullptr);
         RT_HIP(ctx, hipGetLastError());
-        return RTHIP_OK;
+        return work_slot_launched(ctx, slot, stream);
     }
     const uint32_t blocks = div_up(n, kBlock);
     if (d_counters)
@@ -723,10 +759,12 @@ int launch_persistent(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_se
     uint32_t blocks = div_up(total, kBlock);
     if (blocks > ctx->persistent_blocks) blocks = ctx->persistent_blocks;
     const size_t lds = (size_t)(scene.max_bounces ? scene.max_bounces : 1) * kBlock * sizeof(uint32_t);
-    // every launch gets its own set of 8 work counters (one 128-byte line each) out of a ring of kWorkSlots, so that
-    // casts enqueued back to back or on several streams do not share them; a slot is zero when a launch starts (the
-    // ring is zeroed once, and every launch leaves its slot zeroed: work_slot_release)
-    uint32_t* work = (uint32_t*)ctx->work_ring.p + (size_t)(ctx->work_next++ % kWorkSlots) * 256u;
+    // every launch gets its own set of 8 work counters (one 128-byte line each), so that casts enqueued back to back or
+    // on several streams do not share them; a slot is taken only once its previous launch has finished, and is zero
+    // when a launch starts (the ring is zeroed once, and every launch leaves its slot zeroed: work_slot_release)
+    uint32_t* work = nullptr;
+    int slot = -1;
+    RT_TRY(work_slot_take(ctx, stream, &work, &slot));
     const bool defer = inst_batch != 0;
 #define RT_LAUNCH_CAST(COUNT, DEFER, CNT)                                                                              \
     cast_kernel<COUNT, DEFER><<<blocks, kBlock, lds, stream>>>(scene, cast, seed, d_rgb, width, height, shard, work, \
@@ -740,7 +778,7 @@ int launch_persistent(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_se
     }
 #undef RT_LAUNCH_CAST
     RT_HIP(ctx, hipGetLastError());
-    return RTHIP_OK;
+    return work_slot_launched(ctx, slot, stream);
 }
 
 struct Candidate {
@@ -841,7 +879,8 @@ int entry_batch(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_settings
         *batch = (uint32_t)ctx->samples_inst_batch_env;
         return RTHIP_OK;
     }
-    if (!ctx->small_meshes) return RTHIP_OK;
+    // a kernel selected by name runs as named: only RTHIP_KERNEL_AUTO probes (the probe renders and waits on the stream)
+    if (!ctx->small_meshes || ctx->cast_mode != 3) return RTHIP_OK;
     const uint64_t key[4] = {ctx->scene_generation, ((uint64_t)(uint32_t)width << 32) | (uint32_t)height,
                              (uint64_t)cast.samples * cast.samples, ((uint64_t)shard.mode << 32) | shard.world};
     if (!(ctx->batch_known && memcmp(key, ctx->batch_key, sizeof key) == 0)) {

@@ -5,7 +5,9 @@ is exchanged, once per frame:
   tiles    every rank renders the 64x64 tiles t with t % world == rank, other pixels stay 0, so the
            element-wise SUM of the shares is the frame (bit-identical to a single-GPU render);
   samples  every rank renders the sample indices s with s % world == rank of every pixel and leaves
-           the plain sum; SUM over ranks then one multiply by 1/samples^2 gives the frame;
+           the plain sum; SUM over ranks then one multiply by 1/samples^2 gives the frame up to
+           rounding (the sum is taken in another order than a single GPU's sample loop: equal to a few
+           ulp, not bit for bit -- tiles are the bit-exact mode);
   frames   every rank renders the whole frame with its own seed; SUM / world averages them
            (world times the samples in the same wall time: the weak-scaling mode of bench.py).
 """

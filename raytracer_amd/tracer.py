@@ -267,3 +267,17 @@ def set_morton_bounds(tracer: RT_Tracer, boxes: bool) -> None:
 
 def set_counting(tracer: RT_Tracer, enabled: bool) -> None:
     tracer.check(tracer.lib.rthip_set_counting(tracer.h, 1 if enabled else 0), "rthip_set_counting")
+
+
+def host_alloc(tracer: RT_Tracer, shape, dtype=np.float32) -> np.ndarray:
+    """A numpy array in page-locked host memory from rthip_host_alloc: rt_tracer_cast copies frames into it by DMA
+    (see include/rthip.h).  The memory lives until host_free or rt_tracer_cleanup."""
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    p = C.c_void_p()
+    tracer.check(tracer.lib.rthip_host_alloc(tracer.h, n, C.byref(p)), "rthip_host_alloc")
+    buf = (C.c_char * n).from_address(p.value)
+    return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+
+def host_free(tracer: RT_Tracer, a: np.ndarray) -> None:
+    tracer.check(tracer.lib.rthip_host_free(tracer.h, a.ctypes.data), "rthip_host_free")

@@ -457,6 +457,70 @@ def test_casts_can_be_captured_in_a_hip_graph(gpu_tracer, kernel):
         T.set_cast_kernel(gpu_tracer, "auto")
 
 
+def test_persistent_launches_never_share_work_counters(gpu_tracer):
+    """Every launch of the persistent kernel owns a slot of work counters until it has finished.  One long frame on one
+    stream while another stream runs through more short launches than there are slots, a captured graph replayed beside
+    eager casts, and more unfinished launches than slots (an error, not a silent collision)."""
+    import torch
+
+    verts, indices = scenes.bunny_class_mesh(4)
+    w, cam, sky = scenes.instanced_grid(24, seed=1, verts=verts, indices=indices)
+    build(gpu_tracer, w, 6, sky)
+    lib, h = gpu_tracer.lib, gpu_tracer.h
+    big_c, small_c = cam(1600, 1200, 2), cam(40, 24, 1)
+
+    def cast(c, wd, ht, seed, buf, stream):
+        gpu_tracer.check(lib.rthip_cast_device(h, abi.ptr(c), seed, buf.data_ptr(), wd, ht, None, stream.cuda_stream), "rthip_cast_device")
+
+    T.set_cast_kernel(gpu_tracer, "static")
+    main = torch.cuda.current_stream()
+    want_big = torch.zeros((1200, 1600, 3), dtype=torch.float32, device="cuda")
+    cast(big_c, 1600, 1200, 5, want_big, main)
+    want_small = [torch.zeros((24, 40, 3), dtype=torch.float32, device="cuda") for _ in range(150)]
+    for k, b in enumerate(want_small):
+        cast(small_c, 40, 24, 100 + k, b, main)
+    torch.cuda.synchronize()
+    T.set_cast_kernel(gpu_tracer, "persistent")
+    try:
+        a, b_stream, g_stream = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+        # a graph of two persistent launches, captured first
+        gbufs = [torch.zeros((24, 40, 3), dtype=torch.float32, device="cuda") for _ in range(2)]
+        graph = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(graph, stream=g_stream):
+            for k, gb in enumerate(gbufs):
+                cast(small_c, 40, 24, 100 + k, gb, torch.cuda.current_stream())
+        got_big = torch.full((1200, 1600, 3), -1.0, dtype=torch.float32, device="cuda")
+        got_small = [torch.full((24, 40, 3), -1.0, dtype=torch.float32, device="cuda") for _ in range(150)]
+        cast(big_c, 1600, 1200, 5, got_big, a)  # long: still running while the short ones go round the ring twice
+        for k, sb in enumerate(got_small):
+            cast(small_c, 40, 24, 100 + k, sb, b_stream)
+            if k % 10 == 0:
+                with torch.cuda.stream(g_stream):
+                    graph.replay()
+            if k % 50 == 49:
+                b_stream.synchronize()  # short launches finish and free their slots; the long one keeps its own
+        torch.cuda.synchronize()
+        assert torch.equal(got_big.view(torch.int32), want_big.view(torch.int32)), "the long frame lost pixels"
+        for k in range(150):
+            assert torch.equal(got_small[k].view(torch.int32), want_small[k].view(torch.int32)), f"short frame {k}"
+        for k in range(2):
+            assert torch.equal(gbufs[k].view(torch.int32), want_small[k].view(torch.int32)), f"graph frame {k}"
+        # more unfinished launches than slots: the call says so
+        blocker = torch.cuda.Stream()
+        with torch.cuda.stream(blocker):
+            torch.cuda._sleep(300_000_000)  # keeps everything behind it on this stream unfinished for a while
+        with pytest.raises(T.RTHipError, match="unfinished"):
+            for k in range(70):
+                cast(small_c, 40, 24, 100 + k, got_small[k], blocker)
+        torch.cuda.synchronize()
+        cast(small_c, 40, 24, 100, got_small[0], main)  # and the context works on afterwards
+        torch.cuda.synchronize()
+        assert torch.equal(got_small[0].view(torch.int32), want_small[0].view(torch.int32))
+    finally:
+        T.set_cast_kernel(gpu_tracer, "auto")
+
+
 def test_cornell_with_mesh_scene(oracle, gpu_tracer):
     """The multi-GPU configuration's scene (Cornell box + a metal PN mesh): trees, radiance and a tile shard."""
     verts, indices = scenes.bunny_class_mesh(3)
@@ -720,6 +784,24 @@ def test_occlusion_rays(oracle, gpu_tracer):
         assert (got == want).all(), f"instanced tmax {tmax}: {(got != want).sum()} rays differ"
     assert 0 < int(T.occluded(gpu_tracer, o, d, 3.0).sum()) < int(T.occluded(gpu_tracer, o, d, 40.0).sum())
     assert T.occluded(gpu_tracer, np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32)).size == 0
+
+
+def test_cast_into_page_locked_host_memory(gpu_tracer):
+    """A framebuffer from rthip_host_alloc changes how the frame reaches the host, not a bit of it."""
+    w, cam, sky = scenes.cornell()
+    build(gpu_tracer, w, 8, sky)
+    c = cam(200, 120, 2)
+    plain = np.zeros((120, 200, 3), dtype=np.float32)
+    T.rt_tracer_cast(gpu_tracer, c, plain, 200, 120, seed=3)
+    big = T.host_alloc(gpu_tracer, (4, 120, 200, 3))
+    big[:] = -1.0
+    for k in (2, 0):
+        T.rt_tracer_cast(gpu_tracer, c, big[k], 200, 120, seed=3)
+        assert (bits(big[k]) == bits(plain)).all()
+    assert float(big[1].max()) == -1.0 and float(big[3].max()) == -1.0
+    T.host_free(gpu_tracer, big)
+    with pytest.raises(T.RTHipError):
+        gpu_tracer.check(gpu_tracer.lib.rthip_host_free(gpu_tracer.h, plain.ctypes.data), "rthip_host_free")
 
 
 def test_shards_sum_to_the_frame(oracle, gpu_tracer):
