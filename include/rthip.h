@@ -304,6 +304,26 @@ int rthip_occluded(rthip_ctx* ctx, const float* origins, const float* directions
 int rthip_occluded_device(rthip_ctx* ctx, const float* d_origins, const float* d_directions, uint64_t n, float tmax,
                           uint8_t* d_out, void* stream);
 
+/* How the BVHs are walked by every cast and ray query that follows.  No counterpart in the reference (one walk,
+ * lbvh.c:151-161).
+ *   RTHIP_TRAV_EXACT (default)  the reference's walk: depth first, always the left child before the right one,
+ *                               whatever the ray.  Results are the reference's bit for bit.
+ *   RTHIP_TRAV_FAST             opt-in: the same trees, the same box / triangle / sphere arithmetic and the same
+ *                               acceptance rule (min <= t <= max), but the nearer child is visited first (the farther
+ *                               one waits on a per-lane stack in LDS) and an inner node's record holds both children's
+ *                               boxes.  Rays test several times fewer boxes.  The result is the closest hit as well;
+ *                               it differs from the reference's only where the reference's answer is an artefact of
+ *                               its visiting order: which of several primitives at exactly the same distance is
+ *                               reported, and seam rays where the reference skips a triangle because its box (tested
+ *                               without slack) lies behind the interval already shrunk to a neighbour's hit while
+ *                               the triangle test (with slack) would have accepted it, or the other way round.
+ *                               DESIGN.md holds the measured mismatch counts.  The wavefront kernel has no fast
+ *                               walk: RTHIP_KERNEL_WAVEFRONT renders with RTHIP_KERNEL_PERSISTENT in this mode.
+ * Switching to FAST builds the extra records for the trees that exist (and for every tree built afterwards: +64 bytes
+ * per inner node); it waits for the GPU. */
+enum { RTHIP_TRAV_EXACT = 0, RTHIP_TRAV_FAST = 1 };
+int rthip_set_traversal(rthip_ctx* ctx, int mode);
+
 /* Reads (and clears) the traversal counters; blocks until the context's work is done. */
 int rthip_get_stats(rthip_ctx* ctx, rthip_stats* out);
 /* Turns traversal counting on or off (off by default: counting costs atomics). */

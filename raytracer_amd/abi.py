@@ -90,6 +90,7 @@ SYMBOLS = [
     ("rthip_occluded_device", C.c_int, [_P, _P, _P, C.c_uint64, C.c_float, _P, _P]),
     ("rthip_get_stats", C.c_int, [_P, _P]),
     ("rthip_set_counting", C.c_int, [_P, C.c_int]),
+    ("rthip_set_traversal", C.c_int, [_P, C.c_int]),
     ("rthip_set_cast_kernel", C.c_int, [_P, C.c_int]),
     ("rthip_set_persistent_params", C.c_int, [_P, C.c_uint32, C.c_uint32]),
     ("rthip_get_tree", C.c_int, [_P, C.c_int, _P, _P]),

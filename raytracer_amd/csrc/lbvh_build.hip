@@ -1026,6 +1026,40 @@ __global__ __launch_bounds__(kBlock) void instance_aabb_kernel(const DevInstance
     }
 }
 
+// ---- records of the ordered (fast) traversal -------------------------------------------------------------------
+// From the finished pre-order tree (the walk's record form): inner node i has its left child in record i + 1 and its
+// right child in record skip(i + 1).  Inner nodes are numbered in pre-order among themselves (rank = exclusive count
+// of inner records before i), so the root is record 0 and a left inner child is the next record.  One record = 4
+// float4: {min.x, max.x, min.y, max.y} {min.z, max.z, ref, 0} of the left child, then the same of the right child;
+// ref = rank of an inner child, or 0x80000000 | id for a leaf child.
+__global__ __launch_bounds__(kBlock) void wide_flags_kernel(const float4* __restrict__ nodes, uint32_t n_nodes,
+                                                            uint32_t* __restrict__ flags) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n_nodes) flags[i] = __float_as_uint(nodes[2 * (uint64_t)i + 1].w) == 0u ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(kBlock) void wide_emit_kernel(const float4* __restrict__ nodes, uint32_t n_nodes,
+                                                           const uint32_t* __restrict__ rank, const uint32_t* __restrict__ tile_sums,
+                                                           float4* __restrict__ wide) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n_nodes) return;
+    const float4 mine = nodes[2 * (uint64_t)i + 1];
+    if (__float_as_uint(mine.w) != 0u) return;  // a leaf has no record of its own
+    auto rank_of = [&](uint32_t k) { return rank[k] + (tile_sums ? tile_sums[k / (uint32_t)kScanTile] : 0u); };
+    const uint32_t L = i + 1;
+    const float4 la = nodes[2 * (uint64_t)L], lb = nodes[2 * (uint64_t)L + 1];
+    const uint32_t R = __float_as_uint(lb.z);
+    const float4 ra = nodes[2 * (uint64_t)R], rb = nodes[2 * (uint64_t)R + 1];
+    const uint32_t lid = __float_as_uint(lb.w), rid = __float_as_uint(rb.w);
+    const uint32_t refl = lid ? (0x80000000u | lid) : rank_of(L);
+    const uint32_t refr = rid ? (0x80000000u | rid) : rank_of(R);
+    float4* out = wide + 4 * (uint64_t)rank_of(i);
+    out[0] = la;
+    out[1] = make_float4(lb.x, lb.y, __uint_as_float(refl), 0.f);
+    out[2] = ra;
+    out[3] = make_float4(rb.x, rb.y, __uint_as_float(refr), 0.f);
+}
+
 inline uint32_t div_up(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
 
 // exclusive / inclusive prefix sum of n uint32 in place; tmp holds the block sums of every level
@@ -1096,6 +1130,20 @@ int radix_sort_workspace_device(rthip_ctx* ctx, uint64_t n, int n_bytes, hipStre
         cur ^= 1;
     }
     *cur_io = cur;
+    return RTHIP_OK;
+}
+
+int wide_convert_device(rthip_ctx* ctx, const float4* d_nodes, uint32_t n_nodes, float4* d_wide, hipStream_t s) {
+    if (n_nodes < 3) return RTHIP_OK;  // a single leaf has no inner record
+    RT_TRY(rthip_reserve(ctx, ctx->wide_rank, (size_t)n_nodes * 4));
+    RT_TRY(rthip_reserve(ctx, ctx->ws.scan_aux, scan_tmp_elems(n_nodes) * 4));
+    uint32_t* rank = (uint32_t*)ctx->wide_rank.p;
+    const uint32_t blocks = div_up(n_nodes, kBlock);
+    wide_flags_kernel<<<blocks, kBlock, 0, s>>>(d_nodes, n_nodes, rank);
+    RT_HIP(ctx, hipGetLastError());
+    RT_TRY((scan_u32<false>(ctx, rank, n_nodes, (uint32_t*)ctx->ws.scan_aux.p, s)));
+    wide_emit_kernel<<<blocks, kBlock, 0, s>>>(d_nodes, n_nodes, rank, nullptr, d_wide);
+    RT_HIP(ctx, hipGetLastError());
     return RTHIP_OK;
 }
 

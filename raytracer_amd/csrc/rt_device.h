@@ -318,6 +318,200 @@ __device__ __forceinline__ Hit closest_hit_query_batched(const DevScene& S, V3 w
     return T.h;
 }
 
+template <bool COUNT>
+__device__ __forceinline__ bool any_hit_query(const DevScene& S, V3 wo, V3 wd, float tmax, Counters& cnt);
+
+// ---- ordered traversal (RTHIP_TRAV_FAST) ------------------------------------------------------------------------
+// The reference's query visits the two children of a node always left first (lbvh.c:157-158), whatever the ray, so a
+// ray that hits something close by still walks every subtree whose box it pierces in front of AND behind the hit until
+// the interval has shrunk.  The opt-in fast mode walks the same tree with the same box, triangle and sphere tests, but
+// (1) from records that hold BOTH children's boxes (64 bytes, one aligned fetch per inner node; leaves have no record
+// of their own, a child reference is either an inner record or a primitive id), (2) nearer child first, the farther one
+// pushed on a per-lane stack in LDS, so that a close hit shrinks the interval before the far subtrees are looked at.
+// Same acceptance rule for every primitive (min <= t <= max, ties accepted), so the result is the closest hit too; it
+// can differ from the reference's only where the reference's own answer depends on its visiting order: among hits at
+// exactly equal t the last visited wins, and a primitive whose box test (no slack) fails against the already shrunk
+// interval is never tested although its triangle test (with slack) would have accepted it.
+constexpr uint32_t kLeafBit = 0x80000000u;  // child reference: kLeafBit | 1-based primitive id, else index of an inner record
+constexpr uint32_t kPop = 0xffffffffu;      // "take the next reference from the stack"
+// Stack entries per lane, in LDS (entry e of a lane at lds[e * kBlock]: no bank conflicts).  The stack holds the far
+// siblings along the current path, so it is as deep as the tree at most; 24 covers the trees of scenes up to tens of
+// millions of primitives.  A ray that would need more (a degenerate tree: thousands of primitives at one point) sets
+// `overflow` and is answered by the stackless fixed-order walk instead, which needs no stack at all.
+constexpr int kFastLds = 24;
+
+struct FastStack {
+    uint32_t* lds;  // this lane's column
+};
+
+// The slab test of `slab` that also reports where the ray enters the box (the lower end of the clipped interval).
+__device__ __forceinline__ bool slab_near(float4 xy, float zlo, float zhi, V3 o, V3 inv, float tmax, float& tnear) {
+    float tmin = kEps;
+    slab_axis(xy.x, xy.y, o.x, inv.x, tmin, tmax);
+    slab_axis(xy.z, xy.w, o.y, inv.y, tmin, tmax);
+    slab_axis(zlo, zhi, o.z, inv.z, tmin, tmax);
+    tnear = tmin;
+    return !(tmax < tmin);
+}
+
+struct TravFast {
+    V3 wo, wd, winv;  // world-space ray and 1/d
+    V3 o, d, inv;     // ray of the level being walked
+    float tmax;
+    uint32_t cur;       // the reference to look at next (kPop: take one from the stack)
+    uint32_t sp, base;  // stack height, and the height at which the current instance was entered
+    uint32_t cur_inst;  // TLAS id of the instance being walked (0: in the TLAS)
+    uint32_t tri_base;
+    uint32_t overflow;  // the stack was too short for this ray: T.h is not valid, ask the stackless walk
+    const float4* nodes;  // the records being walked: 4 x float4 per inner node
+    Hit h;
+};
+
+__device__ __forceinline__ void trav_fast_begin(TravFast& T, const DevScene& S, V3 o, V3 d) {
+    T.wo = o;
+    T.wd = d;
+    T.winv = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);
+    T.o = o;
+    T.d = d;
+    T.inv = T.winv;
+    T.tmax = kMaxF;
+    T.cur = S.n_inst == 0 ? kPop : (S.n_inst == 1 ? (kLeafBit | 1u) : 0u);
+    T.sp = 0;
+    T.base = 0;
+    T.cur_inst = 0;
+    T.tri_base = 0;
+    T.overflow = 0;
+    T.nodes = S.tlas_wide;
+    T.h.inst = 0;
+    T.h.tri = 0;
+    T.h.u = 0.f;
+    T.h.v = 0.f;
+    T.h.t = kMaxF;
+}
+
+// One step.  Returns true when the query has ended (T.h is final).  ANY: stop at the first accepted primitive.
+template <bool COUNT>
+__device__ __forceinline__ bool trav_fast_step(TravFast& T, const DevScene& S, Counters& cnt, FastStack& st) {
+    uint32_t cur = T.cur;
+    if (cur == kPop) {
+        if (T.sp == T.base) {
+            if (T.cur_inst == 0) {
+                T.h.t = T.tmax;
+                return true;
+            }
+            // the instance's subtree is done: back to the TLAS walk with the world-space ray
+            T.cur_inst = 0;
+            T.nodes = S.tlas_wide;
+            T.o = T.wo;
+            T.d = T.wd;
+            T.inv = T.winv;
+            T.base = 0;
+            return false;
+        }
+        T.sp--;
+        cur = st.lds[T.sp * kBlock];
+    }
+    if (cur & kLeafBit) {
+        const uint32_t id = cur & ~kLeafBit;
+        T.cur = kPop;
+        if (T.cur_inst != 0) {  // a triangle
+            const float4* tv = S.tri_v + 3 * (size_t)(T.tri_base + (id - 1));
+            const float4 a = tv[0], b = tv[1], c = tv[2];
+            if (COUNT) cnt.tris++;
+            float u, v;
+            if (tri_test(T.o, T.d, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), kEps, T.tmax, u, v)) {
+                T.h.inst = T.cur_inst;
+                T.h.tri = (id - 1) * 3;
+                T.h.u = u;
+                T.h.v = v;
+            }
+            return false;
+        }
+        const DevInstance* it = &S.inst[id - 1];
+        if (COUNT) cnt.insts++;
+        if (it->type == RTHIP_INST_SPHERE) {
+            const float4 cr = *(const float4*)it->sphere_center;
+            if (sphere_test(T.o, T.d, mk(cr.x, cr.y, cr.z), it->sphere_radius, kEps, T.tmax)) {
+                T.h.inst = id;
+                T.h.tri = 0;
+                T.h.u = 0.f;
+                T.h.v = 0.f;
+            }
+            return false;
+        }
+        const float4 tr = *(const float4*)it->translation;
+        const float4 q = *(const float4*)it->rotation;
+        const float4 sc = *(const float4*)it->scale;
+        const V3 qv = mk(-q.x, -q.y, -q.z);
+        const V3 s3 = mk(sc.x, sc.y, sc.z);
+        T.o = divv(rot_quat(sub(T.wo, mk(tr.x, tr.y, tr.z)), qv, q.w), s3);
+        T.d = divv(rot_quat(T.wd, qv, q.w), s3);
+        T.inv = mk(1.f / T.d.x, 1.f / T.d.y, 1.f / T.d.z);
+        T.cur_inst = id;
+        T.tri_base = it->tri_base;
+        T.nodes = S.blas_wide + 4 * (size_t)it->wide_base;
+        T.base = T.sp;
+        T.cur = it->n_nodes == 1 ? (kLeafBit | 1u) : 0u;  // a one-triangle mesh has no inner record
+        return false;
+    }
+    const float4* rec = T.nodes + 4 * (size_t)cur;
+    const float4 l0 = rec[0], l1 = rec[1], r0 = rec[2], r1 = rec[3];
+    if (COUNT) cnt.nodes += 2;
+    float tl, tr_;
+    const bool hl = slab_near(l0, l1.x, l1.y, T.o, T.inv, T.tmax, tl);
+    const bool hr = slab_near(r0, r1.x, r1.y, T.o, T.inv, T.tmax, tr_);
+    const uint32_t refl = __float_as_uint(l1.z), refr = __float_as_uint(r1.z);
+    if (hl && hr) {
+        const bool right_first = tr_ < tl;  // equal entry distances: left first, like the reference
+        if (T.sp >= (uint32_t)kFastLds) {  // no room: give up on this walk (the caller falls back, see kFastLds)
+            T.overflow = 1;
+            T.h.t = T.tmax;
+            return true;
+        }
+        st.lds[T.sp * kBlock] = right_first ? refl : refr;
+        T.sp++;
+        T.cur = right_first ? refr : refl;
+    } else {
+        T.cur = hl ? refl : (hr ? refr : kPop);
+    }
+    return false;
+}
+
+template <bool COUNT>
+__device__ __forceinline__ Hit closest_hit_query_fast(const DevScene& S, V3 wo, V3 wd, Counters& cnt, uint32_t* lds_column) {
+    TravFast T;
+    FastStack st;
+    st.lds = lds_column;
+    trav_fast_begin(T, S, wo, wd);
+    for (;;) {
+        if (COUNT) {
+            const uint64_t walking = __ballot(1);
+            if ((int)(threadIdx.x & 63) == __ffsll((long long)walking) - 1) cnt.wave_steps++;
+        }
+        if (trav_fast_step<COUNT>(T, S, cnt, st)) break;
+    }
+    if (T.overflow) return closest_hit_query<COUNT>(S, wo, wd, cnt);
+    return T.h;
+}
+
+template <bool COUNT>
+__device__ __forceinline__ bool any_hit_query_fast(const DevScene& S, V3 wo, V3 wd, float tmax, Counters& cnt, uint32_t* lds_column) {
+    TravFast T;
+    FastStack st;
+    st.lds = lds_column;
+    trav_fast_begin(T, S, wo, wd);
+    T.tmax = tmax;
+    for (;;) {
+        if (COUNT) {
+            const uint64_t walking = __ballot(1);
+            if ((int)(threadIdx.x & 63) == __ffsll((long long)walking) - 1) cnt.wave_steps++;
+        }
+        if (trav_fast_step<COUNT>(T, S, cnt, st) || T.h.inst != 0) break;
+    }
+    if (T.overflow) return any_hit_query<COUNT>(S, wo, wd, tmax, cnt);
+    return T.h.inst != 0;
+}
+
 // Occlusion: whether the same query over the interval [EPSILON_F32, tmax] would report a hit.  The
 // walk up to the first accepted primitive does not depend on anything after it, so it stops there.
 template <bool COUNT>

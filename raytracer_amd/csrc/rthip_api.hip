@@ -64,6 +64,8 @@ DevScene make_scene(const rthip_ctx* ctx) {
     s.tlas = (const float4*)ctx->tlas_nodes.p;
     s.n_tlas = ctx->n_inst ? 2 * ctx->n_inst - 1 : 0;
     s.blas = (const float4*)ctx->blas_nodes.p;
+    s.tlas_wide = (const float4*)ctx->tlas_wide.p;
+    s.blas_wide = (const float4*)ctx->blas_wide.p;
     s.tri_v = (const float4*)ctx->tri_v.p;
     s.tri_n = (const float4*)ctx->tri_n.p;
     s.inst = (const DevInstance*)ctx->inst.p;
@@ -91,6 +93,25 @@ int check_cast(rthip_ctx* ctx, const rthip_cast_settings* cast, int width, int h
 }
 
 uint64_t* counters_or_null(rthip_ctx* ctx) { return ctx->counting ? (uint64_t*)ctx->counters.p : nullptr; }
+
+// RTHIP_TRAV_FAST: the records of the ordered walk for every committed mesh / for the TLAS (enqueued on ctx->stream)
+int convert_blas_wide(rthip_ctx* ctx) {
+    RT_TRY(rthip_reserve(ctx, ctx->blas_wide, (ctx->total_tris ? ctx->total_tris : 1) * 64));
+    for (HostMesh& m : ctx->meshes)
+        RT_TRY(wide_convert_device(ctx, (const float4*)ctx->blas_nodes.p + 2 * (size_t)m.dev.node_base, m.dev.n_nodes,
+                                   (float4*)ctx->blas_wide.p + 4 * (size_t)m.dev.wide_base, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->blas_wide_ready = true;
+    return RTHIP_OK;
+}
+int convert_tlas_wide(rthip_ctx* ctx) {
+    RT_TRY(rthip_reserve(ctx, ctx->tlas_wide, (ctx->n_inst ? (size_t)ctx->n_inst : 1) * 64));
+    if (ctx->n_inst)
+        RT_TRY(wide_convert_device(ctx, (const float4*)ctx->tlas_nodes.p, 2 * ctx->n_inst - 1, (float4*)ctx->tlas_wide.p, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->tlas_wide_ready = true;
+    return RTHIP_OK;
+}
 
 }  // namespace
 
@@ -151,7 +172,7 @@ void rthip_destroy(rthip_ctx* ctx) {
     LbvhWorkspace& w = ctx->ws;
     DevBuf* all[] = {&w.aabb, &w.keys[0], &w.keys[1], &w.vals[0], &w.vals[1], &w.block_hist, &w.scan_tmp, &w.scan_aux, &w.prio,
                      &w.child, &w.flags, &w.starters, &w.node_info, &w.node_dl, &w.leaf_sorted, &w.cnt_l, &w.bounds, &ctx->blas_nodes, &ctx->tri_v, &ctx->tri_n,
-                     &ctx->tlas_nodes, &ctx->inst, &ctx->mats, &ctx->inst_aabb, &ctx->counters, &ctx->work_ring, &ctx->scratch_a,
+                     &ctx->blas_wide, &ctx->tlas_wide, &ctx->wide_rank, &ctx->tlas_nodes, &ctx->inst, &ctx->mats, &ctx->inst_aabb, &ctx->counters, &ctx->work_ring, &ctx->scratch_a,
                      &ctx->scratch_b, &ctx->scratch_c, &ctx->scratch_d, &ctx->scratch_e, &ctx->frame, &ctx->hdr_stage,
                      &ctx->hdr_lengths, &ctx->hdr_offsets, &ctx->hdr_out, &ctx->hdr_size, &ctx->obj.cp, &ctx->obj.cn, &ctx->obj.ct,
                      &ctx->obj.pos, &ctx->obj.nrm, &ctx->obj.uv, &ctx->obj.head, &ctx->obj.first, &ctx->obj.run_first,
@@ -188,6 +209,21 @@ int rthip_set_morton_bounds(rthip_ctx* ctx, int mode) {
     return RTHIP_OK;
 }
 
+int rthip_set_traversal(rthip_ctx* ctx, int mode) {
+    if (!ctx) return RTHIP_E_INVALID;
+    if (mode != RTHIP_TRAV_EXACT && mode != RTHIP_TRAV_FAST)
+        return rthip_fail(ctx, RTHIP_E_INVALID, "traversal mode must be RTHIP_TRAV_EXACT (0) or RTHIP_TRAV_FAST (1), got %d", mode);
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    if (mode == RTHIP_TRAV_FAST) {  // trees built so far get their records now, later ones when they are built
+        RT_HIP(ctx, hipDeviceSynchronize());
+        if (ctx->blas_committed && !ctx->blas_wide_ready) RT_TRY(convert_blas_wide(ctx));
+        if (ctx->tlas_built && !ctx->tlas_wide_ready) RT_TRY(convert_tlas_wide(ctx));
+    }
+    ctx->traversal = mode;
+    ctx->scene_generation++;  // measured kernel choices belong to the other walk
+    return RTHIP_OK;
+}
+
 int rthip_set_counting(rthip_ctx* ctx, int enabled) {
     if (!ctx) return RTHIP_E_INVALID;
     ctx->counting = enabled ? 1 : 0;
@@ -221,6 +257,7 @@ int rthip_blas_begin(rthip_ctx* ctx, uint32_t n_meshes) {
     ctx->meshes.resize(n_meshes);
     ctx->blas_committed = false;
     ctx->tlas_built = false;
+    ctx->blas_wide_ready = ctx->tlas_wide_ready = false;
     ctx->total_blas_nodes = 0;
     ctx->total_tris = 0;
     return RTHIP_OK;
@@ -334,6 +371,7 @@ int rthip_blas_commit(rthip_ctx* ctx) {
         HostMesh& m = ctx->meshes[k];
         if (!m.present) return rthip_fail(ctx, RTHIP_E_INVALID, "mesh %zu was never added", k);
         m.dev.node_base = (uint32_t)nodes;
+        m.dev.wide_base = (uint32_t)(tris - k);  // a mesh of T triangles has T - 1 inner nodes
         m.dev.n_nodes = 2 * m.n_tris - 1;
         m.dev.tri_base = (uint32_t)tris;
         m.dev.n_tris = m.n_tris;
@@ -378,6 +416,8 @@ int rthip_blas_commit(rthip_ctx* ctx) {
         for (DevBuf* b : staging) rthip_release(*b);
     }
     ctx->last_build_ms = total_ms;
+    ctx->blas_wide_ready = false;
+    if (ctx->traversal == RTHIP_TRAV_FAST) RT_TRY(convert_blas_wide(ctx));
     ctx->blas_committed = true;
     ctx->scene_generation++;
     ctx->capture_next = 0;  // graphs captured over the previous scene are void
@@ -411,6 +451,7 @@ int rthip_tlas_build(rthip_ctx* ctx, const rthip_instance* instances, uint32_t n
                 return rthip_fail(ctx, RTHIP_E_INVALID, "instance %u: blas_id %u out of range (%zu meshes)", k, s.blas_id, ctx->meshes.size());
             const DevMesh& m = ctx->meshes[s.blas_id].dev;
             d.node_base = m.node_base;
+            d.wide_base = m.wide_base;
             d.n_nodes = m.n_nodes;
             d.tri_base = m.tri_base;
             d.has_normals = m.has_normals;
@@ -457,6 +498,8 @@ int rthip_tlas_build(rthip_ctx* ctx, const rthip_instance* instances, uint32_t n
     }
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));  // dev[] must outlive the copy
     if (n_instances) RT_HIP(ctx, hipEventElapsedTime(&ctx->last_build_ms, ctx->ev0, ctx->ev1));
+    ctx->tlas_wide_ready = false;
+    if (ctx->traversal == RTHIP_TRAV_FAST) RT_TRY(convert_tlas_wide(ctx));
     ctx->tlas_built = true;
     return RTHIP_OK;
 }

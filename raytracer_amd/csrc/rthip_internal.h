@@ -51,6 +51,7 @@ struct DevTree {
 
 // Per-mesh data the traversal kernels read.
 struct DevMesh {
+    uint32_t wide_base;  // first inner record of this mesh in the fast mode's record array
     uint32_t node_base;  // first node of this BLAS in the shared node array (in nodes, not float4s)
     uint32_t n_nodes;
     uint32_t tri_base;   // first triangle of this mesh in the shared triangle arrays
@@ -67,7 +68,7 @@ struct DevInstance {
     uint32_t tri_base;
     uint32_t has_normals;
     float sphere_radius;
-    float pad0;
+    uint32_t wide_base;  // first inner record of this mesh in the fast mode's record array (records, not float4s)
     float sphere_center[4];
     float translation[4];
     float rotation[4];
@@ -80,6 +81,8 @@ struct DevScene {
     const float4* blas;       // all BLAS nodes, mesh after mesh
     const float4* tri_v;      // 3 x float4 per triangle: v0, v1, v2 (w unused), mesh after mesh
     const float4* tri_n;      // 3 x float4 per triangle: n0, n1, n2 (meshes without normals: unused)
+    const float4* tlas_wide;  // RTHIP_TRAV_FAST: 4 x float4 per inner TLAS node (both children's boxes and references)
+    const float4* blas_wide;  // the same for every mesh, mesh after mesh
     const DevInstance* inst;  // by TLAS id - 1
     const rthip_material* mats;
     uint32_t n_inst;
@@ -145,6 +148,11 @@ struct rthip_ctx {
     DevBuf tri_n;       // float4[3 * total tris]
     uint64_t total_blas_nodes = 0, total_tris = 0;
 
+    int traversal = 0;        // RTHIP_TRAV_EXACT / RTHIP_TRAV_FAST
+    DevBuf blas_wide;         // float4[4 * (total tris - meshes)]: the fast mode's records of every BLAS
+    DevBuf tlas_wide;         // float4[4 * (n_inst - 1)]
+    DevBuf wide_rank;         // uint32[nodes]: scratch of the conversion
+    bool blas_wide_ready = false, tlas_wide_ready = false;
     DevBuf tlas_nodes;  // float4[2 * (2 n_inst - 1)]
     DevBuf inst;        // DevInstance[n_inst]
     DevBuf mats;        // rthip_material[n_mats]
@@ -248,6 +256,10 @@ int mesh_prepare_device(rthip_ctx* ctx, const float* px, const float* py, const 
 
 int deinterleave_device(rthip_ctx* ctx, const void* d_interleaved, uint32_t vertex_count, uint32_t stride,
                         uint32_t off, float* x, float* y, float* z, hipStream_t stream);
+
+// The fast mode's records (both children's boxes and references per inner node, in pre-order among the inner nodes)
+// from a finished pre-order tree in the walk's own record form.  d_wide holds 4 float4 per inner node ((n_nodes - 1) / 2).
+int wide_convert_device(rthip_ctx* ctx, const float4* d_nodes, uint32_t n_nodes, float4* d_wide, hipStream_t stream);
 
 int instance_aabbs_device(rthip_ctx* ctx, const DevInstance* d_inst, uint32_t n, const float4* d_blas,
                           float* d_aabb6, hipStream_t stream);

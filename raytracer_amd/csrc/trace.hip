@@ -42,6 +42,44 @@ __device__ __forceinline__ void put_pixel(float* __restrict__ out, uint32_t pixe
     }
 }
 
+// The state of one lane's query in either traversal mode behind one interface, so that every renderer kernel exists
+// for both: the reference's fixed-order stackless walk (Trav) and the ordered walk with a stack (TravFast).
+template <bool FAST>
+struct Walk;
+template <>
+struct Walk<false> {
+    Trav T;
+    __device__ __forceinline__ void init(uint32_t*) {}
+    __device__ __forceinline__ void begin(const DevScene& S, V3 o, V3 d) { trav_begin(T, S, o, d); }
+    template <bool COUNT, bool DEFER>
+    __device__ __forceinline__ bool step(const DevScene& S, Counters& cnt) { return trav_step<COUNT, DEFER>(T, S, cnt); }
+};
+template <>
+struct Walk<true> {
+    TravFast T;
+    FastStack st;
+    __device__ __forceinline__ void init(uint32_t* lds_column) { st.lds = lds_column; }
+    __device__ __forceinline__ void begin(const DevScene& S, V3 o, V3 d) { trav_fast_begin(T, S, o, d); }
+    template <bool COUNT, bool DEFER>
+    __device__ __forceinline__ bool step(const DevScene& S, Counters& cnt) {
+        if (!trav_fast_step<COUNT>(T, S, cnt, st)) return false;
+        if (T.overflow) T.h = closest_hit_query<COUNT>(S, T.wo, T.wd, cnt);  // see kFastLds
+        return true;
+    }
+};
+
+// This lane's column of the ordered walk's stack: it lies behind the bounce stack in the dynamic LDS block.
+__device__ __forceinline__ uint32_t* fast_column(uint32_t* bounce_stack_base, uint32_t max_bounces) {
+    return bounce_stack_base + (size_t)(max_bounces ? max_bounces : 1u) * kBlock + threadIdx.x;
+}
+
+// One closest-hit query in the chosen mode.
+template <bool COUNT, bool FAST>
+__device__ __forceinline__ Hit query(const DevScene& S, V3 o, V3 d, Counters& cnt, uint32_t* fast_col) {
+    if constexpr (FAST) return closest_hit_query_fast<COUNT>(S, o, d, cnt, fast_col);
+    else return closest_hit_query<COUNT>(S, o, d, cnt);
+}
+
 // End of a persistent kernel: the slot of work counters is left zeroed for its next user by the last wave to get here
 // (every wave counts itself in word 16 when it has stopped taking work; no barrier, a finished wave leaves at once).
 // No memset between launches, so a launch is one graph node and replays of a captured graph start from zeroed counters.
@@ -55,7 +93,7 @@ __device__ __forceinline__ void work_slot_release(uint32_t* work) {
     }
 }
 
-template <bool COUNT, bool DEFER>
+template <bool COUNT, bool DEFER, bool FAST = false>
 __global__ __launch_bounds__(kBlock, 5) void cast_kernel(DevScene S, rthip_cast_settings c, uint64_t seed,
                                                       float* __restrict__ out, int width, int height,
                                                       rthip_shard shard, uint32_t* work_counters, uint32_t refill, uint32_t inst_batch,
@@ -87,8 +125,9 @@ __global__ __launch_bounds__(kBlock, 5) void cast_kernel(DevScene S, rthip_cast_
     P.ior_top = P.ior_below = c.ior;
     P.g.key = 0;
     P.g.draw = 0;
-    Trav T;
-    trav_begin(T, S, mk(0.f, 0.f, 0.f), mk(0.f, 0.f, 1.f));
+    Walk<FAST> Wk;
+    Wk.init(fast_column(bounce_stack, S.max_bounces));
+    Wk.begin(S, mk(0.f, 0.f, 0.f), mk(0.f, 0.f, 1.f));
 
     for (;;) {
         // ---- phase 1: a pixel whose samples are all done is written out ---------------------------
@@ -174,7 +213,7 @@ __global__ __launch_bounds__(kBlock, 5) void cast_kernel(DevScene S, rthip_cast_
                 acc = add(acc, mk(0.f, 0.f, 0.f));
                 sidx++;
             } else {
-                trav_begin(T, S, o, d);
+                Wk.begin(S, o, d);
                 rays++;
                 state = ST_TRAVERSE;
             }
@@ -192,33 +231,33 @@ __global__ __launch_bounds__(kBlock, 5) void cast_kernel(DevScene S, rthip_cast_
             // else can step): the same work per lane, in fewer executions of the long branch.  It pays where
             // rays enter instances often (many small instances); elsewhere the plain step is faster.
             if (COUNT && (int)lane == __ffsll((long long)walking) - 1) cnt.wave_steps++;
-            if (DEFER) {
-                const uint64_t parked = __ballot(state == ST_TRAVERSE && T.pend_id != 0);
+            if constexpr (DEFER && !FAST) {
+                const uint64_t parked = __ballot(state == ST_TRAVERSE && Wk.T.pend_id != 0);
                 const bool enter_now =
                     parked != 0 && ((uint32_t)__popcll(parked) >= inst_batch || (walking & ~parked) == 0);
                 if (state == ST_TRAVERSE) {
-                    if (T.pend_id != 0) {
-                        if (enter_now) trav_enter<COUNT>(T, S, cnt);
-                    } else if (trav_step<COUNT, true>(T, S, cnt)) {
+                    if (Wk.T.pend_id != 0) {
+                        if (enter_now) trav_enter<COUNT>(Wk.T, S, cnt);
+                    } else if (trav_step<COUNT, true>(Wk.T, S, cnt)) {
                         state = ST_SHADE;
                     }
                 }
             } else if (state == ST_TRAVERSE) {
-                if (trav_step<COUNT, false>(T, S, cnt)) state = ST_SHADE;
+                if (Wk.template step<COUNT, false>(S, cnt)) state = ST_SHADE;
             }
         }
 
         // ---- phase 5: shading / bounce generation ----------------------------------------------------
         if (state == ST_SHADE) {
-            V3 o = T.wo, d = T.wd;
+            V3 o = Wk.T.wo, d = Wk.T.wd;
             V3 L;
-            if (path_bounce(S, P, T.h, o, d, L, stack, kBlock)) {
+            if (path_bounce(S, P, Wk.T.h, o, d, L, stack, kBlock)) {
                 L = path_fold(S, P, L, stack, kBlock);
                 acc = add(acc, L);
                 sidx++;
                 state = ST_NEED_SAMPLE;
             } else {
-                trav_begin(T, S, o, d);
+                Wk.begin(S, o, d);
                 rays++;
                 state = ST_TRAVERSE;
             }
@@ -248,7 +287,7 @@ __device__ __forceinline__ bool pixel_of_thread(int width, int height, int& x, i
 #ifndef RT_STATIC_WAVES
 #define RT_STATIC_WAVES 5
 #endif
-template <bool COUNT, bool BATCH = false>
+template <bool COUNT, bool BATCH = false, bool FAST = false>
 __global__ __launch_bounds__(kBlock, RT_STATIC_WAVES) void cast_static_kernel(DevScene S, rthip_cast_settings c, uint64_t seed,
                                                              float* __restrict__ out, int width, int height,
                                                              rthip_shard shard, uint32_t accumulate, uint64_t* counters,
@@ -287,7 +326,8 @@ __global__ __launch_bounds__(kBlock, RT_STATIC_WAVES) void cast_static_kernel(De
                     if (P.depth != 0) {
                         for (;;) {
                             rays++;
-                            const Hit h = BATCH ? closest_hit_query_batched<COUNT>(S, o, d, cnt, inst_batch) : closest_hit_query<COUNT>(S, o, d, cnt);
+                            const Hit h = BATCH ? closest_hit_query_batched<COUNT>(S, o, d, cnt, inst_batch)
+                                                : query<COUNT, FAST>(S, o, d, cnt, fast_column(bounce_stack, S.max_bounces));
                             if (path_bounce(S, P, h, o, d, L, stack, kBlock)) break;
                         }
                         L = path_fold(S, P, L, stack, kBlock);
@@ -325,7 +365,7 @@ __global__ __launch_bounds__(kBlock, RT_STATIC_WAVES) void cast_static_kernel(De
 // kernel would hold the frame in a few long-running waves (Cornell 512^2 at 4 spp: 4096 waves, all resident from the
 // start, the slowest 1.5 times the median).  The samples of a pixel are added in the order of the sample loop
 // (raytracer_cpu.c:196-236) by the pixel's first lane, so the sum has the same bits.
-template <bool COUNT, bool BATCH>
+template <bool COUNT, bool BATCH, bool FAST = false>
 __global__ __launch_bounds__(kBlock, RT_STATIC_WAVES) void cast_samples_kernel(DevScene S, rthip_cast_settings c, uint64_t seed,
                                                               float* __restrict__ out, int width, int height,
                                                               rthip_shard shard, uint32_t log2_group, uint32_t accumulate,
@@ -363,7 +403,8 @@ __global__ __launch_bounds__(kBlock, RT_STATIC_WAVES) void cast_samples_kernel(D
         if (P.depth != 0) {
             for (;;) {
                 rays++;
-                const Hit h = BATCH ? closest_hit_query_batched<COUNT>(S, o, d, cnt, inst_batch) : closest_hit_query<COUNT>(S, o, d, cnt);
+                const Hit h = BATCH ? closest_hit_query_batched<COUNT>(S, o, d, cnt, inst_batch)
+                                    : query<COUNT, FAST>(S, o, d, cnt, fast_column(bounce_stack, S.max_bounces));
                 if (path_bounce(S, P, h, o, d, L, stack, kBlock)) break;
             }
             L = path_fold(S, P, L, stack, kBlock);
@@ -387,6 +428,7 @@ __global__ __launch_bounds__(kBlock, RT_STATIC_WAVES) void cast_samples_kernel(D
 // Debugging aid: the renderer with one thread per path (pixel-major, then sample: the reference's loop order) that
 // also stores what a BUILD_DEBUG build of the reference dumps for every ray (src/raytracer/cpu/extra/dump.c:11-32):
 // path i writes its k-th ray to slots[i * max_bounces + k] and the number of its rays to counts[i].
+template <bool FAST>
 __global__ __launch_bounds__(kBlock) void cast_records_kernel(DevScene S, rthip_cast_settings c, uint64_t seed, int width,
                                                               int height, rthip_ray_record* __restrict__ slots,
                                                               uint32_t* __restrict__ counts) {
@@ -410,7 +452,7 @@ __global__ __launch_bounds__(kBlock) void cast_records_kernel(DevScene S, rthip_
     if (P.depth != 0) {
         V3 L = mk(0.f, 0.f, 0.f);
         for (;;) {
-            const Hit h = closest_hit_query<false>(S, o, d, cnt);
+            const Hit h = query<false, FAST>(S, o, d, cnt, fast_column(bounce_stack, S.max_bounces));
             rthip_ray_record r;
             r.origin[0] = o.x, r.origin[1] = o.y, r.origin[2] = o.z;
             r.direction[0] = d.x, r.direction[1] = d.y, r.direction[2] = d.z;
@@ -444,9 +486,10 @@ __global__ __launch_bounds__(kBlock) void records_compact_kernel(const rthip_ray
     for (uint32_t k = 0; k < end - begin; k++) out[begin + k] = slots[path * max_bounces + k];
 }
 
-template <bool COUNT>
+template <bool COUNT, bool FAST = false>
 __global__ __launch_bounds__(kBlock) void primary_hits_kernel(DevScene S, rthip_cast_settings c, int width, int height,
                                                               uint32_t* __restrict__ hits4, uint64_t* counters) {
+    extern __shared__ uint32_t fast_lds[];  // FAST: kFastLds entries per lane
     int x, y;
     const bool inside = pixel_of_thread(width, height, x, y);
     Counters cnt = {0, 0, 0, 0};
@@ -458,7 +501,7 @@ __global__ __launch_bounds__(kBlock) void primary_hits_kernel(DevScene S, rthip_
         V3 o, d;
         camera_ray(c1, width, height, x, y, 0, 0, false, g, o, d);
         rays = 1;
-        const Hit h = closest_hit_query<COUNT>(S, o, d, cnt);
+        const Hit h = query<COUNT, FAST>(S, o, d, cnt, fast_lds + threadIdx.x);
         uint32_t* r = hits4 + 4 * ((size_t)y * width + x);
         r[0] = h.inst;
         r[1] = h.inst ? h.tri : 0u;
@@ -491,11 +534,12 @@ __device__ __forceinline__ void write_ray_result(const DevScene& S, uint64_t i, 
     }
 }
 
-template <bool COUNT>
+template <bool COUNT, bool FAST = false>
 __global__ __launch_bounds__(kBlock) void trace_rays_kernel(DevScene S, const float* __restrict__ ro,
                                                             const float* __restrict__ rd, uint64_t n,
                                                             uint32_t* __restrict__ hits4, float* __restrict__ uv,
                                                             float* __restrict__ normal, uint64_t* counters) {
+    extern __shared__ uint32_t fast_lds[];  // FAST: kFastLds entries per lane
     const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     Counters cnt = {0, 0, 0, 0};
     uint32_t rays = 0;
@@ -503,7 +547,7 @@ __global__ __launch_bounds__(kBlock) void trace_rays_kernel(DevScene S, const fl
         const V3 o = mk(ro[3 * i], ro[3 * i + 1], ro[3 * i + 2]);
         const V3 d = mk(rd[3 * i], rd[3 * i + 1], rd[3 * i + 2]);
         rays = 1;
-        const Hit h = closest_hit_query<COUNT>(S, o, d, cnt);
+        const Hit h = query<COUNT, FAST>(S, o, d, cnt, fast_lds + threadIdx.x);
         write_ray_result(S, i, h, o, d, hits4, uv, normal);
     }
     if (COUNT) flush_counters(counters, cnt, rays);
@@ -515,13 +559,14 @@ __global__ __launch_bounds__(kBlock) void trace_rays_kernel(DevScene S, const fl
 // and prefix count; it goes back for rays whenever `refill` lanes are idle.
 constexpr uint32_t kRayGrab = 1024;
 
-template <bool COUNT>
+template <bool COUNT, bool FAST = false>
 __global__ __launch_bounds__(kBlock) void trace_rays_persistent_kernel(DevScene S, const float* __restrict__ ro,
                                                                        const float* __restrict__ rd, uint64_t n,
                                                                        uint32_t* __restrict__ hits4,
                                                                        float* __restrict__ uv, float* __restrict__ normal,
                                                                        uint32_t* work_counter, uint32_t refill,
                                                                        uint64_t* counters) {
+    extern __shared__ uint32_t fast_lds[];  // FAST: kFastLds entries per lane
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     Counters cnt = {0, 0, 0, 0};
@@ -530,8 +575,9 @@ __global__ __launch_bounds__(kBlock) void trace_rays_persistent_kernel(DevScene 
     bool exhausted = false;         // wave-uniform: the stream has no rays left to reserve
     bool active = false;
     uint64_t ray = 0;
-    Trav T;
-    trav_begin(T, S, mk(0.f, 0.f, 0.f), mk(0.f, 0.f, 1.f));
+    Walk<FAST> Wk;
+    Wk.init(fast_lds + threadIdx.x);
+    Wk.begin(S, mk(0.f, 0.f, 0.f), mk(0.f, 0.f, 1.f));
 
     for (;;) {
         uint64_t idle = __ballot(!active);
@@ -553,8 +599,8 @@ __global__ __launch_bounds__(kBlock) void trace_rays_persistent_kernel(DevScene 
             const uint32_t my_rank = (uint32_t)__popcll(idle & lt_mask);
             if (!active && my_rank < take) {
                 ray = cur + my_rank;
-                trav_begin(T, S, mk(ro[3 * ray], ro[3 * ray + 1], ro[3 * ray + 2]),
-                           mk(rd[3 * ray], rd[3 * ray + 1], rd[3 * ray + 2]));
+                Wk.begin(S, mk(ro[3 * ray], ro[3 * ray + 1], ro[3 * ray + 2]),
+                         mk(rd[3 * ray], rd[3 * ray + 1], rd[3 * ray + 2]));
                 active = true;
                 rays++;
             }
@@ -567,8 +613,8 @@ __global__ __launch_bounds__(kBlock) void trace_rays_persistent_kernel(DevScene 
                 const uint64_t walking = __ballot(active);
                 if ((int)lane == __ffsll((long long)walking) - 1) cnt.wave_steps++;
             }
-            if (active && trav_step<COUNT>(T, S, cnt)) {
-                write_ray_result(S, ray, T.h, T.wo, T.wd, hits4, uv, normal);
+            if (active && Wk.template step<COUNT, false>(S, cnt)) {
+                write_ray_result(S, ray, Wk.T.h, Wk.T.wo, Wk.T.wd, hits4, uv, normal);
                 active = false;
             }
             const uint32_t n_idle = (uint32_t)__popcll(__ballot(!active));
@@ -579,10 +625,11 @@ __global__ __launch_bounds__(kBlock) void trace_rays_persistent_kernel(DevScene 
     if (COUNT) flush_counters(counters, cnt, rays);
 }
 
-template <bool COUNT>
+template <bool COUNT, bool FAST = false>
 __global__ __launch_bounds__(kBlock) void occlusion_kernel(DevScene S, const float* __restrict__ ro,
                                                            const float* __restrict__ rd, uint64_t n, float tmax,
                                                            uint8_t* __restrict__ out, uint64_t* counters) {
+    extern __shared__ uint32_t fast_lds[];  // FAST: kFastLds entries per lane
     const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     Counters cnt = {0, 0, 0, 0};
     uint32_t rays = 0;
@@ -590,12 +637,17 @@ __global__ __launch_bounds__(kBlock) void occlusion_kernel(DevScene S, const flo
         const V3 o = mk(ro[3 * i], ro[3 * i + 1], ro[3 * i + 2]);
         const V3 d = mk(rd[3 * i], rd[3 * i + 1], rd[3 * i + 2]);
         rays = 1;
-        out[i] = any_hit_query<COUNT>(S, o, d, tmax, cnt) ? 1 : 0;
+        bool hit;
+        if constexpr (FAST) hit = any_hit_query_fast<COUNT>(S, o, d, tmax, cnt, fast_lds + threadIdx.x);
+        else hit = any_hit_query<COUNT>(S, o, d, tmax, cnt);
+        out[i] = hit ? 1 : 0;
     }
     if (COUNT) flush_counters(counters, cnt, rays);
 }
 
 inline uint32_t div_up(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+
+constexpr size_t kFastLdsBytes = (size_t)kFastLds * kBlock * sizeof(uint32_t);  // the ordered walk's LDS stack per workgroup
 
 }  // namespace
 
@@ -636,6 +688,7 @@ int work_slot_launched(rthip_ctx* ctx, int slot, hipStream_t stream) {
 int trace_rays_launch(rthip_ctx* ctx, const DevScene& scene, const float* d_o, const float* d_d, uint64_t n,
                       uint32_t* d_hits4, float* d_uv, float* d_normal, uint64_t* d_counters, hipStream_t stream) {
     if (n == 0) return RTHIP_OK;
+    const bool fast = ctx->traversal == RTHIP_TRAV_FAST;
     // Long streams over a scene that the caches can hold: resident waves with lane refill.  Once the
     // scene is larger than the Infinity Cache the walk is bound by HBM line fetches, not by idle lanes,
     // and the plain kernel (fewer registers, more waves) is the faster one.
@@ -647,20 +700,32 @@ int trace_rays_launch(rthip_ctx* ctx, const DevScene& scene, const float* d_o, c
         uint32_t* work = nullptr;  // a slot of zeroed counters: see work_slot_release
         int slot = -1;
         RT_TRY(work_slot_take(ctx, stream, &work, &slot));
-        if (d_counters)
-            trace_rays_persistent_kernel<true><<<blocks, kBlock, 0, stream>>>(scene, d_o, d_d, n, d_hits4, d_uv, d_normal,
-                                                                             work, ctx->refill_lanes, d_counters);
-        else
-            trace_rays_persistent_kernel<false><<<blocks, kBlock, 0, stream>>>(scene, d_o, d_d, n, d_hits4, d_uv, d_normal,
-                                                                              work, ctx->refill_lanes, nullptr);
+#define RT_LAUNCH_RAYS_P(COUNT, FAST, CNT)                                                                              \
+    trace_rays_persistent_kernel<COUNT, FAST><<<blocks, kBlock, (FAST) ? kFastLdsBytes : 0, stream>>>(                  \
+        scene, d_o, d_d, n, d_hits4, d_uv, d_normal, work, ctx->refill_lanes, CNT)
+        if (fast) {
+            if (d_counters) RT_LAUNCH_RAYS_P(true, true, d_counters);
+            else RT_LAUNCH_RAYS_P(false, true, nullptr);
+        } else {
+            if (d_counters) RT_LAUNCH_RAYS_P(true, false, d_counters);
+            else RT_LAUNCH_RAYS_P(false, false, nullptr);
+        }
+#undef RT_LAUNCH_RAYS_P
         RT_HIP(ctx, hipGetLastError());
         return work_slot_launched(ctx, slot, stream);
     }
     const uint32_t blocks = div_up(n, kBlock);
-    if (d_counters)
-        trace_rays_kernel<true><<<blocks, kBlock, 0, stream>>>(scene, d_o, d_d, n, d_hits4, d_uv, d_normal, d_counters);
-    else
-        trace_rays_kernel<false><<<blocks, kBlock, 0, stream>>>(scene, d_o, d_d, n, d_hits4, d_uv, d_normal, nullptr);
+#define RT_LAUNCH_RAYS(COUNT, FAST, CNT)                                                                                \
+    trace_rays_kernel<COUNT, FAST><<<blocks, kBlock, (FAST) ? kFastLdsBytes : 0, stream>>>(scene, d_o, d_d, n, d_hits4, d_uv, \
+                                                                                          d_normal, CNT)
+    if (fast) {
+        if (d_counters) RT_LAUNCH_RAYS(true, true, d_counters);
+        else RT_LAUNCH_RAYS(false, true, nullptr);
+    } else {
+        if (d_counters) RT_LAUNCH_RAYS(true, false, d_counters);
+        else RT_LAUNCH_RAYS(false, false, nullptr);
+    }
+#undef RT_LAUNCH_RAYS
     RT_HIP(ctx, hipGetLastError());
     return RTHIP_OK;
 }
@@ -669,7 +734,12 @@ int occlusion_launch(rthip_ctx* ctx, const DevScene& scene, const float* d_o, co
                      uint8_t* d_out, uint64_t* d_counters, hipStream_t stream) {
     if (n == 0) return RTHIP_OK;
     const uint32_t blocks = div_up(n, kBlock);
-    if (d_counters)
+    if (ctx->traversal == RTHIP_TRAV_FAST) {
+        if (d_counters)
+            occlusion_kernel<true, true><<<blocks, kBlock, kFastLdsBytes, stream>>>(scene, d_o, d_d, n, tmax, d_out, d_counters);
+        else
+            occlusion_kernel<false, true><<<blocks, kBlock, kFastLdsBytes, stream>>>(scene, d_o, d_d, n, tmax, d_out, nullptr);
+    } else if (d_counters)
         occlusion_kernel<true><<<blocks, kBlock, 0, stream>>>(scene, d_o, d_d, n, tmax, d_out, d_counters);
     else
         occlusion_kernel<false><<<blocks, kBlock, 0, stream>>>(scene, d_o, d_d, n, tmax, d_out, nullptr);
@@ -680,7 +750,12 @@ int occlusion_launch(rthip_ctx* ctx, const DevScene& scene, const float* d_o, co
 int primary_hits_launch(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_settings& cast, int width, int height,
                         uint32_t* d_hits4, uint64_t* d_counters, hipStream_t stream) {
     const uint32_t blocks = div_up(width, 16) * div_up(height, 16);
-    if (d_counters)
+    if (ctx->traversal == RTHIP_TRAV_FAST) {
+        if (d_counters)
+            primary_hits_kernel<true, true><<<blocks, kBlock, kFastLdsBytes, stream>>>(scene, cast, width, height, d_hits4, d_counters);
+        else
+            primary_hits_kernel<false, true><<<blocks, kBlock, kFastLdsBytes, stream>>>(scene, cast, width, height, d_hits4, nullptr);
+    } else if (d_counters)
         primary_hits_kernel<true><<<blocks, kBlock, 0, stream>>>(scene, cast, width, height, d_hits4, d_counters);
     else
         primary_hits_kernel<false><<<blocks, kBlock, 0, stream>>>(scene, cast, width, height, d_hits4, nullptr);
@@ -694,7 +769,10 @@ int cast_records_launch(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_
     const uint64_t n_paths = (uint64_t)width * height * cast.samples * cast.samples;
     const size_t lds = (size_t)(scene.max_bounces ? scene.max_bounces : 1) * kBlock * sizeof(uint32_t);
     const uint32_t blocks = div_up(n_paths, kBlock);
-    cast_records_kernel<<<blocks, kBlock, lds, stream>>>(scene, cast, seed, width, height, d_slots, d_counts);
+    if (ctx->traversal == RTHIP_TRAV_FAST)
+        cast_records_kernel<true><<<blocks, kBlock, lds + kFastLdsBytes, stream>>>(scene, cast, seed, width, height, d_slots, d_counts);
+    else
+        cast_records_kernel<false><<<blocks, kBlock, lds, stream>>>(scene, cast, seed, width, height, d_slots, d_counts);
     RT_HIP(ctx, hipGetLastError());
     RT_TRY(scan_inclusive_u32_device(ctx, d_counts, n_paths, stream));
     uint32_t total = 0;
@@ -714,6 +792,14 @@ int launch_static(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_settin
                   int width, int height, rthip_shard shard, uint64_t* d_counters, hipStream_t stream, uint32_t ib = 0) {
     const size_t lds = (size_t)(scene.max_bounces ? scene.max_bounces : 1) * kBlock * sizeof(uint32_t);
     const uint32_t blocks = div_up(width, 16) * div_up(height, 16);
+    if (ctx->traversal == RTHIP_TRAV_FAST) {
+        if (d_counters)
+            cast_static_kernel<true, false, true><<<blocks, kBlock, lds + kFastLdsBytes, stream>>>(scene, cast, seed, d_rgb, width, height, shard, ctx->cast_accumulate, d_counters);
+        else
+            cast_static_kernel<false, false, true><<<blocks, kBlock, lds + kFastLdsBytes, stream>>>(scene, cast, seed, d_rgb, width, height, shard, ctx->cast_accumulate, nullptr);
+        RT_HIP(ctx, hipGetLastError());
+        return RTHIP_OK;
+    }
     // ib != 0: the instance entries of a wave run in batches (closest_hit_query_batched; entry_batch decides)
     if (ib) {
         if (d_counters)
@@ -739,7 +825,12 @@ int launch_samples(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_setti
 #define RT_LAUNCH_SAMPLES(COUNT, BATCH, CNT)                                                                               \
     cast_samples_kernel<COUNT, BATCH><<<blocks, kBlock, lds, stream>>>(scene, cast, seed, d_rgb, width, height, shard, log2_group, \
                                                                        ctx->cast_accumulate, CNT, ib)
-    if (d_counters) {
+    if (ctx->traversal == RTHIP_TRAV_FAST) {
+        if (d_counters)
+            cast_samples_kernel<true, false, true><<<blocks, kBlock, lds + kFastLdsBytes, stream>>>(scene, cast, seed, d_rgb, width, height, shard, log2_group, ctx->cast_accumulate, d_counters, 0u);
+        else
+            cast_samples_kernel<false, false, true><<<blocks, kBlock, lds + kFastLdsBytes, stream>>>(scene, cast, seed, d_rgb, width, height, shard, log2_group, ctx->cast_accumulate, nullptr, 0u);
+    } else if (d_counters) {
         if (ib) RT_LAUNCH_SAMPLES(true, true, d_counters);
         else RT_LAUNCH_SAMPLES(true, false, d_counters);
     } else {
@@ -769,7 +860,12 @@ int launch_persistent(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_se
 #define RT_LAUNCH_CAST(COUNT, DEFER, CNT)                                                                              \
     cast_kernel<COUNT, DEFER><<<blocks, kBlock, lds, stream>>>(scene, cast, seed, d_rgb, width, height, shard, work, \
                                                                refill, inst_batch, ctx->cast_accumulate, CNT)
-    if (d_counters) {
+    if (ctx->traversal == RTHIP_TRAV_FAST) {
+        if (d_counters)
+            cast_kernel<true, false, true><<<blocks, kBlock, lds + kFastLdsBytes, stream>>>(scene, cast, seed, d_rgb, width, height, shard, work, refill, 0u, ctx->cast_accumulate, d_counters);
+        else
+            cast_kernel<false, false, true><<<blocks, kBlock, lds + kFastLdsBytes, stream>>>(scene, cast, seed, d_rgb, width, height, shard, work, refill, 0u, ctx->cast_accumulate, nullptr);
+    } else if (d_counters) {
         if (defer) RT_LAUNCH_CAST(true, true, d_counters);
         else RT_LAUNCH_CAST(true, false, d_counters);
     } else {
@@ -905,9 +1001,11 @@ int entry_batch(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_settings
 int cast_launch(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_settings& cast, uint64_t seed, float* d_rgb,
                 int width, int height, rthip_shard shard, uint64_t* d_counters, hipStream_t stream) {
     ctx->last_cast_kernel = 2;
-    if (ctx->cast_mode == 2)
+    const bool fast = ctx->traversal == RTHIP_TRAV_FAST;
+    if (ctx->cast_mode == 2 && !fast)
         return cast_wavefront_launch(ctx, scene, cast, seed, d_rgb, width, height, shard, d_counters, stream);
-    Candidate choice = {ctx->cast_mode, ctx->refill_lanes, ctx->inst_batch};
+    // the wavefront renderer has no ordered walk: in that mode its name selects the persistent kernel
+    Candidate choice = {ctx->cast_mode == 2 ? 0 : ctx->cast_mode, ctx->refill_lanes, ctx->inst_batch};
     // One lane per sample needs samples^2 = 4, 16 or 64.  Measured against the other two kernels over frame sizes
     // (tools/probe_samples.py): never slower than the pixel-per-thread kernel (its waves are shorter and the samples of
     // a pixel walk the same part of the tree), 1.2x (Cornell 512^2) to 7x (256^2 frames of deep scenes) faster on
@@ -917,7 +1015,12 @@ int cast_launch(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_settings
     const bool deep = ctx->n_inst >= 64u || ctx->total_tris >= (1ull << 20);
     const uint64_t pixel_waves = (uint64_t)div_up(width, 8) * div_up(height, 8);
     if (choice.kernel == 4 && !by_samples_possible) choice.kernel = 1;
-    if (ctx->cast_mode == 3 && by_samples_possible && pixel_waves < (deep ? 20480ull : 40000ull)) {
+    if (ctx->cast_mode == 3 && fast) {
+        // The ordered walk's paths are shorter and more alike, and its step is longer: measured at 1920x1080, the
+        // pixel- / sample-per-lane kernels beat the persistent one on every workload (10 M-triangle soup 554 vs 415,
+        // 10 000 instances 805 vs 726, bunny-class 7508 vs 4758 Mrays/s), so no probe is needed.
+        choice.kernel = by_samples_possible ? 4 : 1;
+    } else if (ctx->cast_mode == 3 && by_samples_possible && pixel_waves < (deep ? 20480ull : 40000ull)) {
         choice.kernel = 4;
     } else if (ctx->cast_mode == 3) {
         const uint64_t spp = (uint64_t)cast.samples * cast.samples;
@@ -951,7 +1054,7 @@ int cast_launch(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_settings
     ctx->last_cast_kernel = (uint32_t)choice.kernel;
     ctx->last_cast_refill = choice.kernel == 0 ? choice.refill : 0u;
     uint32_t ib = 0;
-    if (choice.kernel == 4 || choice.kernel == 1) RT_TRY(entry_batch(ctx, scene, cast, seed, d_rgb, width, height, shard, stream, &ib));
+    if (!fast && (choice.kernel == 4 || choice.kernel == 1)) RT_TRY(entry_batch(ctx, scene, cast, seed, d_rgb, width, height, shard, stream, &ib));
     if (choice.kernel == 4) return launch_samples(ctx, scene, cast, seed, d_rgb, width, height, shard, d_counters, stream, ib);
     if (choice.kernel == 1) return launch_static(ctx, scene, cast, seed, d_rgb, width, height, shard, d_counters, stream, ib);
     return launch_persistent(ctx, scene, cast, seed, d_rgb, width, height, shard, choice.refill, choice.inst_batch, d_counters,

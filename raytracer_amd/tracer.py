@@ -281,3 +281,12 @@ def host_alloc(tracer: RT_Tracer, shape, dtype=np.float32) -> np.ndarray:
 
 def host_free(tracer: RT_Tracer, a: np.ndarray) -> None:
     tracer.check(tracer.lib.rthip_host_free(tracer.h, a.ctypes.data), "rthip_host_free")
+
+
+TRAVERSALS = {"exact": 0, "fast": 1}
+
+
+def set_traversal(tracer: RT_Tracer, mode: str) -> None:
+    """"exact": the reference's fixed left-before-right walk (default, bit-identical results); "fast": nearer child
+    first with a per-lane stack (see include/rthip.h at rthip_set_traversal)."""
+    tracer.check(tracer.lib.rthip_set_traversal(tracer.h, TRAVERSALS[mode]), "rthip_set_traversal")

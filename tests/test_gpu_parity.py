@@ -739,7 +739,16 @@ def test_ten_million_triangle_soup_incoherent_rays(oracle, gpu_tracer):
         m = 1 << 16
         head, st = run(m, counting=True)
         assert torch.equal(head, plain[:m])
+        # the opt-in ordered walk on the same stream: the same distance bit for bit on every ray; another primitive only
+        # where two lie at exactly that distance (the reference reports the last one it visits); a third fewer box tests
+        T.set_traversal(gpu_tracer, "fast")
+        fast, fst = run(n, counting=True)
+        assert torch.equal(fast[:, 2], plain[:, 2]), f"{int((fast[:, 2] != plain[:, 2]).sum())} rays at another distance"
+        other = int(((fast[:, 0] != plain[:, 0]) | (fast[:, 1] != plain[:, 1])).sum())
+        assert other <= 8, f"{other} rays report another primitive"
+        assert fst["nodes_tested"] < 0.85 * 651.87 * n
     finally:
+        T.set_traversal(gpu_tracer, "exact")
         T.set_cast_kernel(gpu_tracer, "auto")
     sc = oracle.Scene(flat, 1, sky)
     oi, ot, ott, _, _, cnt = sc.trace(o[:m].cpu().numpy(), d[:m].cpu().numpy(), threads=8, want_normal=False)
@@ -761,6 +770,134 @@ def test_ten_million_triangle_soup_incoherent_rays(oracle, gpu_tracer):
             assert (bits(img) == bits(want)).all(), kernel
     finally:
         T.set_cast_kernel(gpu_tracer, "auto")
+
+
+def fast_vs_exact_rays(gpu_tracer, o, d):
+    """(rays at another distance, rays with another primitive at the same distance, hit-versus-miss rays) between the
+    two walks, and both result sets."""
+    T.set_traversal(gpu_tracer, "exact")
+    a = T.trace_rays(gpu_tracer, o, d)
+    T.set_traversal(gpu_tracer, "fast")
+    try:
+        b = T.trace_rays(gpu_tracer, o, d)
+    finally:
+        T.set_traversal(gpu_tracer, "exact")
+    t_differs = bits(a[2]) != bits(b[2])
+    prim_differs = (a[0] != b[0]) | (a[1] != b[1])
+    return int(t_differs.sum()), int((prim_differs & ~t_differs).sum()), int(((a[0] != 0) != (b[0] != 0)).sum()), a, b
+
+
+def test_fast_traversal_against_the_exact_walk(oracle, gpu_tracer):
+    """RTHIP_TRAV_FAST (nearer child first, stack in LDS) against the reference's walk.  Pinned: on the reference's own
+    scenes every primary ray gets the same primitive at the same distance; on incoherent rays through deep scenes the
+    distance is equal bit for bit and at most a handful of rays report another primitive at that same distance."""
+    g = golden("demo_cornell")
+    w, cam, sky = scenes.cornell()
+    build(gpu_tracer, w, 8, sky)
+    o, d = oracle.primary_rays(cam(512, 512, 1), 512, 512)
+    assert fast_vs_exact_rays(gpu_tracer, o, d)[:3] == (0, 0, 0)
+    T.set_traversal(gpu_tracer, "fast")
+    try:
+        inst, tri, t = T.primary_hits(gpu_tracer, cam(512, 512, 1), 512, 512)  # the reference's 512^2 answers, seam rays included
+        assert hashlib.sha256(inst.tobytes()).hexdigest() == str(g["ref_512_inst_sha"])
+        assert hashlib.sha256(tri.tobytes()).hexdigest() == str(g["ref_512_tri_sha"])
+        assert hashlib.sha256(t.tobytes()).hexdigest() == str(g["ref_512_t_sha"])
+        # whole frames: every kernel renders the fast walk's image, and on Cornell that is the exact walk's image
+        c = cam(96, 80, 2)
+        want, _ = oracle.Scene(world.flatten_world(w), 8, sky).cast(c, 4, 96, 80, rng_mode=oracle.RNG_COUNTER, threads=8)
+        for kernel in ("static", "static-samples", "persistent", "wavefront", "auto"):
+            T.set_cast_kernel(gpu_tracer, kernel)
+            img = np.zeros((80, 96, 3), dtype=np.float32)
+            T.rt_tracer_cast(gpu_tracer, c, img, 96, 80, seed=4)
+            assert (bits(img) == bits(want)).all(), kernel
+    finally:
+        T.set_cast_kernel(gpu_tracer, "auto")
+        T.set_traversal(gpu_tracer, "exact")
+    for name in ("tri", "spheres"):
+        w, cam, sky = DEMOS[name]()
+        build(gpu_tracer, w, 8, sky)
+        gd = golden("demo_" + name)
+        assert fast_vs_exact_rays(gpu_tracer, gd["rays_o"], gd["rays_d"])[:3] == (0, 0, 0), name
+    # bunny-class mesh, 1920x1080 primary rays: the reference's answers
+    gb = golden("demo_bunny_class")
+    verts, indices = scenes.bunny_class_mesh()
+    w, cam, sky = scenes.bunny(verts, indices)
+    build(gpu_tracer, w, 2, sky)
+    T.set_traversal(gpu_tracer, "fast")
+    try:
+        inst, tri, t = T.primary_hits(gpu_tracer, cam(1920, 1080, 1), 1920, 1080)
+        assert hashlib.sha256(inst.tobytes()).hexdigest() == str(gb["ref_1080_inst_sha"])
+        assert hashlib.sha256(tri.tobytes()).hexdigest() == str(gb["ref_1080_tri_sha"])
+        assert hashlib.sha256(t.tobytes()).hexdigest() == str(gb["ref_1080_t_sha"])
+    finally:
+        T.set_traversal(gpu_tracer, "exact")
+    # instances (rotated, scaled) and a soup, incoherent rays, occlusion, animated TLAS rebuilds while in fast mode
+    verts, indices = scenes.bunny_class_mesh(3)
+    w, cam, sky = scenes.instanced_grid(12, seed=1, verts=verts, indices=indices)
+    build(gpu_tracer, w, 4, sky)
+    o, d = scenes.random_rays(200_000, seed=3, lo=(-15, -2, -15), hi=(15, 3, 15))
+    t_diff, prim_diff, hit_miss, a, b = fast_vs_exact_rays(gpu_tracer, o, d)
+    assert t_diff == 0 and hit_miss == 0 and prim_diff <= 2, (t_diff, prim_diff, hit_miss)
+    same = (a[0] == b[0]) & (a[1] == b[1])
+    assert (bits(a[3]) == bits(b[3]))[same].all() and (bits(a[4]) == bits(b[4]))[same].all()  # uv and normals
+    occ = T.occluded(gpu_tracer, o, d, 3.0)
+    T.set_traversal(gpu_tracer, "fast")
+    try:
+        assert int((T.occluded(gpu_tracer, o, d, 3.0) != occ).sum()) == 0
+        T.rt_tracer_build_tlas(gpu_tracer, w)  # a rebuild in fast mode makes its records too
+        assert (T.trace_rays(gpu_tracer, o, d)[0] == b[0]).all()
+    finally:
+        T.set_traversal(gpu_tracer, "exact")
+    w, cam, sky = scenes.soup_world(200_000, seed=1)
+    build(gpu_tracer, w, 4, sky)
+    o, d = scenes.random_rays(100_000, seed=2)
+    t_diff, prim_diff, hit_miss, a, b = fast_vs_exact_rays(gpu_tracer, o, d)
+    assert t_diff == 0 and hit_miss == 0 and prim_diff <= 2, (t_diff, prim_diff, hit_miss)
+    with pytest.raises(T.RTHipError):
+        gpu_tracer.check(gpu_tracer.lib.rthip_set_traversal(gpu_tracer.h, 7), "rthip_set_traversal")
+
+
+def test_fast_traversal_on_a_tree_deeper_than_its_stack(gpu_tracer):
+    """Sixty large triangles, each with a centroid coordinate half the previous one's, make a radix tree about sixty
+    levels deep whose boxes a ray pierces all at once: it wants more stack than the ordered walk keeps (24 entries), and
+    such a ray is answered by the stackless walk.  Most of the triangles lie in one plane, so which of them is reported
+    is a tie; the distance is not."""
+    tris = []
+    for j in range(1, 21):
+        dlt = 0.5 ** j
+        for axis in range(3):
+            xmax = 3 + 2 * dlt if axis == 0 else 3.0
+            ymax = 3 + 2 * dlt if axis == 1 else 3.0
+            z = dlt if axis == 2 else 0.0
+            tris.append([[-3, -3, z], [xmax, -3, z], [-3, ymax, z]])
+    v = np.zeros((180, 4), dtype=np.float32)
+    v[:, :3] = np.array(tris, dtype=np.float32).reshape(180, 3)
+    w = world.rt_make_world()
+    m = world.rt_world_add_mesh(w)
+    scenes._set_mesh(m, v, None, scenes.GEO_P)
+    mat = world.rt_world_add_material(w)
+    mat.type, mat.albedo = abi.MAT_LAMBERTIAN, scenes.v3(0.5, 0.5, 0.5)
+    it = world.rt_world_add_instance(w)
+    it.type, it.material, it.mesh = abi.INST_MESH, mat, m
+    it.translation, it.rotation, it.scale = scenes.v3(0, 0, 0), scenes.IDENTITY_QUAT, scenes.v3(1, 1, 1)
+    build(gpu_tracer, w, 2, True)
+    nodes = T.get_tree(gpu_tracer, 0)
+    depth, open_until = 0, []
+    for i in range(nodes.shape[0]):
+        while open_until and open_until[-1] <= i:
+            open_until.pop()
+        depth = max(depth, len(open_until))
+        open_until.append(int(nodes["skip"][i]))
+    assert depth >= 40, depth
+    rng = np.random.default_rng(1)
+    n = 4096
+    o = np.concatenate([rng.uniform(-2.5, -1.5, (n, 2)), np.full((n, 1), 3.0)], axis=1).astype(np.float32)
+    d = np.tile(np.array([[0.0, 0.0, -1.0]], dtype=np.float32), (n, 1))
+    d[n // 2:, 2] = 1.0  # half of them from behind
+    o[n // 2:, 2] = -3.0
+    t_diff, prim_diff, hit_miss, a, b = fast_vs_exact_rays(gpu_tracer, o, d)
+    assert (t_diff, hit_miss) == (0, 0) and int((a[0] != 0).sum()) == n
+    assert np.allclose(a[2][: n // 2], 2.5, rtol=1e-6) and np.allclose(a[2][n // 2:], 3.0, rtol=1e-6)
 
 
 def test_occlusion_rays(oracle, gpu_tracer):
