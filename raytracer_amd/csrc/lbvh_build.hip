@@ -206,9 +206,11 @@ __device__ __forceinline__ uint32_t morton_axis(float c, float mn, float ext) {
 
 __global__ __launch_bounds__(kBlock) void morton_kernel(const float* __restrict__ aabb6, uint64_t n,
                                                         const uint32_t* __restrict__ bounds,
-                                                        uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+                                                        uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                                                        uint32_t* __restrict__ zero) {
     uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
+    if (zero) zero[i] = 0u;  // the climbs' arrival counters, cleared on the way (one launch fewer)
     float mn[3], ext[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
@@ -223,7 +225,7 @@ __global__ __launch_bounds__(kBlock) void morton_kernel(const float* __restrict_
         code |= spread21(morton_axis(c, mn[k], ext[k])) << k;
     }
     keys[i] = code;
-    vals[i] = (uint32_t)i;
+    if (vals) vals[i] = (uint32_t)i;  // the sort's first pass takes positions as values by itself
 }
 
 // ---- K3: LSD radix sort, 8 bits per pass, stable ---------------------------------------
@@ -405,7 +407,7 @@ __global__ __launch_bounds__(kSortBlock) void radix_scatter_kernel(const uint64_
         uint32_t pos = bin_start[d] + wave_cnt[wave][d] + rank[j];
         uint64_t i = wbase + (uint64_t)j * 64 + lane;
         skeys[pos] = key[j];
-        svals[pos] = (i < n) ? vals_in[i] : 0u;
+        svals[pos] = (i < n) ? (vals_in ? vals_in[i] : (uint32_t)i) : 0u;
     }
     __syncthreads();
 
@@ -515,47 +517,47 @@ __device__ __forceinline__ uint8_t gap_priority_of(const uint64_t* keys, uint64_
     return (uint8_t)(64u + depth);
 }
 
-__global__ __launch_bounds__(kBlock) void gap_priority_kernel(const uint64_t* __restrict__ keys, uint64_t n,
-                                                              uint8_t* __restrict__ prio) {
-    uint64_t g = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (g + 1 >= n) return;
-    prio[g] = gap_priority_of(keys, n, g);
-}
-
 // ---- K5 + K6: hierarchy emission with box refit ------------------------------------------
-// lbvh_create_subtree, lbvh.c:44-72, bottom-up.  A child leaves its record in its parent's
-// slot and bumps the parent's arrival counter; the second child to arrive reads its
-// sibling's record, merges (merge_rng3_f32(left, right), lbvh.c:58), records the finished node
-// and walks on.  Nobody ever waits for anybody.
+// lbvh_create_subtree, lbvh.c:44-72, bottom-up, in two climbs of the same shape.
 //
-// Two kernels.  hierarchy_local_kernel: a workgroup owns kChunk consecutive sorted leaves, one
-// per thread.  A gap whose node lies entirely inside the chunk (it is bounded on both sides,
-// inside the chunk, by gaps of smaller priority) is "local": both of its children are produced
-// by this workgroup, so their hand-off goes through LDS.  A thread that reaches a parent that
-// is not local stores its record in HBM, counts itself at the parent (+1) and is done.
-// hierarchy_upper_kernel finishes the nodes that span chunks (a few per cent of all): one
-// thread per gap; the gaps whose two children both arrived in the first kernel start climbing,
-// with the hand-off through HBM (MODE 0, the default): the record is written with device-scope
-// stores, the counter add (+16, so the starting condition "two arrivals from the first kernel"
-// stays readable) is a device-scope release read-modify-write, and the second child to arrive
-// passes a device-scope acquire fence before it reads the sibling's record -- a release /
-// acquire pair through the counter in the HIP memory model (the first child to arrive reads
-// nothing and needs no acquire).  MODE 1 (RTHIP_REFIT_FENCE=1, diagnostic): plain accesses bracketed by
-// __threadfence().  MODE 2 (RTHIP_REFIT_FENCE=2): relaxed accesses ordered only by draining the
-// wave's stores (s_waitcnt vmcnt(0)) before a relaxed add; correct on gfx950, where device-scope
-// stores write through, but not by the memory model -- kept to measure what the model costs.
+// The climb: one thread per sorted leaf.  A node is identified by its leaf range [l, r]; its parent is the gap that
+// bounds the range with the larger priority.  A child leaves a record in its parent's slot and bumps the parent's
+// arrival counter; the second child to arrive reads its sibling's record, becomes the parent and walks on.  Nobody
+// ever waits for anybody.
+//
+// First climb (topology, no boxes): records hold {far end of the range, left-spine length}.  It yields the length of
+// the left spine that starts at every leaf (cnt_l), whose prefix sum gives every node its pre-order index:
+// leaf i sits at i + S(i), the inner node with range [l, r] and `dl` left edges below it at l + S(l) - dl.
+// Second climb (boxes): the same walk with the boxes merged on the way (merge_rng3_f32(left, right), lbvh.c:58); every
+// node's final 32-byte record goes straight to its pre-order place: no intermediate node arrays, no layout pass.
+//
+// Each climb is two kernels.  *_local: a workgroup owns kChunk consecutive sorted leaves.  A gap whose node lies
+// entirely inside the chunk (it is bounded on both sides, inside the chunk, by gaps of smaller priority) is "local":
+// both of its children are produced by this workgroup, so their hand-off goes through LDS.  A thread that reaches a
+// parent that is not local stores its record in HBM, counts itself at the parent and is done.  *_upper finishes the
+// nodes that span chunks (a few per cent of all): one thread per gap whose two children both arrived in the local
+// kernel (the second child to be counted there puts the gap on a list), hand-offs through HBM.
+//
+// Hand-offs through HBM (upper kernels).  Every access to a record and to the counter is a device-scope atomic, so
+// what the hand-off needs beyond per-location coherence is ORDER: record before count, count before the sibling's
+// record.  MODE 2 (the default): the wave drains its record stores (s_waitcnt vmcnt(0): device-scope stores are
+// acknowledged once they are visible device-wide on gfx950) before a relaxed counter add, and reads the sibling after
+// the add has returned; the asm statement is a compiler barrier as well.  That is the hardware's ordering, not one the
+// HIP memory model promises for relaxed atomics.  MODE 0 (RTHIP_REFIT_FENCE=0) is the model's own form: a device-
+// scope release read-modify-write on the counter, and an acquire fence before the second child to arrive reads the
+// sibling's record (the first reads nothing).  Same trees bit for bit (tests run all three); its release writes the
+// L2 back and its acquire invalidates it at every level of a latency-bound chain: measured 2.15 ms instead of 1.84 ms
+// for 10^7 triangles, 0.25 / 0.23 ms for 81 920.  MODE 1 (RTHIP_REFIT_FENCE=1, diagnostic): plain accesses bracketed
+// by __threadfence().
+//
+// One arrival counter per gap serves both climbs and both kernels of each, in 4-bit fields: topology local +1,
+// topology upper +16, boxes local +256, boxes upper +4096.
 constexpr int kChunk = 512;  // sorted leaves per workgroup, one per thread
 
-struct alignas(16) NodeInfo {  // a finished inner node, indexed by its gap
-    float box[6];
-    uint32_t l, r;  // leaf range
+struct alignas(8) TopoRec {  // what a child leaves at its parent in the topology climb
+    uint32_t far_end;
+    uint32_t dl;
 };
-struct alignas(16) LeafRec {  // a leaf in sorted order
-    float box[6];
-    uint32_t id;  // 1-based primitive id
-    uint32_t pad;
-};
-static_assert(sizeof(NodeInfo) == 32 && sizeof(LeafRec) == 32, "32-byte records");
 
 template <bool FENCE>
 __device__ __forceinline__ void child_store(ChildRec* slot, const float* box, uint32_t far_end, uint32_t dl) {
@@ -592,6 +594,18 @@ __device__ __forceinline__ void child_load(const ChildRec* slot, float* box, uin
     *far_end = (uint32_t)w3;
     *dl = (uint32_t)(w3 >> 32);
 }
+template <bool FENCE>
+__device__ __forceinline__ void topo_store(TopoRec* slot, uint32_t far_end, uint32_t dl) {
+    const uint64_t w = (uint64_t)far_end | ((uint64_t)dl << 32);
+    if (FENCE) *(uint64_t*)slot = w;
+    else __hip_atomic_store((uint64_t*)slot, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool FENCE>
+__device__ __forceinline__ void topo_load(const TopoRec* slot, uint32_t* far_end, uint32_t* dl) {
+    const uint64_t w = FENCE ? *(volatile uint64_t*)slot : __hip_atomic_load((uint64_t*)slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *far_end = (uint32_t)w;
+    *dl = (uint32_t)(w >> 32);
+}
 
 // merge with a sibling: the LEFT child's box is the first argument of every Min / Max (lbvh.c:58)
 __device__ __forceinline__ void merge_sibling(float* box, const float* sbox, bool sibling_is_right) {
@@ -602,55 +616,91 @@ __device__ __forceinline__ void merge_sibling(float* box, const float* sbox, boo
     }
 }
 
-// STREAM: write-through stores that leave no dirty line behind in the L2 (the upper kernel's release operations write
-// the L2's dirty lines back; its own node records need not be among them)
-template <bool STREAM = false>
-__device__ __forceinline__ void node_store(NodeInfo* node_info, uint8_t* node_dl, uint32_t gap, const float* box,
-                                           uint32_t l, uint32_t r, uint32_t dl) {
-    if (STREAM) {
-        typedef float vfloat4 __attribute__((ext_vector_type(4)));
-        vfloat4* p = (vfloat4*)&node_info[gap];
-        const vfloat4 a = {box[0], box[1], box[2], box[3]}, b = {box[4], box[5], __uint_as_float(l), __uint_as_float(r)};
-        __builtin_nontemporal_store(a, p);
-        __builtin_nontemporal_store(b, p + 1);
-        __builtin_nontemporal_store((uint8_t)dl, &node_dl[gap]);
-        return;
+// ---- K7: pre-order records ------------------------------------------------------------------
+// A record in one of two forms: the documented rthip_node (min.xyz, skip | max.xyz, id), or the walk's own
+// (min.x, max.x, min.y, max.y | min.z, max.z, skip, id), in which the two bounds of an axis sit in neighbouring
+// registers after the load -- what the packed subtract / multiply of the slab test want (trav_step in rt_device.h
+// reads it).
+__device__ __forceinline__ void put_node(float4* __restrict__ nodes, uint32_t pre, const float* box, uint32_t skip, uint32_t id,
+                                         uint32_t paired) {
+    if (paired) {
+        nodes[2 * (uint64_t)pre] = make_float4(box[0], box[3], box[1], box[4]);
+        nodes[2 * (uint64_t)pre + 1] = make_float4(box[2], box[5], __uint_as_float(skip), __uint_as_float(id));
+    } else {
+        nodes[2 * (uint64_t)pre] = make_float4(box[0], box[1], box[2], __uint_as_float(skip));
+        nodes[2 * (uint64_t)pre + 1] = make_float4(box[3], box[4], box[5], __uint_as_float(id));
     }
-    NodeInfo ni;
-#pragma unroll
-    for (int k = 0; k < 6; k++) ni.box[k] = box[k];
-    ni.l = l;
-    ni.r = r;
-    node_info[gap] = ni;
-    node_dl[gap] = (uint8_t)dl;
 }
 
-__device__ __forceinline__ void hierarchy_local_body(uint32_t c0, uint32_t n, const uint8_t* __restrict__ prio,
-                                                                 const uint32_t* __restrict__ sorted_idx,
-                                                                 const float* __restrict__ aabb6,
-                                                                 ChildRec* __restrict__ child, uint32_t* flags,
-                                                                 uint32_t* __restrict__ cnt_l,
-                                                                 NodeInfo* __restrict__ node_info,
-                                                                 uint8_t* __restrict__ node_dl,
-                                                                 LeafRec* __restrict__ leaf_sorted,
-                                                                 uint32_t* __restrict__ starters, uint32_t* start_count) {
+// S(i): inclusive prefix sum of the left-spine lengths up to leaf i (the tile scan, plus the sums of the tiles before)
+__device__ __forceinline__ uint32_t spine_prefix(const uint32_t* __restrict__ scan, const uint32_t* __restrict__ tile_sums, uint32_t i) {
+    return scan[i] + (tile_sums ? tile_sums[i / (uint32_t)kScanTile] : 0u);
+}
+// the finished inner node with leaf range [l, r] and dl left edges down to leaf l
+__device__ __forceinline__ void put_inner(float4* __restrict__ nodes, const uint32_t* __restrict__ scan, const uint32_t* __restrict__ tile_sums,
+                                          const float* box, uint32_t l, uint32_t r, uint32_t dl, uint32_t paired) {
+    const uint32_t pre = l + spine_prefix(scan, tile_sums, l) - dl;
+    put_node(nodes, pre, box, pre + 2u * (r - l + 1u) - 1u, 0u, paired);
+}
+
+struct ClimbArgs {
+    uint32_t n;
+    const uint64_t* keys;      // sorted Morton codes (topology climb: the gap priorities are taken from them)
+    uint8_t* prio;             // gap priorities: written by the topology climb, read by the box climb
+    const uint32_t* sorted_idx;
+    const float* aabb6;
+    ChildRec* child;           // box climb: records for parents that span chunks
+    TopoRec* child_topo;       // topology climb: the same
+    uint32_t* flags;           // arrival counters
+    uint32_t* cnt_l;           // topology climb: left-spine length per leaf; box climb: their tile-wise inclusive scan
+    const uint32_t* tile_sums; // box climb: exclusive sums of the scan tiles (nullptr: cnt_l holds the whole scan)
+    uint32_t* starters;        // gaps whose two children both arrived in the local kernel
+    uint32_t* start_count;
+    float4* nodes;             // box climb: the pre-order records
+    uint32_t paired;
+    bool prio_ready;           // topology climb: prio already holds the priorities (the one-workgroup build)
+};
+
+// The chunk-local part of a climb.  BOXES = false: topology (fills cnt_l, prio, the starter list); true: boxes.
+template <bool BOXES>
+__device__ __forceinline__ void climb_local(uint32_t c0, const ClimbArgs& A) {
     // window of gap priorities: entry k is gap c0 - 1 + k, k = 0 .. kChunk; bit 7 marks a local gap.
     // Gaps that do not exist (-1, >= n-1) read as 0, below every real priority (>= 1).
     __shared__ uint8_t win[kChunk + 8];
     __shared__ uint32_t lflag[kChunk];
-    __shared__ ChildRec lrec[2 * kChunk];
+    __shared__ uint64_t lrec_raw[(BOXES ? sizeof(ChildRec) : sizeof(TopoRec)) * 2 * kChunk / 8];
     __shared__ uint32_t wmin_l[kChunk / 64], wmin_r[kChunk / 64];
-    __shared__ uint32_t n_start, base_start;  // gaps that this workgroup found complete for the upper kernel
+    __shared__ uint32_t n_start, base_start;  // gaps that this workgroup found complete for the upper kernels
+    ChildRec* lrec_box = (ChildRec*)lrec_raw;
+    TopoRec* lrec_topo = (TopoRec*)lrec_raw;
 
+    const uint32_t n = A.n;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     if (tid == 0) n_start = 0;
 
     {
         const int64_t g = (int64_t)c0 - 1 + tid;
-        win[tid] = (g >= 0 && g + 1 < (int64_t)n) ? prio[g] : (uint8_t)0;
+        const bool exists = g >= 0 && g + 1 < (int64_t)n;
+        uint8_t p = 0;
+        if (exists) {
+            if (BOXES || A.prio_ready) p = A.prio[g];
+            else {
+                p = gap_priority_of(A.keys, n, (uint64_t)g);
+                if (tid >= 1) A.prio[g] = p;  // entry 0 is the previous chunk's last gap: that chunk writes it
+            }
+        }
+        win[tid] = p;
         if (tid == 0) {
             const int64_t ge = (int64_t)c0 - 1 + kChunk;
-            win[kChunk] = (ge + 1 < (int64_t)n) ? prio[ge] : (uint8_t)0;
+            uint8_t pe = 0;
+            if (ge + 1 < (int64_t)n) {
+                if (BOXES || A.prio_ready) pe = A.prio[ge];
+                else {
+                    pe = gap_priority_of(A.keys, n, (uint64_t)ge);
+                    A.prio[ge] = pe;
+                }
+            }
+            win[kChunk] = pe;
         }
     }
     lflag[tid] = 0;
@@ -685,215 +735,183 @@ __device__ __forceinline__ void hierarchy_local_body(uint32_t c0, uint32_t n, co
     const uint32_t i = c0 + (uint32_t)tid;
     uint32_t my_start = 0xffffffffu, my_slot = 0;
     if (i < n) {
-    uint32_t l = i, r = i, dl = 0;
-    float box[6];
-    {
-        const uint32_t prim = sorted_idx[i];
-        const float* b = aabb6 + 6 * (uint64_t)prim;  // node->aabb = in_aabbs[id - 1], lbvh.c:53
+        uint32_t l = i, r = i, dl = 0;
+        float box[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (BOXES) {
+            const uint32_t prim = A.sorted_idx[i];
+            const float* b = A.aabb6 + 6 * (uint64_t)prim;  // node->aabb = in_aabbs[id - 1], lbvh.c:53
 #pragma unroll
-        for (int k = 0; k < 6; k++) box[k] = b[k];
-        LeafRec lr;
-#pragma unroll
-        for (int k = 0; k < 6; k++) lr.box[k] = box[k];
-        lr.id = prim + 1;  // id = idx + 1, lbvh.c:116
-        lr.pad = 0;
-        leaf_sorted[i] = lr;
-    }
-    for (;;) {
-        if (l == 0 && r == n - 1) {  // the root: top of the left spine that starts at leaf 0
-            cnt_l[0] = dl;
-            break;
+            for (int k = 0; k < 6; k++) box[k] = b[k];
+            const uint32_t pre = i + spine_prefix(A.cnt_l, A.tile_sums, i);
+            put_node(A.nodes, pre, box, pre + 1, prim + 1, A.paired);  // id = idx + 1, lbvh.c:116
         }
-        // Priorities of the two gaps that bound [l, r]; the parent is the one with the larger priority.
-        // While the node is inside the chunk both gaps are inside the window.
-        const uint32_t pr_r = (r != n - 1) ? (uint32_t)win[r + 1 - c0] : 0u;
-        const uint32_t pr_l = (l != 0) ? (uint32_t)win[l - c0] : 0u;
-        const bool parent_right = (l == 0) || (r != n - 1 && (pr_r & 0x7fu) > (pr_l & 0x7fu));
-        const uint32_t parent = parent_right ? r : l - 1;
-        const uint32_t side = parent_right ? 0u : 1u;  // 0: this node is the LEFT child
-        const bool local = ((parent_right ? pr_r : pr_l) & 0x80u) != 0;
-        if (side == 1) cnt_l[l] = dl;  // a right child tops the left spine that starts at l
-        if (!local) {  // the parent spans chunks: leave the record for hierarchy_upper_kernel
-            ChildRec mine;
+        for (;;) {
+            if (l == 0 && r == n - 1) {  // the root: top of the left spine that starts at leaf 0
+                if (!BOXES) A.cnt_l[0] = dl;
+                break;
+            }
+            // Priorities of the two gaps that bound [l, r]; the parent is the one with the larger priority.
+            // While the node is inside the chunk both gaps are inside the window.
+            const uint32_t pr_r = (r != n - 1) ? (uint32_t)win[r + 1 - c0] : 0u;
+            const uint32_t pr_l = (l != 0) ? (uint32_t)win[l - c0] : 0u;
+            const bool parent_right = (l == 0) || (r != n - 1 && (pr_r & 0x7fu) > (pr_l & 0x7fu));
+            const uint32_t parent = parent_right ? r : l - 1;
+            const uint32_t side = parent_right ? 0u : 1u;  // 0: this node is the LEFT child
+            const bool local = ((parent_right ? pr_r : pr_l) & 0x80u) != 0;
+            if (!BOXES && side == 1) A.cnt_l[l] = dl;  // a right child tops the left spine that starts at l
+            const uint32_t far_end = parent_right ? l : r;
+            if (!local) {  // the parent spans chunks: leave the record for the upper kernel
+                if (BOXES) {
+                    ChildRec mine;
 #pragma unroll
-            for (int k = 0; k < 6; k++) mine.box[k] = box[k];
-            mine.far_end = parent_right ? l : r;
-            mine.dl = dl;
-            child[2 * (uint64_t)parent + side] = mine;
-            // the second child to be counted knows that the parent is complete: it goes on the upper kernel's list
-            if (atomicAdd(&flags[parent], 1u) == 1u) my_start = parent;
-            break;
-        }
-        const uint32_t slot = parent - c0;
-        ChildRec mine;
+                    for (int k = 0; k < 6; k++) mine.box[k] = box[k];
+                    mine.far_end = far_end;
+                    mine.dl = dl;
+                    A.child[2 * (uint64_t)parent + side] = mine;
+                    atomicAdd(&A.flags[parent], 256u);
+                } else {
+                    TopoRec mine = {far_end, dl};
+                    A.child_topo[2 * (uint64_t)parent + side] = mine;
+                    // the second child to be counted knows that the parent is complete: it goes on the upper kernels' list
+                    if (atomicAdd(&A.flags[parent], 1u) == 1u) my_start = parent;
+                }
+                break;
+            }
+            const uint32_t slot = parent - c0;
+            if (BOXES) {
+                ChildRec mine;
 #pragma unroll
-        for (int k = 0; k < 6; k++) mine.box[k] = box[k];
-        mine.far_end = parent_right ? l : r;
-        mine.dl = dl;
-        lrec[2 * slot + side] = mine;
-        // order the LDS record before the LDS counter and the counter before the sibling's record; LDS only:
-        // a fence that also covered global memory would make every level wait for the node stores below it
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-        const uint32_t old = atomicAdd(&lflag[slot], 1u);
-        if (old == 0) break;  // first to arrive: the sibling's thread carries on from here
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-        const ChildRec sib = lrec[2 * slot + (1u - side)];
-        merge_sibling(box, sib.box, side == 0);
-        if (side == 0) {
-            r = sib.far_end;
-            dl = dl + 1;
-        } else {
-            l = sib.far_end;
-            dl = sib.dl + 1;
+                for (int k = 0; k < 6; k++) mine.box[k] = box[k];
+                mine.far_end = far_end;
+                mine.dl = dl;
+                lrec_box[2 * slot + side] = mine;
+            } else {
+                TopoRec mine = {far_end, dl};
+                lrec_topo[2 * slot + side] = mine;
+            }
+            // order the LDS record before the LDS counter and the counter before the sibling's record; LDS only:
+            // a fence that also covered global memory would make every level wait for the node stores below it
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            const uint32_t old = atomicAdd(&lflag[slot], 1u);
+            if (old == 0) break;  // first to arrive: the sibling's thread carries on from here
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+            uint32_t s_far, s_dl;
+            if (BOXES) {
+                const ChildRec sib = lrec_box[2 * slot + (1u - side)];
+                merge_sibling(box, sib.box, side == 0);
+                s_far = sib.far_end;
+                s_dl = sib.dl;
+            } else {
+                const TopoRec sib = lrec_topo[2 * slot + (1u - side)];
+                s_far = sib.far_end;
+                s_dl = sib.dl;
+            }
+            if (side == 0) {
+                r = s_far;
+                dl = dl + 1;
+            } else {
+                l = s_far;
+                dl = s_dl + 1;
+            }
+            if (BOXES) put_inner(A.nodes, A.cnt_l, A.tile_sums, box, l, r, dl, A.paired);
         }
-        node_store(node_info, node_dl, parent, box, l, r, dl);
     }
+    if (!BOXES) {  // hand the complete gaps to the upper kernels: one device-wide atomic per workgroup
+        if (my_start != 0xffffffffu) my_slot = atomicAdd(&n_start, 1u);
+        __syncthreads();
+        if (tid == 0 && n_start != 0) base_start = atomicAdd(A.start_count, n_start);
+        __syncthreads();
+        if (my_start != 0xffffffffu) A.starters[base_start + my_slot] = my_start;
     }
-    // hand the complete gaps to the upper kernel: one device-wide atomic per workgroup
-    if (my_start != 0xffffffffu) my_slot = atomicAdd(&n_start, 1u);
-    __syncthreads();
-    if (tid == 0 && n_start != 0) base_start = atomicAdd(start_count, n_start);
-    __syncthreads();
-    if (my_start != 0xffffffffu) starters[base_start + my_slot] = my_start;
 }
 
-__global__ __launch_bounds__(kChunk) void hierarchy_local_kernel(uint32_t n, const uint8_t* __restrict__ prio,
-                                                                 const uint32_t* __restrict__ sorted_idx,
-                                                                 const float* __restrict__ aabb6,
-                                                                 ChildRec* __restrict__ child, uint32_t* flags,
-                                                                 uint32_t* __restrict__ cnt_l,
-                                                                 NodeInfo* __restrict__ node_info,
-                                                                 uint8_t* __restrict__ node_dl,
-                                                                 LeafRec* __restrict__ leaf_sorted,
-                                                                 uint32_t* __restrict__ starters, uint32_t* start_count) {
-    hierarchy_local_body(blockIdx.x * (uint32_t)kChunk, n, prio, sorted_idx, aabb6, child, flags, cnt_l, node_info, node_dl,
-                         leaf_sorted, starters, start_count);
+template <bool BOXES>
+__global__ __launch_bounds__(kChunk) void climb_local_kernel(ClimbArgs A) {
+    climb_local<BOXES>(blockIdx.x * (uint32_t)kChunk, A);
 }
 
-template <int MODE>
-__global__ __launch_bounds__(kBlock) void hierarchy_upper_kernel(uint32_t n, const uint8_t* __restrict__ prio,
-                                                                 ChildRec* child, uint32_t* flags,
-                                                                 uint32_t* __restrict__ cnt_l,
-                                                                 NodeInfo* __restrict__ node_info,
-                                                                 uint8_t* __restrict__ node_dl,
-                                                                 const uint32_t* __restrict__ starters,
-                                                                 const uint32_t* __restrict__ start_count) {
-    // one thread per gap whose two children were both delivered by hierarchy_local_kernel (its arrivals
-    // count 1 in flags, the arrivals of this kernel 16)
-    const uint32_t count = *start_count;
+template <int MODE, bool BOXES>
+__global__ __launch_bounds__(kBlock) void climb_upper_kernel(ClimbArgs A) {
+    // one thread per gap whose two children were both delivered by the local kernel
+    constexpr uint32_t kMine = BOXES ? 4096u : 16u;   // this kernel's arrivals
+    constexpr int kShift = BOXES ? 8 : 0;             // this climb's two 4-bit fields
+    const uint32_t n = A.n;
+    const uint32_t count = *A.start_count;
     for (uint32_t t = blockIdx.x * kBlock + threadIdx.x; t < count; t += gridDim.x * kBlock) {
-    uint32_t parent = starters[t];
-    uint32_t l, r, dl;
-    float box[6];
-    {
-        const ChildRec a = child[2 * (uint64_t)parent], b = child[2 * (uint64_t)parent + 1];  // left, right
+        uint32_t parent = A.starters[t];
+        uint32_t l, r, dl;
+        float box[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (BOXES) {
+            const ChildRec a = A.child[2 * (uint64_t)parent], b = A.child[2 * (uint64_t)parent + 1];  // left, right
 #pragma unroll
-        for (int k = 0; k < 6; k++) box[k] = a.box[k];
-        merge_sibling(box, b.box, true);
-        l = a.far_end;
-        r = b.far_end;
-        dl = a.dl + 1;
-        node_store<MODE == 0>(node_info, node_dl, parent, box, l, r, dl);
-    }
-    for (;;) {
-        if (l == 0 && r == n - 1) {
-            cnt_l[0] = dl;
-            break;
-        }
-        const uint32_t pr_r = (r != n - 1) ? (uint32_t)prio[r] : 0u;
-        const uint32_t pr_l = (l != 0) ? (uint32_t)prio[l - 1] : 0u;
-        const bool parent_right = (l == 0) || (r != n - 1 && pr_r > pr_l);
-        parent = parent_right ? r : l - 1;
-        const uint32_t side = parent_right ? 0u : 1u;
-        if (side == 1) { if (MODE == 0) __builtin_nontemporal_store(dl, &cnt_l[l]); else cnt_l[l] = dl; }
-        child_store<MODE == 1>(&child[2 * (uint64_t)parent + side], box, parent_right ? l : r, dl);
-        uint32_t old;
-        if (MODE == 0) {  // release: the record is visible device-wide before the count
-            old = __hip_atomic_fetch_add(&flags[parent], 16u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            for (int k = 0; k < 6; k++) box[k] = a.box[k];
+            merge_sibling(box, b.box, true);
+            l = a.far_end;
+            r = b.far_end;
+            dl = a.dl + 1;
+            put_inner(A.nodes, A.cnt_l, A.tile_sums, box, l, r, dl, A.paired);
         } else {
+            const TopoRec a = A.child_topo[2 * (uint64_t)parent], b = A.child_topo[2 * (uint64_t)parent + 1];
+            l = a.far_end;
+            r = b.far_end;
+            dl = a.dl + 1;
+        }
+        for (;;) {
+            if (l == 0 && r == n - 1) {
+                if (!BOXES) A.cnt_l[0] = dl;
+                break;
+            }
+            const uint32_t pr_r = (r != n - 1) ? (uint32_t)A.prio[r] : 0u;
+            const uint32_t pr_l = (l != 0) ? (uint32_t)A.prio[l - 1] : 0u;
+            const bool parent_right = (l == 0) || (r != n - 1 && pr_r > pr_l);
+            parent = parent_right ? r : l - 1;
+            const uint32_t side = parent_right ? 0u : 1u;
+            if (!BOXES && side == 1) A.cnt_l[l] = dl;
+            if (BOXES) child_store<MODE == 1>(&A.child[2 * (uint64_t)parent + side], box, parent_right ? l : r, dl);
+            else topo_store<MODE == 1>(&A.child_topo[2 * (uint64_t)parent + side], parent_right ? l : r, dl);
+            uint32_t old;
+            if (MODE == 0) {  // release: the record is visible device-wide before the count
+                old = __hip_atomic_fetch_add(&A.flags[parent], kMine, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                if (MODE == 1) __threadfence();
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                old = atomicAdd(&A.flags[parent], kMine);
+            }
+            old >>= kShift;
+            if ((old & 15u) + ((old >> 4) & 15u) == 0u) break;  // first to arrive: the sibling carries on from here
+            if (MODE == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the sibling's record, released before its count
             if (MODE == 1) __threadfence();
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            old = atomicAdd(&flags[parent], 16u);
+            uint32_t s_far, s_dl;
+            if (BOXES) {
+                float sbox[6];
+                child_load<MODE == 1>(&A.child[2 * (uint64_t)parent + (1u - side)], sbox, &s_far, &s_dl);
+                merge_sibling(box, sbox, side == 0);
+            } else {
+                topo_load<MODE == 1>(&A.child_topo[2 * (uint64_t)parent + (1u - side)], &s_far, &s_dl);
+            }
+            if (side == 0) {
+                r = s_far;
+                dl = dl + 1;
+            } else {
+                l = s_far;
+                dl = s_dl + 1;
+            }
+            if (BOXES) put_inner(A.nodes, A.cnt_l, A.tile_sums, box, l, r, dl, A.paired);
         }
-        if ((old & 15u) + (old >> 4) == 0u) break;  // first to arrive: the sibling carries on from here
-        if (MODE == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the sibling's record, released before its count
-        if (MODE == 1) __threadfence();
-        float sbox[6];
-        uint32_t s_far, s_dl;
-        child_load<MODE == 1>(&child[2 * (uint64_t)parent + (1u - side)], sbox, &s_far, &s_dl);
-        merge_sibling(box, sbox, side == 0);
-        if (side == 0) {
-            r = s_far;
-            dl = dl + 1;
-        } else {
-            l = s_far;
-            dl = s_dl + 1;
-        }
-        node_store<MODE == 0>(node_info, node_dl, parent, box, l, r, dl);
     }
-    }
-}
-
-// ---- K7: pre-order records ------------------------------------------------------------------
-// Thread t writes leaf t and inner node (gap) t: neighbours in pre-order are written by
-// neighbouring threads, so the 32-byte records combine into full lines on their way to HBM.
-// A record in one of two forms: the documented rthip_node (min.xyz, skip | max.xyz, id), or the walk's own
-// (min.x, max.x, min.y, max.y | min.z, max.z, skip, id), in which the two bounds of an axis sit in neighbouring
-// registers after the load -- what the packed subtract / multiply of the slab test want (node_box / node_links in
-// rt_device.h read it).
-__device__ __forceinline__ void put_node(float4* __restrict__ nodes, uint32_t pre, const float* box, uint32_t skip, uint32_t id,
-                                         uint32_t paired) {
-    if (paired) {
-        nodes[2 * (uint64_t)pre] = make_float4(box[0], box[3], box[1], box[4]);
-        nodes[2 * (uint64_t)pre + 1] = make_float4(box[2], box[5], __uint_as_float(skip), __uint_as_float(id));
-    } else {
-        nodes[2 * (uint64_t)pre] = make_float4(box[0], box[1], box[2], __uint_as_float(skip));
-        nodes[2 * (uint64_t)pre + 1] = make_float4(box[3], box[4], box[5], __uint_as_float(id));
-    }
-}
-
-__device__ __forceinline__ void emit_body(uint64_t t, uint32_t n, const LeafRec* __restrict__ leaf_sorted,
-                                          const NodeInfo* __restrict__ node_info, const uint8_t* __restrict__ node_dl,
-                                          const uint32_t* __restrict__ spine_scan, float4* __restrict__ nodes, uint32_t paired) {
-    if (t >= n) return;
-    {
-        const uint32_t i = (uint32_t)t;
-        const uint32_t pre = i + spine_scan[i];
-        const LeafRec lr = leaf_sorted[i];
-        put_node(nodes, pre, lr.box, pre + 1, lr.id, paired);
-    }
-    if (t + 1 < n) {
-        const NodeInfo ni = node_info[t];
-        const uint32_t dl = node_dl[t];
-        const uint32_t pre = ni.l + spine_scan[ni.l] - dl;
-        const uint32_t size = 2 * (ni.r - ni.l + 1) - 1;
-        put_node(nodes, pre, ni.box, pre + size, 0u, paired);
-    }
-}
-
-__global__ __launch_bounds__(kBlock) void emit_kernel(uint32_t n, const LeafRec* __restrict__ leaf_sorted,
-                                                      const NodeInfo* __restrict__ node_info,
-                                                      const uint8_t* __restrict__ node_dl,
-                                                      const uint32_t* __restrict__ spine_scan,
-                                                      float4* __restrict__ nodes, uint32_t paired) {
-    emit_body((uint64_t)blockIdx.x * kBlock + threadIdx.x, n, leaf_sorted, node_info, node_dl, spine_scan, nodes, paired);
 }
 
 // ---- the whole build in one workgroup, for n <= kChunk ---------------------------------------
 // Small trees (the demos' meshes and TLASes have 1 .. 12 primitives) are all launch overhead in the
 // pipeline above.  Here one 512-thread workgroup, one primitive per thread, runs the same steps with
 // the same device functions: centroid bounds, Morton codes, a stable sort in LDS (bitonic network on
-// (code, index) pairs), gap priorities, the chunk-local hierarchy climb (every gap is local), the
-// prefix sum of the left-spine lengths and the pre-order records.
+// (code, index) pairs), gap priorities, the topology climb (every gap is local), the prefix sum of the
+// left-spine lengths and the box climb that writes the pre-order records.
 __global__ __launch_bounds__(kChunk) void lbvh_small_kernel(uint32_t n, const float* __restrict__ aabb6,
                                                             uint64_t* __restrict__ codes_unsorted,
                                                             uint64_t* __restrict__ keys_sorted,
-                                                            uint32_t* __restrict__ vals_sorted, uint8_t* __restrict__ prio,
-                                                            ChildRec* __restrict__ child, uint32_t* flags,
-                                                            uint32_t* __restrict__ cnt_l, NodeInfo* __restrict__ node_info,
-                                                            uint8_t* __restrict__ node_dl, LeafRec* __restrict__ leaf_sorted,
-                                                            uint32_t* __restrict__ starters, float4* __restrict__ nodes,
-                                                            uint32_t box_bounds, uint32_t paired) {
+                                                            uint32_t* __restrict__ vals_sorted, ClimbArgs A,
+                                                            uint32_t box_bounds) {
     __shared__ uint64_t skey[kChunk];
     __shared__ uint32_t sidx[kChunk];
     __shared__ uint32_t sbounds[6];
@@ -952,13 +970,12 @@ __global__ __launch_bounds__(kChunk) void lbvh_small_kernel(uint32_t n, const fl
         keys_sorted[t] = skey[t];
         vals_sorted[t] = sidx[t];
     }
-    if (t + 1 < n) prio[t] = gap_priority_of(skey, n, t);
-    __syncthreads();  // the climb reads prio and vals_sorted back from memory
-    hierarchy_local_body(0u, n, prio, vals_sorted, aabb6, child, flags, cnt_l, node_info, node_dl, leaf_sorted, starters,
-                         flags /* never counted: no gap spans chunks */);
+    if (t + 1 < n) A.prio[t] = gap_priority_of(skey, n, t);
+    __syncthreads();  // the climbs read prio and vals_sorted back from memory
+    climb_local<false>(0u, A);
     __syncthreads();
     {   // inclusive prefix sum of the left-spine lengths
-        const uint32_t v = (t < n) ? cnt_l[t] : 0u;
+        const uint32_t v = (t < n) ? A.cnt_l[t] : 0u;
         uint32_t incl = v;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -969,10 +986,10 @@ __global__ __launch_bounds__(kChunk) void lbvh_small_kernel(uint32_t n, const fl
         __syncthreads();
         uint32_t before = 0;
         for (int w = 0; w < wave; w++) before += wave_tot[w];
-        if (t < n) cnt_l[t] = before + incl;
+        if (t < n) A.cnt_l[t] = before + incl;
     }
     __syncthreads();
-    emit_body(t, n, leaf_sorted, node_info, node_dl, cnt_l, nodes, paired);
+    climb_local<true>(0u, A);
 }
 
 // ---- K8: world box of every instance, rt_cpu_tlas_node_to_aabb, raytracer_cpu.c:131-147 ------
@@ -1079,6 +1096,23 @@ int scan_u32(rthip_ctx* ctx, uint32_t* d, uint64_t n, uint32_t* tmp, hipStream_t
     return RTHIP_OK;
 }
 
+// Inclusive prefix sum per tile of kScanTile values, with the exclusive sums of the tiles left in tmp (*tile_sums; nullptr
+// when one tile holds everything): the consumer adds the tile's sum itself instead of a pass over the data doing it.
+int scan_u32_tiles(rthip_ctx* ctx, uint32_t* d, uint64_t n, uint32_t* tmp, hipStream_t s, const uint32_t** tile_sums) {
+    uint32_t blocks = div_up(n, kScanTile);
+    if (blocks <= 1) {
+        scan_tile_kernel<true><<<1, kBlock, 0, s>>>(d, n, nullptr);
+        RT_HIP(ctx, hipGetLastError());
+        *tile_sums = nullptr;
+        return RTHIP_OK;
+    }
+    scan_tile_kernel<true><<<blocks, kBlock, 0, s>>>(d, n, tmp);
+    RT_HIP(ctx, hipGetLastError());
+    RT_TRY((scan_u32<false>(ctx, tmp, blocks, tmp + ((blocks + 63) & ~63u), s)));
+    *tile_sums = tmp;
+    return RTHIP_OK;
+}
+
 size_t scan_tmp_elems(uint64_t n) {
     size_t total = 0;
     while (n > (uint64_t)kScanTile) {
@@ -1091,7 +1125,8 @@ size_t scan_tmp_elems(uint64_t n) {
 
 }  // namespace
 
-int radix_sort_workspace_device(rthip_ctx* ctx, uint64_t n, int n_bytes, hipStream_t s, int* cur_io, LbvhWorkspace* ws) {
+int radix_sort_workspace_device(rthip_ctx* ctx, uint64_t n, int n_bytes, hipStream_t s, int* cur_io, LbvhWorkspace* ws,
+                                bool identity_vals) {
     LbvhWorkspace& w = ws ? *ws : ctx->ws;
     const uint32_t tiles = div_up(n, kSortTile);
     RT_TRY(rthip_reserve(ctx, w.block_hist, (256ull * tiles + 256) * 4));
@@ -1109,7 +1144,8 @@ int radix_sort_workspace_device(rthip_ctx* ctx, uint64_t n, int n_bytes, hipStre
         RT_HIP(ctx, hipGetLastError());
         for (int pass = 0; pass < n_bytes; pass++) {
             const bool last = pass + 1 == n_bytes;
-            radix_scatter_kernel<true><<<tiles, kSortBlock, 0, s>>>(keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, pass * 8,
+            radix_scatter_kernel<true><<<tiles, kSortBlock, 0, s>>>(keys[cur], (pass == 0 && identity_vals) ? nullptr : vals[cur],
+                                                                keys[cur ^ 1], vals[cur ^ 1], n, pass * 8,
                                                                 h + (size_t)(pass % 3) * table, tiles,
                                                                 last ? nullptr : h + (size_t)((pass + 1) % 3) * table,
                                                                 last ? nullptr : h + (size_t)((pass + 2) % 3) * table);
@@ -1119,12 +1155,17 @@ int radix_sort_workspace_device(rthip_ctx* ctx, uint64_t n, int n_bytes, hipStre
         *cur_io = cur;
         return RTHIP_OK;
     }
+    // A one-sweep form (digit totals of all passes from one pass over the keys, tile offsets by decoupled look-back over
+    // per-tile status words instead of the histogram and offsets kernels) was built and measured at 10^7 keys: 94 us
+    // per pass against 61 + 18 + 6 here -- with ~600 tiles in flight a tile's predecessors have published their own
+    // counts but not yet their inclusive ones, so every look-back walks far, one device-scope load latency per step.
     for (int pass = 0; pass < n_bytes; pass++) {
         const int shift = pass * 8;
         radix_hist_kernel<<<tiles, kSortBlock, 0, s>>>(keys[cur], n, shift, (uint32_t*)w.block_hist.p, tiles);
         RT_HIP(ctx, hipGetLastError());
         radix_offsets_kernel<<<256, kBlock, 0, s>>>((uint32_t*)w.block_hist.p, tiles);
-        radix_scatter_kernel<false><<<tiles, kSortBlock, 0, s>>>(keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, shift,
+        radix_scatter_kernel<false><<<tiles, kSortBlock, 0, s>>>(keys[cur], (pass == 0 && identity_vals) ? nullptr : vals[cur],
+                                                             keys[cur ^ 1], vals[cur ^ 1], n, shift,
                                                              (const uint32_t*)w.block_hist.p, tiles, nullptr, nullptr);
         RT_HIP(ctx, hipGetLastError());
         cur ^= 1;
@@ -1204,9 +1245,7 @@ int lbvh_reserve_workspace(rthip_ctx* ctx, uint64_t n, LbvhWorkspace* ws) {
     RT_TRY(rthip_reserve(ctx, w.scan_tmp, (scan_tmp_elems(hist_elems) + scan_tmp_elems(n)) * 4));
     RT_TRY(rthip_reserve(ctx, w.prio, n));
     RT_TRY(rthip_reserve(ctx, w.child, 2 * n * sizeof(ChildRec)));
-    RT_TRY(rthip_reserve(ctx, w.node_info, n * sizeof(NodeInfo)));
-    RT_TRY(rthip_reserve(ctx, w.node_dl, n));
-    RT_TRY(rthip_reserve(ctx, w.leaf_sorted, n * sizeof(LeafRec)));
+    RT_TRY(rthip_reserve(ctx, w.child_topo, 2 * n * sizeof(TopoRec)));
     RT_TRY(rthip_reserve(ctx, w.flags, n * 4));
     RT_TRY(rthip_reserve(ctx, w.starters, n * 4));
     RT_TRY(rthip_reserve(ctx, w.cnt_l, n * 4));
@@ -1231,12 +1270,28 @@ int lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, float4* 
     uint32_t* vals[2] = {(uint32_t*)w.vals[0].p, (uint32_t*)w.vals[1].p};
     uint32_t* scan_tmp = (uint32_t*)w.scan_tmp.p;
 
+    ClimbArgs A;
+    A.n = (uint32_t)n;
+    A.prio = (uint8_t*)w.prio.p;
+    A.aabb6 = d_aabb6;
+    A.child = (ChildRec*)w.child.p;
+    A.child_topo = (TopoRec*)w.child_topo.p;
+    A.flags = (uint32_t*)w.flags.p;
+    A.cnt_l = (uint32_t*)w.cnt_l.p;
+    A.tile_sums = nullptr;
+    A.starters = (uint32_t*)w.starters.p;
+    A.start_count = (uint32_t*)w.flags.p + (n - 1);
+    A.nodes = d_nodes;
+    A.paired = paired ? 1u : 0u;
+    A.prio_ready = false;
+
     if (n <= (uint64_t)kChunk) {  // one workgroup does everything
         ctx->bounds_of = nullptr;
-        lbvh_small_kernel<<<1, kChunk, 0, s>>>((uint32_t)n, d_aabb6, keys[0], keys[1], vals[1], (uint8_t*)w.prio.p,
-                                               (ChildRec*)w.child.p, (uint32_t*)w.flags.p, (uint32_t*)w.cnt_l.p,
-                                               (NodeInfo*)w.node_info.p, (uint8_t*)w.node_dl.p, (LeafRec*)w.leaf_sorted.p,
-                                               (uint32_t*)w.starters.p, d_nodes, ctx->box_bounds, paired ? 1u : 0u);
+        A.keys = keys[1];
+        A.sorted_idx = vals[1];
+        A.prio_ready = true;
+        A.start_count = (uint32_t*)w.flags.p;  // never counted: no gap spans chunks
+        lbvh_small_kernel<<<1, kChunk, 0, s>>>((uint32_t)n, d_aabb6, keys[0], keys[1], vals[1], A, ctx->box_bounds);
         RT_HIP(ctx, hipGetLastError());
         if (d_codes_unsorted) RT_HIP(ctx, hipMemcpyAsync(d_codes_unsorted, keys[0], n * 8, hipMemcpyDeviceToDevice, s));
         if (d_keys_sorted) RT_HIP(ctx, hipMemcpyAsync(d_keys_sorted, keys[1], n * 8, hipMemcpyDeviceToDevice, s));
@@ -1250,44 +1305,39 @@ int lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, float4* 
         bounds_kernel<<<bblocks, kBlock, 0, s>>>(d_aabb6, n, bounds, ctx->box_bounds);
     }
     ctx->bounds_of = nullptr;
-    morton_kernel<<<div_up(n, kBlock), kBlock, 0, s>>>(d_aabb6, n, bounds, keys[0], vals[0]);
+    // values: see identity_vals; the arrival counters of the n - 1 gaps + the starter count are cleared on the way
+    morton_kernel<<<div_up(n, kBlock), kBlock, 0, s>>>(d_aabb6, n, bounds, keys[0], nullptr, (uint32_t*)w.flags.p);
     RT_HIP(ctx, hipGetLastError());
     if (d_codes_unsorted)
         RT_HIP(ctx, hipMemcpyAsync(d_codes_unsorted, keys[0], n * 8, hipMemcpyDeviceToDevice, s));
 
     int cur = 0;
-    if (n > 1) RT_TRY(radix_sort_workspace_device(ctx, n, 8, s, &cur, &w));
+    RT_TRY(radix_sort_workspace_device(ctx, n, 8, s, &cur, &w, true));
     if (d_keys_sorted) RT_HIP(ctx, hipMemcpyAsync(d_keys_sorted, keys[cur], n * 8, hipMemcpyDeviceToDevice, s));
     if (d_ids_sorted) RT_HIP(ctx, hipMemcpyAsync(d_ids_sorted, vals[cur], n * 4, hipMemcpyDeviceToDevice, s));
 
-    const uint32_t n32 = (uint32_t)n;
-    if (n > 1) {
-        gap_priority_kernel<<<div_up(n - 1, kBlock), kBlock, 0, s>>>(keys[cur], n, (uint8_t*)w.prio.p);
-        RT_HIP(ctx, hipGetLastError());
-        RT_HIP(ctx, hipMemsetAsync(w.flags.p, 0, n * 4, s));  // arrival counters of the n - 1 gaps + the starter count
-    }
+    A.keys = keys[cur];
+    A.sorted_idx = vals[cur];
     const uint32_t chunks = div_up(n, kChunk);
-    hierarchy_local_kernel<<<chunks, kChunk, 0, s>>>(n32, (const uint8_t*)w.prio.p, vals[cur], d_aabb6, (ChildRec*)w.child.p,
-                                                     (uint32_t*)w.flags.p, (uint32_t*)w.cnt_l.p, (NodeInfo*)w.node_info.p,
-                                                     (uint8_t*)w.node_dl.p, (LeafRec*)w.leaf_sorted.p, (uint32_t*)w.starters.p,
-                                                     (uint32_t*)w.flags.p + (n - 1));
+    uint32_t ublocks = div_up(n - 1, kBlock);
+    if (ublocks > 2048) ublocks = 2048;
+#define RT_UPPER(BOXES)                                                                  \
+    do {                                                                                 \
+        if (ctx->refit_fence == 1) climb_upper_kernel<1, BOXES><<<ublocks, kBlock, 0, s>>>(A); \
+        else if (ctx->refit_fence == 2) climb_upper_kernel<2, BOXES><<<ublocks, kBlock, 0, s>>>(A); \
+        else climb_upper_kernel<0, BOXES><<<ublocks, kBlock, 0, s>>>(A);                 \
+    } while (0)
+    // topology: gap priorities, left-spine lengths, the list of gaps the upper kernels start from
+    climb_local_kernel<false><<<chunks, kChunk, 0, s>>>(A);
     RT_HIP(ctx, hipGetLastError());
-    if (n > 1) {
-        uint32_t ublocks = div_up(n - 1, kBlock);
-        if (ublocks > 2048) ublocks = 2048;
-#define RT_UPPER(MODE)                                                                                                 \
-    hierarchy_upper_kernel<MODE><<<ublocks, kBlock, 0, s>>>(                                                          \
-        n32, (const uint8_t*)w.prio.p, (ChildRec*)w.child.p, (uint32_t*)w.flags.p, (uint32_t*)w.cnt_l.p,              \
-        (NodeInfo*)w.node_info.p, (uint8_t*)w.node_dl.p, (const uint32_t*)w.starters.p, (const uint32_t*)w.flags.p + (n - 1))
-        if (ctx->refit_fence == 1) RT_UPPER(1);
-        else if (ctx->refit_fence == 2) RT_UPPER(2);
-        else RT_UPPER(0);
+    RT_UPPER(false);
+    RT_HIP(ctx, hipGetLastError());
+    RT_TRY(scan_u32_tiles(ctx, (uint32_t*)w.cnt_l.p, n, scan_tmp + scan_tmp_elems(hist_elems), s, &A.tile_sums));
+    // boxes: every node's record goes to its pre-order place
+    climb_local_kernel<true><<<chunks, kChunk, 0, s>>>(A);
+    RT_HIP(ctx, hipGetLastError());
+    RT_UPPER(true);
 #undef RT_UPPER
-        RT_HIP(ctx, hipGetLastError());
-    }
-    RT_TRY((scan_u32<true>(ctx, (uint32_t*)w.cnt_l.p, n, scan_tmp + scan_tmp_elems(hist_elems), s)));
-    emit_kernel<<<div_up(n, kBlock), kBlock, 0, s>>>(n32, (const LeafRec*)w.leaf_sorted.p, (const NodeInfo*)w.node_info.p,
-                                                    (const uint8_t*)w.node_dl.p, (const uint32_t*)w.cnt_l.p, d_nodes, paired ? 1u : 0u);
     RT_HIP(ctx, hipGetLastError());
     return RTHIP_OK;
 }
@@ -1295,12 +1345,12 @@ int lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, float4* 
 // ---- a workspace that is not allocated ------------------------------------------------------------
 // Callers that cannot allocate (code under HIP graph capture, serving loops, harnesses that forbid hipMalloc) build in
 // this file-scope device array instead.  Every GPU the library runs on holds its own copy at its own address until the
-// process ends (about 23 MB); the array's name is only a host-side stand-in, so its device address is looked up once
+// process ends (about 17 MB); the array's name is only a host-side stand-in, so its device address is looked up once
 // per device with hipGetSymbolAddress and only that pointer is ever handed to kernels and memsets.
 namespace {
 
 constexpr size_t kStaticSlack = 1u << 20;  // block histograms, scan sums, bounds, alignment padding
-constexpr size_t kStaticBytes = kStaticBuildMaxBoxes * 168u + kStaticSlack;
+constexpr size_t kStaticBytes = kStaticBuildMaxBoxes * 120u + kStaticSlack;  // 117 bytes per box: keys, values, priorities, child slots, counters
 static __device__ __align__(256) unsigned char scratch[kStaticBytes];
 
 constexpr int kMaxDevices = 64;
@@ -1341,8 +1391,7 @@ int lbvh_static_workspace_init(rthip_ctx* ctx) {
               carve(w.block_hist, base, off, hist_bytes > fused_bytes ? hist_bytes : fused_bytes) &&
               carve(w.scan_tmp, base, off, (scan_tmp_elems(hist_elems) + scan_tmp_elems(n)) * 4) &&
               carve(w.prio, base, off, n) && carve(w.child, base, off, 2 * n * sizeof(ChildRec)) &&
-              carve(w.node_info, base, off, n * sizeof(NodeInfo)) && carve(w.node_dl, base, off, n) &&
-              carve(w.leaf_sorted, base, off, n * sizeof(LeafRec)) && carve(w.flags, base, off, n * 4) &&
+              carve(w.child_topo, base, off, 2 * n * sizeof(TopoRec)) && carve(w.flags, base, off, n * 4) &&
               carve(w.starters, base, off, n * 4) && carve(w.cnt_l, base, off, n * 4) && carve(w.bounds, base, off, 64);
     if (!ok) return rthip_fail(ctx, RTHIP_E_LIMIT, "the static workspace of %zu bytes is too small for %llu boxes", kStaticBytes, (unsigned long long)n);
     ctx->ws_static_ready = true;

@@ -133,7 +133,7 @@ int rthip_create(rthip_ctx** out_ctx, int device_id) {
     rthip_ctx* ctx = new rthip_ctx();
     ctx->device = device_id;
     const char* fence = getenv("RTHIP_REFIT_FENCE");
-    ctx->refit_fence = (fence && (fence[0] == '1' || fence[0] == '2')) ? fence[0] - '0' : 0;
+    ctx->refit_fence = (fence && fence[0] >= '0' && fence[0] <= '2') ? fence[0] - '0' : 2;
     const char* mode = getenv("RTHIP_CAST");
     if (mode && strcmp(mode, "static") == 0) ctx->cast_mode = 1;
     if (mode && strcmp(mode, "static-samples") == 0) ctx->cast_mode = 4;
@@ -171,7 +171,7 @@ void rthip_destroy(rthip_ctx* ctx) {
     for (auto& m : ctx->meshes) release_mesh(m);
     LbvhWorkspace& w = ctx->ws;
     DevBuf* all[] = {&w.aabb, &w.keys[0], &w.keys[1], &w.vals[0], &w.vals[1], &w.block_hist, &w.scan_tmp, &w.scan_aux, &w.prio,
-                     &w.child, &w.flags, &w.starters, &w.node_info, &w.node_dl, &w.leaf_sorted, &w.cnt_l, &w.bounds, &ctx->blas_nodes, &ctx->tri_v, &ctx->tri_n,
+                     &w.child, &w.child_topo, &w.flags, &w.starters, &w.cnt_l, &w.bounds, &ctx->blas_nodes, &ctx->tri_v, &ctx->tri_n,
                      &ctx->blas_wide, &ctx->tlas_wide, &ctx->wide_rank, &ctx->tlas_nodes, &ctx->inst, &ctx->mats, &ctx->inst_aabb, &ctx->counters, &ctx->work_ring, &ctx->scratch_a,
                      &ctx->scratch_b, &ctx->scratch_c, &ctx->scratch_d, &ctx->scratch_e, &ctx->frame, &ctx->hdr_stage,
                      &ctx->hdr_lengths, &ctx->hdr_offsets, &ctx->hdr_out, &ctx->hdr_size, &ctx->obj.cp, &ctx->obj.cn, &ctx->obj.ct,

@@ -32,13 +32,11 @@ struct LbvhWorkspace {
     DevBuf scan_tmp;    // uint32[...] block sums of the device-wide scans
     DevBuf scan_aux;    // the same for scan_inclusive_u32_device
     DevBuf prio;        // uint8[n-1]  split priority of every gap
-    DevBuf child;       // ChildInfo[2(n-1)]
-    DevBuf flags;       // uint32[n-1] arrival counters
-    DevBuf starters;     // gaps whose two children both arrived in the chunk-local kernel (start list of the upper kernel)
-    DevBuf node_info;   // NodeInfo[n-1] finished inner nodes by gap
-    DevBuf node_dl;     // uint8[n-1]  left-spine length of every inner node
-    DevBuf leaf_sorted; // LeafRec[n]  leaves in sorted order
-    DevBuf cnt_l;       // uint32[n]   left-spine lengths, then their inclusive scan
+    DevBuf child;       // ChildRec[2(n-1)]  box climb: records for parents that span chunks
+    DevBuf child_topo;  // TopoRec[2(n-1)]   topology climb: the same
+    DevBuf flags;       // uint32[n-1] arrival counters (+ the starter count)
+    DevBuf starters;    // gaps whose two children both arrived in the chunk-local kernel (start list of the upper kernels)
+    DevBuf cnt_l;       // uint32[n]   left-spine lengths, then their tile-wise inclusive scan
     DevBuf bounds;      // uint32[6]   ordered-int centroid bounds
 };
 
@@ -130,7 +128,7 @@ struct rthip_ctx {
     uint32_t max_bounces = 8;
     int sky = 1;
     int counting = 0;
-    int refit_fence = 0;  // hand-offs of the upper hierarchy kernel: 0 acquire-release counter, 1 __threadfence(), 2 relaxed + s_waitcnt
+    int refit_fence = 2;  // hand-offs of the upper hierarchy kernels: 0 release / acquire through the counter, 1 __threadfence(), 2 relaxed + s_waitcnt (default)
 
     struct Pinned { void* p; size_t bytes; };
     std::vector<Pinned> pinned;    // page-locked host memory handed out by rthip_host_alloc
@@ -245,7 +243,9 @@ int lbvh_static_workspace_init(rthip_ctx* ctx);
 
 // Stable LSD radix sort of the n (uint64 key, uint32 value) pairs in ws.keys[*cur] / ws.vals[*cur] (the caller has
 // reserved both ping-pong pairs) by the key's low n_bytes bytes; *cur names the pair that holds the result.
-int radix_sort_workspace_device(rthip_ctx* ctx, uint64_t n, int n_bytes, hipStream_t stream, int* cur, LbvhWorkspace* ws = nullptr);
+// identity_vals: the values are the positions 0 .. n-1 and need not be stored before the call (vals[*cur] is not read).
+int radix_sort_workspace_device(rthip_ctx* ctx, uint64_t n, int n_bytes, hipStream_t stream, int* cur, LbvhWorkspace* ws = nullptr,
+                                bool identity_vals = false);
 // In-place inclusive prefix sum of n uint32.
 int scan_inclusive_u32_device(rthip_ctx* ctx, uint32_t* d, uint64_t n, hipStream_t stream);
 

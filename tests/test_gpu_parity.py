@@ -113,6 +113,33 @@ def test_lbvh_is_deterministic(gpu_tracer):
         assert a.tobytes() == b.tobytes()
 
 
+def test_hierarchy_hand_off_modes_build_the_same_tree(oracle):
+    """The upper hierarchy kernels hand records over in one of three ways (RTHIP_REFIT_FENCE: 2 relaxed atomics ordered by
+    draining the stores, the default; 0 release / acquire through the counter; 1 __threadfence): the same tree from each."""
+    rng = np.random.default_rng(21)
+    n = 400_000
+    cen = rng.random((n, 3)).astype(np.float32)
+    cen[: n // 4] = np.floor(cen[: n // 4] * 6) / 6  # a quarter of them on a lattice: long runs of equal codes
+    half = (rng.random((n, 3)) * 0.002).astype(np.float32)
+    boxes = np.concatenate([cen - half, cen + half], axis=1)
+    want = oracle.lbvh_build(boxes)[3]
+    old = os.environ.get("RTHIP_REFIT_FENCE")
+    try:
+        for mode in ("0", "1", "2"):
+            os.environ["RTHIP_REFIT_FENCE"] = mode
+            t = T.rt_make_tracer(T.RT_TracerSettings(max_bounces=1, sky=True), device_id=0)
+            try:
+                for _ in range(2):
+                    assert_same_tree(T.lbvh_build(t, boxes)[3], want, f"hand-off mode {mode}")
+            finally:
+                T.rt_tracer_cleanup(t)
+    finally:
+        if old is None:
+            os.environ.pop("RTHIP_REFIT_FENCE", None)
+        else:
+            os.environ["RTHIP_REFIT_FENCE"] = old
+
+
 def test_lbvh_ten_million_invariants(gpu_tracer):
     """The benchmark's largest build (10^7 triangles), checked on the GPU through size-independent properties:
     a well-formed pre-order tree, every primitive in exactly one leaf with its own box, every inner box the
