@@ -18,8 +18,9 @@
  *     is the item that was added LAST (src/raytracer/raytracer_core.c:21,37,53
  *     push to the front).  TLAS ids are 1-based indices into that order,
  *     exactly like `id = idx + 1` in src/lbvh/lbvh.c:116.
- *   - one context drives one GPU.  Multi-GPU jobs run one process (one context)
- *     per GPU and shard with rthip_shard.
+ *   - one context drives one GPU.  Multi-GPU jobs either run one process (one context)
+ *     per GPU and shard with rthip_shard, or make a group of contexts in one process
+ *     (rthip_group_*), which shards and gathers by itself.
  *   - a context is not thread-safe: its calls must come from one thread at a time
  *     (the reference's callers are single-threaded, demos_inc.c:9-10).  Different
  *     contexts are independent.  The *_device entry points only enqueue work on
@@ -229,6 +230,44 @@ int rthip_cast_device(rthip_ctx* ctx, const rthip_cast_settings* cast, uint64_t 
  * (use one accumulator per stream). */
 int rthip_cast_accumulate_device(rthip_ctx* ctx, const rthip_cast_settings* cast, uint64_t seed, float* d_accum_rgb,
                                  int width, int height, const rthip_shard* shard, void* stream);
+
+/* ---- several GPUs of one node in one process ------------------------------ */
+
+/* The reference has one tracer and no notion of devices (raytracer_core.h:180-184); a host that wants the whole node
+ * behind those five hooks makes ONE group instead of one context.  A group holds one context per entry of device_ids
+ * (an id may repeat: contexts then share a GPU, which is how the path is tested on a one-GPU box).  The scene calls
+ * mirror the single-context ones and replicate the scene on every device (one host thread per device; every device
+ * builds its own BVHs from the same host data).  rthip_group_cast renders ONE frame with all devices:
+ *   shard_mode 1 (tiles)    device k renders the 64x64 tiles t with t % n == k and ships only those (1/n of the frame),
+ *                           packed: straight to the host buffer (rthip_group_cast: each device copies its own tiles over
+ *                           its own PCIe link into page-locked staging and its thread places the rows), or by peer copy
+ *                           over xGMI to the first device (rthip_group_cast_device).  Bit-identical to rthip_cast.
+ *   shard_mode 2 (samples)  device k renders the samples s with s % n == k of every pixel; the partial sums go to the
+ *                           first device by peer copy and are added there in rank order, then scaled by 1/samples^2:
+ *                           equal to rthip_cast up to the rounding of another order of additions.
+ * d_out_rgb of rthip_group_cast_device is memory of the first device (rthip_group_ctx(g, 0)); both calls return when
+ * the frame is complete.  Settings that are per context (cast kernel, counting, statistics, taps, tree read-back) go
+ * through rthip_group_ctx.  A group is driven from one thread at a time, like a context. */
+typedef struct rthip_group rthip_group;
+int rthip_group_create(rthip_group** out_group, int n, const int* device_ids);
+void rthip_group_destroy(rthip_group* group);
+int rthip_group_size(const rthip_group* group);
+rthip_ctx* rthip_group_ctx(rthip_group* group, int rank);
+const char* rthip_group_last_error(const rthip_group* group);
+int rthip_group_set_tracer(rthip_group* group, uint32_t max_bounces, int sky);
+int rthip_group_set_morton_bounds(rthip_group* group, int mode);
+int rthip_group_set_traversal(rthip_group* group, int mode);
+int rthip_group_blas_begin(rthip_group* group, uint32_t n_meshes);
+int rthip_group_blas_add_mesh(rthip_group* group, uint32_t blas_id, const void* verts, uint32_t vertex_count,
+                              uint32_t stride_bytes, uint32_t pos_off, int32_t nrm_off, const uint32_t* idx,
+                              uint32_t index_count);
+int rthip_group_blas_commit(rthip_group* group);
+int rthip_group_tlas_build(rthip_group* group, const rthip_instance* instances, uint32_t n_instances,
+                           const rthip_material* materials, uint32_t n_materials);
+int rthip_group_cast(rthip_group* group, const rthip_cast_settings* cast, uint64_t seed, float* out_rgb, int width,
+                     int height, int shard_mode);
+int rthip_group_cast_device(rthip_group* group, const rthip_cast_settings* cast, uint64_t seed, float* d_out_rgb, int width,
+                            int height, int shard_mode);
 
 /* ---- parity and measurement taps -------------------------------------- */
 

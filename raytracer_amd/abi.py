@@ -78,6 +78,21 @@ SYMBOLS = [
     ("rthip_host_free", C.c_int, [_P, _P]),
     ("rthip_cast_device", C.c_int, [_P, _P, C.c_uint64, _P, C.c_int, C.c_int, _P, _P]),
     ("rthip_cast_accumulate_device", C.c_int, [_P, _P, C.c_uint64, _P, C.c_int, C.c_int, _P, _P]),
+    ("rthip_group_create", C.c_int, [C.POINTER(_P), C.c_int, _P]),
+    ("rthip_group_destroy", None, [_P]),
+    ("rthip_group_size", C.c_int, [_P]),
+    ("rthip_group_ctx", _P, [_P, C.c_int]),
+    ("rthip_group_last_error", C.c_char_p, [_P]),
+    ("rthip_group_set_tracer", C.c_int, [_P, C.c_uint32, C.c_int]),
+    ("rthip_group_set_morton_bounds", C.c_int, [_P, C.c_int]),
+    ("rthip_group_set_traversal", C.c_int, [_P, C.c_int]),
+    ("rthip_group_blas_begin", C.c_int, [_P, C.c_uint32]),
+    ("rthip_group_blas_add_mesh", C.c_int,
+     [_P, C.c_uint32, _P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32, _P, C.c_uint32]),
+    ("rthip_group_blas_commit", C.c_int, [_P]),
+    ("rthip_group_tlas_build", C.c_int, [_P, _P, C.c_uint32, _P, C.c_uint32]),
+    ("rthip_group_cast", C.c_int, [_P, _P, C.c_uint64, _P, C.c_int, C.c_int, C.c_int]),
+    ("rthip_group_cast_device", C.c_int, [_P, _P, C.c_uint64, _P, C.c_int, C.c_int, C.c_int]),
     ("rthip_lbvh_build", C.c_int, [_P, _P, C.c_uint64, _P, _P, _P, _P, _P]),
     ("rthip_lbvh_build_device", C.c_int, [_P, _P, C.c_uint64, _P, _P]),
     ("rthip_lbvh_reserve", C.c_int, [_P, C.c_uint64]),

@@ -19,7 +19,9 @@ internal RT_Handle rt_hip_tracer_to_handle(RT_HIP_Tracer* tracer) {
 
 static void rt_hip_check(RT_HIP_Tracer* tracer, int rc, const char* what) {
     if (rc != RTHIP_OK) {
-        fprintf(stderr, "rthip: %s failed (%d): %s\n", what, rc, tracer->ctx ? rthip_last_error(tracer->ctx) : "no context");
+        const char* msg = tracer->ctx ? rthip_last_error(tracer->ctx) : "no context";
+        if (tracer->group && rthip_group_last_error(tracer->group)[0]) msg = rthip_group_last_error(tracer->group);
+        fprintf(stderr, "rthip: %s failed (%d): %s\n", what, rc, msg);
     }
     AssertAlways(rc == RTHIP_OK);
 }
@@ -94,15 +96,33 @@ rt_hook RT_Handle rt_make_tracer(RT_TracerSettings settings) {
     tracer->sky = settings.sky;
     tracer->seed = seed;
 
-    const char* dev = getenv("RT_HIP_DEVICE");
-    int rc = rthip_create(&tracer->ctx, dev ? atoi(dev) : 0);
+    // RT_HIP_DEVICES=0,1,2,...: the whole node behind the same five hooks (one context per listed GPU, the scene
+    // replicated, every frame split by 64x64 tiles, bit-identical to one GPU).  Otherwise one GPU: RT_HIP_DEVICE or 0.
+    const char* devs = getenv("RT_HIP_DEVICES");
+    int rc = RTHIP_OK;
+    if (devs && devs[0]) {
+        int ids[64];
+        int n = 0;
+        for (const char* p = devs; *p && n < 64;) {
+            ids[n++] = atoi(p);
+            while (*p && *p != ',') p++;
+            if (*p == ',') p++;
+        }
+        rc = rthip_group_create(&tracer->group, n, ids);
+        if (rc == RTHIP_OK) tracer->ctx = rthip_group_ctx(tracer->group, 0);
+    } else {
+        const char* dev = getenv("RT_HIP_DEVICE");
+        rc = rthip_create(&tracer->ctx, dev ? atoi(dev) : 0);
+    }
     if (rc != RTHIP_OK) fprintf(stderr, "rthip: no usable MI355X (gfx950) device; this backend has no CPU path\n");
     AssertAlways(rc == RTHIP_OK);
-    rt_hip_check(tracer, rthip_set_tracer(tracer->ctx, settings.max_bounces, settings.sky ? 1 : 0), "rthip_set_tracer");
+    if (tracer->group) rt_hip_check(tracer, rthip_group_set_tracer(tracer->group, settings.max_bounces, settings.sky ? 1 : 0), "rthip_group_set_tracer");
+    else rt_hip_check(tracer, rthip_set_tracer(tracer->ctx, settings.max_bounces, settings.sky ? 1 : 0), "rthip_set_tracer");
     // lbvh_make normalises centroids by the boxes' bounds in a BUILD_DEBUG build and by the centroids' own in a
     // release build (lbvh.c:97-104): the trees differ, so the backend follows the flavour it is compiled into.
     #if BUILD_DEBUG
-    rt_hip_check(tracer, rthip_set_morton_bounds(tracer->ctx, RTHIP_BOUNDS_BOXES), "rthip_set_morton_bounds");
+    if (tracer->group) rt_hip_check(tracer, rthip_group_set_morton_bounds(tracer->group, RTHIP_BOUNDS_BOXES), "rthip_group_set_morton_bounds");
+    else rt_hip_check(tracer, rthip_set_morton_bounds(tracer->ctx, RTHIP_BOUNDS_BOXES), "rthip_set_morton_bounds");
     #endif
     return rt_hip_tracer_to_handle(tracer);
 }
@@ -116,7 +136,8 @@ rt_hook void rt_tracer_build_blas(RT_Handle handle, RT_World* world) {
 
     u32 count = 0;
     for EachList(node, RT_MeshNode, meshes->first) count++;
-    rt_hip_check(tracer, rthip_blas_begin(tracer->ctx, count), "rthip_blas_begin");
+    if (tracer->group) rt_hip_check(tracer, rthip_group_blas_begin(tracer->group, count), "rthip_group_blas_begin");
+    else rt_hip_check(tracer, rthip_blas_begin(tracer->ctx, count), "rthip_blas_begin");
 
     u32 idx = 0;
     for EachList(node, RT_MeshNode, meshes->first) {
@@ -125,14 +146,21 @@ rt_hook void rt_tracer_build_blas(RT_Handle handle, RT_World* world) {
         u32 stride = (u32)geo_vertex_stride(mesh->attrs, GEO_VertexAttributes_P);
         u32 pos_off = (u32)geo_vertex_offset(mesh->attrs, GEO_VertexAttributes_P);
         s32 nrm_off = (mesh->attrs & GEO_VertexAttributes_N) ? (s32)geo_vertex_offset(mesh->attrs, GEO_VertexAttributes_N) : -1;
-        rt_hip_check(tracer,
-                     rthip_blas_add_mesh(tracer->ctx, idx, mesh->vertices, mesh->vertices_count, stride, pos_off, nrm_off,
-                                         mesh->indices, mesh->indices_count),
-                     "rthip_blas_add_mesh");
+        if (tracer->group)
+            rt_hip_check(tracer,
+                         rthip_group_blas_add_mesh(tracer->group, idx, mesh->vertices, mesh->vertices_count, stride, pos_off, nrm_off,
+                                                   mesh->indices, mesh->indices_count),
+                         "rthip_group_blas_add_mesh");
+        else
+            rt_hip_check(tracer,
+                         rthip_blas_add_mesh(tracer->ctx, idx, mesh->vertices, mesh->vertices_count, stride, pos_off, nrm_off,
+                                             mesh->indices, mesh->indices_count),
+                         "rthip_blas_add_mesh");
         mesh->blas_id = idx;
         idx++;
     }
-    rt_hip_check(tracer, rthip_blas_commit(tracer->ctx), "rthip_blas_commit");
+    if (tracer->group) rt_hip_check(tracer, rthip_group_blas_commit(tracer->group), "rthip_group_blas_commit");
+    else rt_hip_check(tracer, rthip_blas_commit(tracer->ctx), "rthip_blas_commit");
 
 #if BUILD_DEBUG
     // "<mesh name>.bvh" per named mesh, as the CPU backend writes them (raytracer_cpu.c:92-97)
@@ -228,7 +256,8 @@ rt_hook void rt_tracer_build_tlas(RT_Handle handle, RT_World* world) {
             }
             ii++;
         }
-        rt_hip_check(tracer, rthip_tlas_build(tracer->ctx, insts, inst_count, mats, mat_count), "rthip_tlas_build");
+        if (tracer->group) rt_hip_check(tracer, rthip_group_tlas_build(tracer->group, insts, inst_count, mats, mat_count), "rthip_group_tlas_build");
+        else rt_hip_check(tracer, rthip_tlas_build(tracer->ctx, insts, inst_count, mats, mat_count), "rthip_tlas_build");
     }}
 
     // The CPU backend writes the TLAS to "out.bvh" in every build flavour (its guard is `#ifdef BUILD_DEBUG`,
@@ -244,7 +273,8 @@ rt_hook void rt_tracer_build_tlas(RT_Handle handle, RT_World* world) {
 rt_hook void rt_tracer_cleanup(RT_Handle handle) {
     RT_HIP_Tracer* tracer = rt_hip_handle_to_tracer(handle);
     free(tracer->material_handles);
-    rthip_destroy(tracer->ctx);
+    if (tracer->group) rthip_group_destroy(tracer->group);
+    else rthip_destroy(tracer->ctx);
     arena_release(tracer->arena);
 }
 
@@ -268,7 +298,9 @@ rt_hook void rt_tracer_cast(RT_Handle handle, RT_CastSettings settings, vec3_f32
 
     u64 seed = tracer->seed + tracer->casts;
     tracer->casts++;
-    rt_hip_check(tracer, rthip_cast(tracer->ctx, &c, seed, &out_radiance[0].v[0], width, height), "rthip_cast");
+    if (tracer->group) rt_hip_check(tracer, rthip_group_cast(tracer->group, &c, seed, &out_radiance[0].v[0], width, height, 1), "rthip_group_cast");
+    else rt_hip_check(tracer, rthip_cast(tracer->ctx, &c, seed, &out_radiance[0].v[0], width, height), "rthip_cast");
+    tracer->last_frame = &out_radiance[0].v[0];
 
     const char* dump = getenv("RT_HIP_DUMP_F32");
     if (dump) {
@@ -299,7 +331,8 @@ internal int rt_hip_write_hdr(RT_Handle handle, const char* path, int width, int
     {DeferResource(Temp scratch = scratch_begin(NULL, 0), scratch_end(scratch)) {
         u64 capacity = rthip_hdr_bound(width, height), size = 0;
         u8* bytes = push_array(scratch.arena, u8, capacity + 1);
-        int rc = rthip_hdr_encode(tracer->ctx, NULL, width, height, bytes, capacity, &size);
+        // one GPU: the frame of the last cast is still in its memory; several: it was assembled in the caller's buffer
+        int rc = rthip_hdr_encode(tracer->ctx, tracer->group ? tracer->last_frame : NULL, width, height, bytes, capacity, &size);
         if (rc != RTHIP_OK) {
             fprintf(stderr, "rthip: rthip_hdr_encode failed (%d): %s\n", rc, rthip_last_error(tracer->ctx));
         } else {

@@ -14,7 +14,9 @@
 typedef struct RT_HIP_Tracer RT_HIP_Tracer;
 struct RT_HIP_Tracer {
     Arena* arena;
-    rthip_ctx* ctx;
+    rthip_ctx* ctx;         // the GPU context (with several GPUs: the first device's, for dumps and the .hdr encoder)
+    rthip_group* group;     // RT_HIP_DEVICES=0,1,...: one context per listed GPU, every cast split by tiles; else NULL
+    const float* last_frame;  // the caller's framebuffer of the last cast (the group's frame lives on the host only)
     u8 max_bounces;
     bool sky;
     u64 seed;   // first rand() after the caller's srand(): seeds the GPU generator

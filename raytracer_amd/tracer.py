@@ -290,3 +290,65 @@ def set_traversal(tracer: RT_Tracer, mode: str) -> None:
     """"exact": the reference's fixed left-before-right walk (default, bit-identical results); "fast": nearer child
     first with a per-lane stack (see include/rthip.h at rthip_set_traversal)."""
     tracer.check(tracer.lib.rthip_set_traversal(tracer.h, TRAVERSALS[mode]), "rthip_set_traversal")
+
+
+class RT_TracerGroup:
+    """Several GPUs of one node behind the five hooks (rthip_group_*): one context per device id, the scene replicated,
+    every cast split by tiles (bit-identical to one GPU) or by samples."""
+
+    def __init__(self, device_ids, settings: RT_TracerSettings, shard: str = "tiles"):
+        self.lib = abi.load()
+        ids = (C.c_int * len(device_ids))(*device_ids)
+        g = C.c_void_p()
+        rc = self.lib.rthip_group_create(C.byref(g), len(device_ids), ids)
+        if rc != 0 or not g.value:
+            raise RTHipError(f"rthip_group_create failed with code {rc}")
+        self.g = g
+        self.shard_mode = {"tiles": 1, "samples": 2}[shard]
+        self.check(self.lib.rthip_group_set_tracer(self.g, int(settings.max_bounces), 1 if settings.sky else 0), "rthip_group_set_tracer")
+
+    def check(self, rc: int, what: str):
+        if rc != 0:
+            msg = self.lib.rthip_group_last_error(self.g)
+            raise RTHipError(f"{what}: code {rc}: {msg.decode() if msg else ''}")
+
+    def ctx(self, rank: int) -> RT_Tracer:
+        """A borrowed view of one device's context (for taps and per-context settings); do not close it."""
+        t = RT_Tracer.__new__(RT_Tracer)
+        t.lib = self.lib
+        t.h = C.c_void_p(self.lib.rthip_group_ctx(self.g, rank))
+        t.close = lambda: None
+        return t
+
+    def build_blas(self, world: RT_World) -> None:
+        meshes = flatten_meshes(world)
+        self.check(self.lib.rthip_group_blas_begin(self.g, len(meshes)), "rthip_group_blas_begin")
+        for blas_id, m in enumerate(meshes):
+            idx = m["indices"]
+            self.check(self.lib.rthip_group_blas_add_mesh(self.g, blas_id, abi.ptr(m["verts"]), m["vertex_count"], m["stride"], m["pos_off"],
+                                                          m["nrm_off"], abi.ptr(idx) if idx is not None else None,
+                                                          0 if idx is None else idx.size), "rthip_group_blas_add_mesh")
+        self.check(self.lib.rthip_group_blas_commit(self.g), "rthip_group_blas_commit")
+
+    def build_tlas(self, world: RT_World) -> None:
+        flat = flatten_world(world)
+        inst = np.ascontiguousarray(flat.instances, dtype=abi.INSTANCE)
+        mats = np.ascontiguousarray(flat.materials, dtype=abi.MATERIAL)
+        self.check(self.lib.rthip_group_tlas_build(self.g, abi.ptr(inst), inst.size, abi.ptr(mats), mats.size), "rthip_group_tlas_build")
+
+    def cast(self, settings: np.ndarray, out_radiance: np.ndarray, width: int, height: int, seed: int = 0) -> None:
+        cast = np.ascontiguousarray(settings, dtype=abi.CAST).reshape(1)
+        assert out_radiance.dtype == np.float32 and out_radiance.size == width * height * 3
+        self.check(self.lib.rthip_group_cast(self.g, abi.ptr(cast), int(seed) & (2**64 - 1), abi.ptr(out_radiance), width, height,
+                                             self.shard_mode), "rthip_group_cast")
+
+    def close(self):
+        if getattr(self, "g", None) is not None and self.g.value:
+            self.lib.rthip_group_destroy(self.g)
+            self.g = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -968,6 +968,48 @@ def test_cast_into_page_locked_host_memory(gpu_tracer):
         gpu_tracer.check(gpu_tracer.lib.rthip_host_free(gpu_tracer.h, plain.ctypes.data), "rthip_host_free")
 
 
+def test_group_of_contexts_renders_the_single_context_frame(gpu_tracer):
+    """rthip_group_*: several contexts (here on one GPU) behind one handle.  Tiles: each context renders and ships only its
+    own 64x64 tiles and the frame is the single context's bit for bit, into host memory and into device memory; samples:
+    the partial sums are added in rank order.  Ragged frame sizes, more ranks than tiles, a one-context group."""
+    import torch
+
+    verts, indices = scenes.bunny_class_mesh(3)
+    w, cam, sky = scenes.cornell(extra_mesh=(verts, indices))
+    build(gpu_tracer, w, 6, sky)
+    settings = T.RT_TracerSettings(max_bounces=6, sky=sky)
+    for ids, sizes in (((0, 0), ((200, 150), (64, 64), (65, 129))), ((0, 0, 0, 0, 0), ((130, 70),)), ((0,), ((100, 90),))):
+        for shard in ("tiles", "samples"):
+            g = T.RT_TracerGroup(ids, settings, shard)
+            try:
+                g.build_blas(w)
+                g.build_tlas(w)
+                assert g.lib.rthip_group_size(g.g) == len(ids)
+                for wd, ht in sizes:
+                    c = cam(wd, ht, 2)
+                    want = np.zeros((ht, wd, 3), dtype=np.float32)
+                    T.rt_tracer_cast(gpu_tracer, c, want, wd, ht, seed=11)
+                    got = np.full((ht, wd, 3), -1.0, dtype=np.float32)
+                    g.cast(c, got, wd, ht, seed=11)
+                    dev = torch.full((ht, wd, 3), -1.0, dtype=torch.float32, device="cuda:0")
+                    g.check(g.lib.rthip_group_cast_device(g.g, abi.ptr(np.ascontiguousarray(c, dtype=abi.CAST).reshape(1)), 11,
+                                                          dev.data_ptr(), wd, ht, g.shard_mode), "rthip_group_cast_device")
+                    torch.cuda.synchronize()
+                    if shard == "tiles" or len(ids) == 1:
+                        assert (bits(got) == bits(want)).all(), (ids, shard, wd, ht)
+                        assert (bits(dev.cpu().numpy()) == bits(want)).all(), (ids, shard, wd, ht, "device")
+                    else:
+                        assert np.allclose(got, want, rtol=2e-6, atol=1e-7) and np.allclose(dev.cpu().numpy(), want, rtol=2e-6, atol=1e-7)
+                        assert (bits(dev.cpu().numpy()) == bits(got)).all()  # both paths add in rank order
+                # the same tree on every context, and per-context taps work through the group
+                t0, t1 = g.ctx(0), g.ctx(len(ids) - 1)
+                assert T.get_tree(t0, -1).tobytes() == T.get_tree(t1, -1).tobytes() == T.get_tree(gpu_tracer, -1).tobytes()
+            finally:
+                g.close()
+    with pytest.raises(T.RTHipError):
+        T.RT_TracerGroup((0, 99), settings)
+
+
 def test_shards_sum_to_the_frame(oracle, gpu_tracer):
     import ctypes as C
 

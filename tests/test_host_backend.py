@@ -67,6 +67,30 @@ def test_reference_demo_binary_renders_through_the_backend(gpu_tracer, tmp_path,
 
 
 @pytest.mark.gpu
+def test_reference_demo_binary_on_a_group_of_contexts(tmp_path):
+    """RT_HIP_DEVICES puts several GPUs behind the same five hooks (here three contexts on the one GPU of the box): the
+    reference's cornell program must render the bits it renders on one context, write the same out.bvh, and the GPU
+    .hdr writer the same file."""
+    exe = os.path.join(BUILD, "cornell_hip")
+    if not os.path.exists(exe):
+        pytest.skip("demo binaries are only built where the reference checkout exists")
+    args = ["--width=200", "--height=150", "--samples=2", "--bounces=8", "--seed=9"]
+    frames = {}
+    for name, devices in (("one", None), ("group", "0,0,0")):
+        d = tmp_path / name
+        d.mkdir()
+        env = dict(os.environ, RT_HIP_DUMP_F32=str(d / "frame.f32"), RT_HIP_HDR=str(d / "gpu.hdr"))
+        env.pop("RT_HIP_DEVICES", None)
+        if devices:
+            env["RT_HIP_DEVICES"] = devices
+        subprocess.check_call([exe, str(d / "out.hdr")] + args, cwd=str(d), env=env, timeout=120)
+        frames[name] = (d / "frame.f32").read_bytes()
+        assert (d / "gpu.hdr").read_bytes() == (d / "out.hdr").read_bytes()
+    assert frames["one"] == frames["group"] and len(frames["one"]) == 200 * 150 * 12
+    assert (tmp_path / "one" / "out.bvh").read_bytes() == (tmp_path / "group" / "out.bvh").read_bytes()
+
+
+@pytest.mark.gpu
 def test_bunny_demo_with_gpu_loader_and_gpu_hdr_writer(gpu_tracer, tmp_path):
     """The reference's bunny demo with its two host-side I/O calls swapped for the backend's (ms_load_obj ->
     rt_hip_load_obj, stbi_write_hdr -> rt_hip_write_hdr; raytracer_amd/host/Makefile): data/bunny.obj is the stand-in
