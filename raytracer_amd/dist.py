@@ -2,8 +2,9 @@
 ROCm, "gloo" for CPU rehearsals).  The BVH is replicated (every rank builds it); only the framebuffer
 is exchanged, once per frame:
 
-  tiles    every rank renders the 64x64 tiles t with t % world == rank, other pixels stay 0, so the
-           element-wise SUM of the shares is the frame (bit-identical to a single-GPU render);
+  tiles    every rank renders the 64x64 tiles t with t % world == rank, other pixels stay 0; the shares
+           are disjoint, so every rank sends only its own tiles' pixels (1/world of the frame, one gather)
+           and the destination places them: bit-identical to a single-GPU render;
   samples  every rank renders the sample indices s with s % world == rank of every pixel and leaves
            the plain sum; SUM over ranks then one multiply by 1/samples^2 gives the frame up to
            rounding (the sum is taken in another order than a single GPU's sample loop: equal to a few
@@ -32,6 +33,8 @@ def combine_framebuffer(fb, mode: str, samples: int, world: int, dst: int = 0):
     there.  `fb` is a torch tensor on the backend's device.  Returns fb (meaningful on dst only)."""
     import torch.distributed as dist
 
+    if world > 1 and mode == "tiles" and fb.dim() == 3:
+        return gather_tiles(fb, fb.shape[1], fb.shape[0], world, dst)  # disjoint shares: moved, not added
     if world > 1:
         dist.reduce(fb, dst=dst, op=dist.ReduceOp.SUM)
         if dist.get_rank() == dst:
@@ -39,6 +42,54 @@ def combine_framebuffer(fb, mode: str, samples: int, world: int, dst: int = 0):
                 fb.mul_(1.0 / float(samples * samples))
             elif mode == "frames":
                 fb.mul_(1.0 / float(world))
+    return fb
+
+
+_TILE = 64  # rthip_shard's tile edge
+_tile_index_cache = {}
+
+
+def tile_pixels(width: int, height: int, rank: int, world: int, device="cpu"):
+    """Flat pixel indices (row-major, torch int64 on `device`) of the pixels a rank renders in tile mode: its 64x64 tiles
+    t % world == rank in tile order, each tile's pixels row by row (tiles at the right and bottom edge are clipped)."""
+    import torch
+
+    key = (width, height, rank, world, str(device))
+    if key not in _tile_index_cache:
+        tx, ty = -(-width // _TILE), -(-height // _TILE)
+        parts = []
+        for t in range(rank, tx * ty, world):
+            x0, y0 = (t % tx) * _TILE, (t // tx) * _TILE
+            ys = np.arange(y0, min(y0 + _TILE, height))[:, None]
+            xs = np.arange(x0, min(x0 + _TILE, width))[None, :]
+            parts.append((ys * width + xs).reshape(-1))
+        idx = np.concatenate(parts) if parts else np.zeros(0, dtype=np.int64)
+        _tile_index_cache[key] = torch.from_numpy(idx.astype(np.int64)).to(device)
+    return _tile_index_cache[key]
+
+
+def gather_tiles(fb, width: int, height: int, world: int, dst: int = 0):
+    """Tile mode: every rank sends only the pixels of its own tiles (1/world of the frame) and `dst` places them; the
+    frame on `dst` is then complete, bit-identical to a single-GPU render (the shares are disjoint, nothing is added).
+    `fb` is this rank's framebuffer [height, width, 3] on the backend's device.  One collective (gather)."""
+    import torch
+    import torch.distributed as dist
+
+    if world == 1:
+        return fb
+    rank = dist.get_rank()
+    flat = fb.view(-1, 3)
+    counts = [int(tile_pixels(width, height, r, world, "cpu").numel()) for r in range(world)]
+    longest = max(counts)
+    send = torch.zeros((longest, 3), dtype=fb.dtype, device=fb.device)
+    mine = tile_pixels(width, height, rank, world, fb.device)
+    send[: counts[rank]] = flat[mine]
+    recv = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
+    dist.gather(send, recv, dst=dst)
+    if rank == dst:
+        for r in range(world):
+            if r != rank and counts[r]:
+                flat[tile_pixels(width, height, r, world, fb.device)] = recv[r][: counts[r]]
     return fb
 
 
@@ -71,6 +122,12 @@ class FramePipeline:
         self.next = 0
         self.last = None
 
+    @staticmethod
+    def _gloo() -> bool:
+        import torch.distributed as dist
+
+        return dist.get_backend() == "gloo"
+
     def _finish(self, k: int) -> None:
         work = self.pending[k]
         if work is None:
@@ -93,7 +150,11 @@ class FramePipeline:
     def submit(self, fb) -> None:
         k = self.next
         assert fb is self.buffers[k], "submit the buffer acquire() returned"
-        if self.world > 1:
+        if self.world > 1 and self.mode == "tiles" and not (fb.is_cuda and self._gloo()):
+            # disjoint shares: one gather of 1/world of the frame per rank; stream-ordered on RCCL, blocking on gloo
+            gather_tiles(fb, fb.shape[1], fb.shape[0], self.world, self.dst)
+            self.pending[k] = None
+        elif self.world > 1:
             import torch.distributed as dist
 
             if fb.is_cuda and dist.get_backend() == "gloo":

@@ -83,3 +83,7 @@ def test_two_ranks_start_themselves():
     d = run_bench("--gpus", "2", "--backend", "gloo", "--steps", "3", "--warmup", "1", "--width", "256", "--height", "144",
                   "--no-cpu-baseline", "--build-sizes", "")
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and d["scaling"] == "weak"
+    for shard in ("tiles", "samples"):  # one frame split over the ranks, a combined frame delivered per step
+        d = run_bench("--gpus", "2", "--backend", "gloo", "--shard", shard, "--workload", "cornell", "--steps", "3", "--warmup", "1",
+                      "--width", "192", "--height", "128", "--no-cpu-baseline", "--build-sizes", "")
+        assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0

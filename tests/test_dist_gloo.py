@@ -58,9 +58,21 @@ def _full(seed):
 
 
 def test_tile_shards_reproduce_the_frame(tmp_path):
+    """Tiles are gathered (every rank sends the pixels of its own tiles only), not summed: the frame's own bits."""
     got = _run("tiles", tmp_path)
     want = _full(5)
-    assert ((got + np.float32(0)).view(np.uint32) == (want + np.float32(0)).view(np.uint32)).all()
+    assert (got.view(np.uint32) == want.view(np.uint32)).all()
+
+
+def test_tile_pixels_partition_the_frame():
+    for (w, h, world) in ((96, 80, 2), (200, 130, 3), (64, 64, 4), (1, 1, 2), (129, 65, 5)):
+        seen = np.zeros(w * h, dtype=np.int32)
+        for r in range(world):
+            idx = rdist.tile_pixels(w, h, r, world).numpy()
+            seen[idx] += 1
+            ys, xs = idx // w, idx % w
+            assert ((((ys // 64) * (-(-w // 64)) + xs // 64) % world) == r).all()
+        assert (seen == 1).all()
 
 
 def test_sample_shards_sum_to_the_frame(tmp_path):
