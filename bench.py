@@ -53,6 +53,11 @@ def make_workload(name: str):
         w, cam, sky = scenes.soup_world(10_000_000, seed=1)
         return dict(world=w, cam=cam, sky=sky, width=1920, height=1080, samples=1, bounces=4,
                     label="10M-triangle soup (1 BLAS), 1920x1080, samples=1, bounces=4, sky on")
+    if name == "heightfield":
+        w, cam, sky = scenes.heightfield_world(3163, seed=1)
+        return dict(world=w, cam=cam, sky=sky, width=1920, height=1080, samples=1, bounces=4,
+                    label="10M-triangle displaced height field (3163^2 x 2 triangles, 1 indexed BLAS: a coherent surface), "
+                          "1920x1080, samples=1, bounces=4, sky on")
     if name == "soup-rays":
         w, cam, sky = scenes.soup_world(10_000_000, seed=1)
         return dict(world=w, cam=cam, sky=sky, width=4096, height=4096, samples=1, bounces=1, rays=1 << 24,
@@ -770,6 +775,7 @@ EXTRA_RUNS = [
     ("instanced_one_stream", "instanced", 1, 6, 1),
     ("soup", "soup", 4, 12, 2),
     ("soup_rays", "soup-rays", 1, 3, 1),
+    ("heightfield", "heightfield", 4, 12, 2),
     ("instanced_rays", "instanced-rays", 4, 8, 2),
     ("cornell", "cornell", 4, 40, 5),
     ("cornell_mesh_4k", "cornell-mesh", 1, 4, 1),

@@ -455,6 +455,42 @@ def soup_world(n_tris: int, seed: int = 1):
     return world, camera, True
 
 
+def heightfield_world(n_side: int = 3163, seed: int = 1):
+    """Configuration 4's coherent variant: a displaced height field over [0,1]^2, n_side x n_side cells of two triangles
+    each (3163^2 x 2 = 10.0 M), one indexed mesh without normals.  Heights are a sum of five seeded sine octaves
+    (amplitude halving, frequency doubling), about +-0.12 around y = 0.2: a connected surface whose Morton order follows
+    its triangle order, unlike the soup."""
+    k = np.arange(n_side + 1, dtype=np.float64) / n_side
+    x, z = np.meshgrid(k, k, indexing="xy")
+    y = np.full_like(x, 0.2)
+    ph = hash_unit(seed, 70, 20) * 2.0 * math.pi
+    for o in range(5):
+        f = 2.0 * math.pi * (1.5 * 2 ** o)
+        y += (0.06 / 2 ** o) * np.sin(f * x + ph[4 * o]) * np.sin(f * z + ph[4 * o + 1])
+        y += (0.03 / 2 ** o) * np.sin(0.7 * f * (x + z) + ph[4 * o + 2]) * np.cos(1.3 * f * (x - z) + ph[4 * o + 3])
+    verts = np.zeros(((n_side + 1) ** 2, 4), dtype=np.float32)
+    verts[:, 0], verts[:, 1], verts[:, 2] = x.reshape(-1), y.reshape(-1), z.reshape(-1)
+    del x, y, z
+    row = np.arange(n_side, dtype=np.uint32)
+    v00 = (row[:, None] * np.uint32(n_side + 1) + row[None, :]).reshape(-1)  # cell (row r, column c): vertex r * (n + 1) + c
+    idx = np.empty((n_side * n_side, 6), dtype=np.uint32)
+    idx[:, 0], idx[:, 1], idx[:, 2] = v00, v00 + np.uint32(n_side + 1), v00 + np.uint32(1)
+    idx[:, 3], idx[:, 4], idx[:, 5] = v00 + np.uint32(1), v00 + np.uint32(n_side + 1), v00 + np.uint32(n_side + 2)
+    world = rt_make_world()
+    m = rt_world_add_mesh(world)
+    _set_mesh(m, verts, idx.reshape(-1), GEO_P)
+    mat = rt_world_add_material(world)
+    mat.type, mat.albedo, mat.billboard = abi.MAT_LAMBERTIAN, v3(0.73, 0.73, 0.73), True
+    it = rt_world_add_instance(world)
+    it.type, it.material, it.mesh = abi.INST_MESH, mat, m
+    it.translation, it.rotation, it.scale = v3(0, 0, 0), IDENTITY_QUAT, v3(1, 1, 1)
+
+    def camera(width, height, samples):
+        return get_rt_cast_settings(width, height, samples, (0.5, 0.75, 0.95), (0.5, 0.2, 0.5), vfov=degrees_to_rad(45))
+
+    return world, camera, True
+
+
 def random_rays(n: int, seed: int, lo=(0.0, 0.0, 0.0), hi=(1.0, 1.0, 1.0)):
     """'Incoherent' rays: origin uniform in the box [lo,hi], direction uniform on the sphere
     (rejection-free: z uniform, azimuth by a rational parametrisation), float32, unit length."""

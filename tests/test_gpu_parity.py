@@ -726,6 +726,40 @@ def test_soup_scene_rays_and_frames(oracle, gpu_tracer):
         T.set_cast_kernel(gpu_tracer, "auto")
 
 
+def test_heightfield_scene(oracle, gpu_tracer):
+    """The coherent variant of the 10 M-triangle configuration in small (a 150 x 150-cell displaced height field, indexed):
+    tree, rays with counters, frames from every kernel, and the ordered walk, against the oracle."""
+    w, cam, sky = scenes.heightfield_world(150, seed=1)
+    build(gpu_tracer, w, 4, sky)
+    flat = world.flatten_world(w)
+    sc = oracle.Scene(flat, 4, sky)
+    assert_same_tree(T.get_tree(gpu_tracer, 0), sc.tree(0), "height field BLAS")
+    o, d = scenes.random_rays(30_000, seed=4, lo=(0.0, 0.35, 0.0), hi=(1.0, 0.6, 1.0))
+    d[:, 1] = -np.abs(d[:, 1])  # downwards: most of them reach the surface
+    T.set_counting(gpu_tracer, True)
+    T.get_stats(gpu_tracer)
+    inst, tri, t, uv, nrm = T.trace_rays(gpu_tracer, o, d)
+    st = T.get_stats(gpu_tracer)
+    T.set_counting(gpu_tracer, False)
+    oi, ot, ott, ouv, onrm, cnt = sc.trace(o, d, threads=8)
+    assert (inst == oi).all() and (tri == ot).all() and (bits(t) == bits(ott)).all()
+    assert (bits(uv) == bits(ouv)).all() and (bits(nrm) == bits(onrm)).all() and int((inst > 0).sum()) > 10_000
+    for k in ("rays", "nodes_tested", "tris_tested", "inst_entered"):
+        assert st[k] == cnt[k], f"traversal counter {k}: {st[k]} vs {cnt[k]}"
+    t_diff, prim_diff, hit_miss, _, _ = fast_vs_exact_rays(gpu_tracer, o, d)
+    assert t_diff == 0 and hit_miss == 0 and prim_diff <= 30, (t_diff, prim_diff, hit_miss)  # shared edges: ties between neighbours
+    c = cam(96, 54, 2)
+    want, _ = sc.cast(c, 8, 96, 54, rng_mode=oracle.RNG_COUNTER, threads=8)
+    try:
+        for kernel in ("static", "persistent", "static-samples", "auto"):
+            T.set_cast_kernel(gpu_tracer, kernel)
+            img = np.zeros((54, 96, 3), dtype=np.float32)
+            T.rt_tracer_cast(gpu_tracer, c, img, 96, 54, seed=8)
+            assert (bits(img) == bits(want)).all(), kernel
+    finally:
+        T.set_cast_kernel(gpu_tracer, "auto")
+
+
 def test_ten_million_triangle_soup_incoherent_rays(oracle, gpu_tracer):
     """The benchmark's 10 M-triangle scene and its ray stream (2^24 incoherent rays, seed 2) at full size: the plain
     ray kernel (the one such a scene takes by default) and the resident-wave kernel must agree on every ray bit for bit,

@@ -91,7 +91,7 @@ def frame_case(tr, cam, W, H, samples, label, out, kernels=("auto",)):
 
 
 def main():
-    names = sys.argv[1:] or ["cornell", "bunny", "instanced", "soup"]
+    names = sys.argv[1:] or ["cornell", "bunny", "instanced", "soup", "heightfield"]
     out = []
     for name in names:
         if name == "cornell":
@@ -106,6 +106,9 @@ def main():
             bounces = 8
         elif name == "soup":
             w, cam, sky = scenes.soup_world(10_000_000, seed=1)
+            bounces = 4
+        elif name == "heightfield":
+            w, cam, sky = scenes.heightfield_world(3163, seed=1)
             bounces = 4
         tr = T.rt_make_tracer(T.RT_TracerSettings(max_bounces=bounces, sky=sky))
         T.rt_tracer_build_blas(tr, w)
@@ -128,6 +131,10 @@ def main():
             rays_case(tr, o[:100_000].contiguous(), d[:100_000].contiguous(), "10M soup, first 10^5 incoherent rays", out)
             rays_case(tr, o, d, "10M soup, 2^24 incoherent rays", out)
             frame_case(tr, cam, 1920, 1080, 1, "10M soup 1080p 1 spp 4 bounces", out, ("auto", "static", "persistent"))
+        elif name == "heightfield":
+            o, d = scenes.incoherent_rays_device(torch, 1 << 22, 2, (0.0, 0.0, 0.0), (1.0, 0.6, 1.0))
+            rays_case(tr, o, d, "10M height field, 2^22 incoherent rays", out)
+            frame_case(tr, cam, 1920, 1080, 1, "10M height field 1080p 1 spp 4 bounces", out, ("auto", "static", "persistent"))
         T.rt_tracer_cleanup(tr)
     with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "probe_fast.json"), "w") as f:
         json.dump(out, f, indent=1)
