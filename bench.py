@@ -383,6 +383,9 @@ def parse_args(argv=None):
                          "inside the timed region): a frame's first waves run while the previous frames' last waves drain.  "
                          "1 = strictly one launch after the other.  Only with --combine end (progressive accumulation) and "
                          "for ray streams; --combine every delivers frames in order on one stream")
+    ap.add_argument("--traversal", default="exact", choices=["exact", "fast"],
+                    help="exact: the reference's fixed left-before-right walk (bit-identical results, the headline); fast: "
+                         "the opt-in ordered walk (rthip_set_traversal)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-workloads", action="store_true",
                     help="default workload at N = 1 only: skip the `workloads` object (the other BASELINE configurations, the "
@@ -483,7 +486,7 @@ def cached_workload(name):
 
 
 def measure(args, name, steps, warmup, n_streams_arg, rank, world, device_index, want_cpu, cpu_budget_s=20.0, cpu_max_paths=1 << 21,
-            extras=True):
+            extras=True, traversal=None):
     """One workload: scene build, counted launches, warm-up, the timed steps, and the figures derived from them."""
     import torch
     import torch.distributed as dist
@@ -499,6 +502,10 @@ def measure(args, name, steps, warmup, n_streams_arg, rank, world, device_index,
     wl["label"] += f", samples={wl['samples']}" if "samples=" not in wl["label"] else ""
     W, H = wl["width"], wl["height"]
     tr = T.rt_make_tracer(T.RT_TracerSettings(max_bounces=wl["bounces"], sky=wl["sky"]), device_id=device_index)
+    traversal = traversal or args.traversal
+    if traversal == "fast":
+        T.set_traversal(tr, "fast")
+        wl["label"] += " [RTHIP_TRAV_FAST: ordered walk, results equal up to ties and seam rays]"
     T.rt_tracer_build_blas(tr, wl["world"])
     blas_ms = T.get_stats(tr)["last_build_ms"]
     T.rt_tracer_build_tlas(tr, wl["world"])
@@ -658,12 +665,13 @@ def measure(args, name, steps, warmup, n_streams_arg, rank, world, device_index,
                    2: "wf_trace_kernel + wf_shade_kernel (wavefront)"}[last["last_cast_kernel"]]
     if ray_o is not None:
         kernel_name = "trace_rays_kernel"
-    traffic = recorded_traffic(name, kernel_name)
+    table_key = name + ("+fast" if traversal == "fast" else "")
+    traffic = recorded_traffic(table_key, kernel_name)
     if ray_o is not None and traffic is None:  # deep scenes: the library takes the ray stream's persistent kernel
-        traffic = recorded_traffic(name, "trace_rays_persistent_kernel")
+        traffic = recorded_traffic(table_key, "trace_rays_persistent_kernel")
         if traffic is not None:
             kernel_name = "trace_rays_persistent_kernel"
-    valu_insts = recorded_valu_insts(name, kernel_name)
+    valu_insts = recorded_valu_insts(table_key, kernel_name)
     line = None
     if rank == 0:
         value = total_rays * steps / elapsed / 1e6
@@ -770,15 +778,22 @@ def host_cast_figure(tr, cast, W, H, rays, reps=8):
 # The other BASELINE configurations and views of the default one, each a short run of its own inside the default
 # `python bench.py` so that the driver's record holds them: (key, workload, streams, steps, warm-up)
 EXTRA_RUNS = [
-    ("bunny_one_stream", "bunny", 1, 40, 5),
-    ("instanced", "instanced", 4, 12, 2),
-    ("instanced_one_stream", "instanced", 1, 6, 1),
-    ("soup", "soup", 4, 12, 2),
-    ("soup_rays", "soup-rays", 1, 3, 1),
-    ("heightfield", "heightfield", 4, 12, 2),
-    ("instanced_rays", "instanced-rays", 4, 8, 2),
-    ("cornell", "cornell", 4, 40, 5),
-    ("cornell_mesh_4k", "cornell-mesh", 1, 4, 1),
+    ("bunny_one_stream", "bunny", 1, 40, 5, "exact"),
+    ("instanced", "instanced", 4, 12, 2, "exact"),
+    ("instanced_one_stream", "instanced", 1, 6, 1, "exact"),
+    ("soup", "soup", 4, 12, 2, "exact"),
+    ("soup_rays", "soup-rays", 1, 3, 1, "exact"),
+    ("heightfield", "heightfield", 4, 12, 2, "exact"),
+    ("instanced_rays", "instanced-rays", 4, 8, 2, "exact"),
+    ("cornell", "cornell", 4, 40, 5, "exact"),
+    ("cornell_mesh_4k", "cornell-mesh", 1, 4, 1, "exact"),
+    # the opt-in ordered walk (rthip_set_traversal(RTHIP_TRAV_FAST)) on the deep scenes
+    ("bunny_fast", "bunny", 4, 40, 5, "fast"),
+    ("instanced_fast", "instanced", 4, 12, 2, "fast"),
+    ("instanced_rays_fast", "instanced-rays", 4, 8, 2, "fast"),
+    ("soup_fast", "soup", 4, 12, 2, "fast"),
+    ("soup_rays_fast", "soup-rays", 1, 3, 1, "fast"),
+    ("heightfield_fast", "heightfield", 4, 12, 2, "fast"),
 ]
 
 
@@ -823,12 +838,13 @@ def main():
 
     want_cpu = not args.no_cpu_baseline and world == 1  # the CPU baseline is reported at N = 1 only
     line = measure(args, args.workload, args.steps, args.warmup, args.streams, rank, world, device_index, want_cpu)
-    default_run = args.workload == "bunny" and world == 1 and not args.no_workloads and args.samples == 0 and args.width == 0
+    default_run = (args.workload == "bunny" and world == 1 and not args.no_workloads and args.samples == 0 and args.width == 0
+                   and args.traversal == "exact")
     if rank == 0 and default_run:
         others = {}
-        for key, name, n_streams, steps, warmup in EXTRA_RUNS:
-            sub = measure(args, name, steps, warmup, n_streams, rank, world, device_index, want_cpu, cpu_budget_s=4.0,
-                          cpu_max_paths=1 << 17, extras=False)
+        for key, name, n_streams, steps, warmup, traversal in EXTRA_RUNS:
+            sub = measure(args, name, steps, warmup, n_streams, rank, world, device_index, want_cpu and traversal == "exact",
+                          cpu_budget_s=4.0, cpu_max_paths=1 << 17, extras=False, traversal=traversal)
             others[key] = compact(sub)
         line["workloads"] = others
     if rank == 0:

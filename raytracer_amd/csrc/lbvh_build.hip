@@ -830,14 +830,22 @@ __global__ __launch_bounds__(kChunk) void climb_local_kernel(ClimbArgs A) {
     climb_local<BOXES>(blockIdx.x * (uint32_t)kChunk, A);
 }
 
+// MODE 3: the whole upper climb in ONE workgroup, for builds of up to kOneGroupUpper leaves, where the upper tree is a
+// couple of thousand nodes and the chain of hand-offs is all there is: all threads sit on one CU, so the hand-off is a
+// workgroup-scope release / acquire pair through the counter, which costs no cache maintenance.  Measured: 81 920
+// leaves 21 + 35 us for the two upper climbs instead of 28 + 41 us device-wide; at 10^6 leaves (20 000 upper nodes on
+// 1024 threads) 146 + 301 us instead of 55 + 60 us, hence the limit.
+constexpr uint64_t kOneGroupUpper = 1ull << 17;
+constexpr int kOneGroupThreads = 1024;
+
 template <int MODE, bool BOXES>
-__global__ __launch_bounds__(kBlock) void climb_upper_kernel(ClimbArgs A) {
+__global__ __launch_bounds__(MODE == 3 ? kOneGroupThreads : kBlock) void climb_upper_kernel(ClimbArgs A) {
     // one thread per gap whose two children were both delivered by the local kernel
     constexpr uint32_t kMine = BOXES ? 4096u : 16u;   // this kernel's arrivals
     constexpr int kShift = BOXES ? 8 : 0;             // this climb's two 4-bit fields
     const uint32_t n = A.n;
     const uint32_t count = *A.start_count;
-    for (uint32_t t = blockIdx.x * kBlock + threadIdx.x; t < count; t += gridDim.x * kBlock) {
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < count; t += gridDim.x * blockDim.x) {
         uint32_t parent = A.starters[t];
         uint32_t l, r, dl;
         float box[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -849,28 +857,37 @@ __global__ __launch_bounds__(kBlock) void climb_upper_kernel(ClimbArgs A) {
             l = a.far_end;
             r = b.far_end;
             dl = a.dl + 1;
-            put_inner(A.nodes, A.cnt_l, A.tile_sums, box, l, r, dl, A.paired);
         } else {
             const TopoRec a = A.child_topo[2 * (uint64_t)parent], b = A.child_topo[2 * (uint64_t)parent + 1];
             l = a.far_end;
             r = b.far_end;
             dl = a.dl + 1;
         }
+        // Every level is a chain of memory round trips (this kernel is bound by their latency, not by bytes), so what does
+        // not depend on each other is asked for together: the two priorities that name the parent and the prefix that
+        // places the node just finished.
         for (;;) {
-            if (l == 0 && r == n - 1) {
+            const bool root = l == 0 && r == n - 1;
+            const uint32_t pr_r = (r != n - 1) ? (uint32_t)A.prio[r] : 0u;
+            const uint32_t pr_l = (l != 0) ? (uint32_t)A.prio[l - 1] : 0u;
+            if (BOXES) {
+                const uint32_t pre = l + spine_prefix(A.cnt_l, A.tile_sums, l) - dl;
+                put_node(A.nodes, pre, box, pre + 2u * (r - l + 1u) - 1u, 0u, A.paired);
+            }
+            if (root) {
                 if (!BOXES) A.cnt_l[0] = dl;
                 break;
             }
-            const uint32_t pr_r = (r != n - 1) ? (uint32_t)A.prio[r] : 0u;
-            const uint32_t pr_l = (l != 0) ? (uint32_t)A.prio[l - 1] : 0u;
             const bool parent_right = (l == 0) || (r != n - 1 && pr_r > pr_l);
             parent = parent_right ? r : l - 1;
             const uint32_t side = parent_right ? 0u : 1u;
             if (!BOXES && side == 1) A.cnt_l[l] = dl;
-            if (BOXES) child_store<MODE == 1>(&A.child[2 * (uint64_t)parent + side], box, parent_right ? l : r, dl);
-            else topo_store<MODE == 1>(&A.child_topo[2 * (uint64_t)parent + side], parent_right ? l : r, dl);
+            if (BOXES) child_store<MODE == 1 || MODE == 3>(&A.child[2 * (uint64_t)parent + side], box, parent_right ? l : r, dl);
+            else topo_store<MODE == 1 || MODE == 3>(&A.child_topo[2 * (uint64_t)parent + side], parent_right ? l : r, dl);
             uint32_t old;
-            if (MODE == 0) {  // release: the record is visible device-wide before the count
+            if (MODE == 3) {
+                old = __hip_atomic_fetch_add(&A.flags[parent], kMine, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else if (MODE == 0) {  // release: the record is visible device-wide before the count
                 old = __hip_atomic_fetch_add(&A.flags[parent], kMine, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             } else {
                 if (MODE == 1) __threadfence();
@@ -884,10 +901,10 @@ __global__ __launch_bounds__(kBlock) void climb_upper_kernel(ClimbArgs A) {
             uint32_t s_far, s_dl;
             if (BOXES) {
                 float sbox[6];
-                child_load<MODE == 1>(&A.child[2 * (uint64_t)parent + (1u - side)], sbox, &s_far, &s_dl);
+                child_load<MODE == 1 || MODE == 3>(&A.child[2 * (uint64_t)parent + (1u - side)], sbox, &s_far, &s_dl);
                 merge_sibling(box, sbox, side == 0);
             } else {
-                topo_load<MODE == 1>(&A.child_topo[2 * (uint64_t)parent + (1u - side)], &s_far, &s_dl);
+                topo_load<MODE == 1 || MODE == 3>(&A.child_topo[2 * (uint64_t)parent + (1u - side)], &s_far, &s_dl);
             }
             if (side == 0) {
                 r = s_far;
@@ -896,7 +913,6 @@ __global__ __launch_bounds__(kBlock) void climb_upper_kernel(ClimbArgs A) {
                 l = s_far;
                 dl = s_dl + 1;
             }
-            if (BOXES) put_inner(A.nodes, A.cnt_l, A.tile_sums, box, l, r, dl, A.paired);
         }
     }
 }
@@ -1323,7 +1339,8 @@ int lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, float4* 
     if (ublocks > 2048) ublocks = 2048;
 #define RT_UPPER(BOXES)                                                                  \
     do {                                                                                 \
-        if (ctx->refit_fence == 1) climb_upper_kernel<1, BOXES><<<ublocks, kBlock, 0, s>>>(A); \
+        if (n <= kOneGroupUpper && !ctx->upper_device_wide) climb_upper_kernel<3, BOXES><<<1, kOneGroupThreads, 0, s>>>(A); \
+        else if (ctx->refit_fence == 1) climb_upper_kernel<1, BOXES><<<ublocks, kBlock, 0, s>>>(A); \
         else if (ctx->refit_fence == 2) climb_upper_kernel<2, BOXES><<<ublocks, kBlock, 0, s>>>(A); \
         else climb_upper_kernel<0, BOXES><<<ublocks, kBlock, 0, s>>>(A);                 \
     } while (0)

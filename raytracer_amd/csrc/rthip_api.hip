@@ -134,6 +134,8 @@ int rthip_create(rthip_ctx** out_ctx, int device_id) {
     ctx->device = device_id;
     const char* fence = getenv("RTHIP_REFIT_FENCE");
     ctx->refit_fence = (fence && fence[0] >= '0' && fence[0] <= '2') ? fence[0] - '0' : 2;
+    const char* wide = getenv("RTHIP_UPPER_DEVICE_WIDE");
+    ctx->upper_device_wide = (wide && wide[0] == '1') ? 1 : 0;
     const char* mode = getenv("RTHIP_CAST");
     if (mode && strcmp(mode, "static") == 0) ctx->cast_mode = 1;
     if (mode && strcmp(mode, "static-samples") == 0) ctx->cast_mode = 4;

@@ -33,9 +33,13 @@ def main(src: str, dst: str) -> None:
                     if row["Counter_Name"] != counter:
                         continue
                     k = short(row["Kernel_Name"])
-                    if k.startswith("__amd") or "at::" in row["Kernel_Name"] or "<true" in k:
-                        continue  # runtime fills/copies, torch kernels, the counting launches (first template argument)
-                    k = k.split("<")[0]
+                    if k.startswith("__amd") or "at::" in row["Kernel_Name"]:
+                        continue  # runtime fills / copies, torch kernels
+                    renderer = k.startswith(("cast_", "trace_rays", "occlusion_", "primary_hits", "wf_"))
+                    if renderer and "<true" in k:
+                        continue  # the counting launches (first template argument of the renderer kernels)
+                    if not k.startswith("climb_"):  # the two climbs of the builder are told apart by their arguments
+                        k = k.split("<")[0]
                     table[workload][k][counter].append((int(row["Grid_Size"]), float(row["Counter_Value"])))
     out = {}
     for workload, kernels in table.items():

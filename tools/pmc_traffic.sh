@@ -5,12 +5,16 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/pmc_traffic
 mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
-for W in ${@:-bunny instanced soup cornell soup-rays}; do
+# a workload named <name>+fast runs with --traversal fast
+for W in ${@:-bunny instanced soup cornell soup-rays instanced-rays cornell-mesh heightfield bunny+fast instanced+fast soup+fast soup-rays+fast instanced-rays+fast heightfield+fast}; do
   SIZES=""
   [ "$W" = "bunny" ] && SIZES="10000000"
+  NAME=${W%+fast}
+  TRAV=exact
+  [ "$NAME" != "$W" ] && TRAV=fast
   for C in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU; do
     timeout -s KILL 240 rocprofv3 --pmc $C --output-format csv -d $OUT/${W}_${C} -- \
-      python3 $ROOT/bench.py --workload $W --streams 1 --steps 2 --warmup 0 --no-cpu-baseline --build-sizes "$SIZES" \
+      python3 $ROOT/bench.py --workload $NAME --traversal $TRAV --streams 1 --steps 2 --warmup 0 --no-cpu-baseline --no-workloads --build-sizes "$SIZES" \
       > $OUT/${W}_${C}.log 2>&1 || { echo "pass $W $C failed"; tail -5 $OUT/${W}_${C}.log; exit 1; }
     echo "pass $W $C done"
   done
