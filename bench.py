@@ -711,7 +711,8 @@ def measure(args, name, steps, warmup, n_streams_arg, rank, world, device_index,
                          "per_ray": {"nodes": round(st["nodes_tested"] / max(rays, 1), 2),
                                      "triangles": round(st["tris_tested"] / max(rays, 1), 3),
                                      "instances": round(st["inst_entered"] / max(rays, 1), 3)},
-                         "lane_utilisation": round(st["nodes_tested"] / max(64 * st["wave_steps"], 1), 4),
+                         # box tests per lane and wave step (the ordered walk tests two boxes in a step)
+                         "lane_utilisation": round(st["nodes_tested"] / max((128 if traversal == "fast" else 64) * st["wave_steps"], 1), 4),
                          "concurrent_launches": n_streams,
                          "algorithmic_rate_overlapped_gbs": round(overlapped, 2),
                          # a fraction of the HBM peak only where that is a statement about HBM: never above 1

@@ -295,7 +295,7 @@ int rthip_lbvh_reserve(rthip_ctx* ctx, uint64_t n);
 
 /* rthip_lbvh_build_device for callers that cannot allocate device memory: code under HIP graph capture, tight serving
  * loops, harnesses that forbid hipMalloc.  No counterpart in the reference.  Same arguments, same tree bit for bit, but
- * the builder's workspace is a fixed array inside the library (about 23 MB per GPU, held until the process ends) instead
+ * the builder's workspace is a fixed array inside the library (about 17 MB per GPU, held until the process ends) instead
  * of memory grown on demand: the call makes no hipMalloc / hipFree, and n is limited to RTHIP_NOALLOC_MAX_BOXES
  * (RTHIP_E_LIMIT beyond).  All contexts on one GPU share that array: calls that overlap on one GPU (other streams,
  * other contexts, other threads) race; calls on one stream, or ordered by events, do not. */
