@@ -31,10 +31,6 @@ constexpr int kBlock = 256;
 constexpr int kSortBlock = 1024;                    // threads per workgroup in the radix kernels
 constexpr int kSortItems = 4;                       // keys per thread
 constexpr int kSortTile = kSortBlock * kSortItems;  // 4096 keys per workgroup
-// Sorts of up to 4 tiles (16384 keys) run one kernel per pass.  Measured build time, separate / fused passes: 600
-// boxes 0.119 / 0.096 ms, 4096: 0.160 / 0.130, 8192: 0.168 / 0.151, 20000: 0.180 / 0.173, 40000: 0.187 / 0.196 (the
-// per-workgroup sum over the tiles and the atomics grow with the input, the saved launches do not).
-constexpr uint32_t kFusedTiles = 4;
 constexpr int kScanItems = 8;
 constexpr int kScanTile = kBlock * kScanItems;  // 2048 values per workgroup
 
@@ -290,19 +286,11 @@ __global__ __launch_bounds__(kBlock) void radix_offsets_kernel(uint32_t* __restr
 // Each workgroup ranks its 4096 keys by the current digit (wave-level match-any on
 // ballots, wave-private LDS counters), sorts the tile in LDS and writes every digit
 // bucket to its place in the output with consecutive lanes on consecutive addresses.
-//
-// FUSED (sorts of at most kFusedTiles tiles, where the chain of dependent launches costs more than the work): the
-// kernel is the whole pass.  gbase is then the RAW tile histogram of this pass's digit (every workgroup sums the rows
-// itself: 256 x tiles counters), the keys' NEXT digit is counted into hist_next by the tile the key lands in (global
-// atomics: cheap at these sizes), and hist_zero -- the table of the pass after next -- is cleared on the way.
-template <bool FUSED>
 __global__ __launch_bounds__(kSortBlock) void radix_scatter_kernel(const uint64_t* __restrict__ keys_in,
                                                                    const uint32_t* __restrict__ vals_in,
                                                                    uint64_t* __restrict__ keys_out,
                                                                    uint32_t* __restrict__ vals_out, uint64_t n, int shift,
-                                                                   const uint32_t* __restrict__ gbase, uint32_t tiles,
-                                                                   uint32_t* __restrict__ hist_next,
-                                                                   uint32_t* __restrict__ hist_zero) {
+                                                                   const uint32_t* __restrict__ gbase, uint32_t tiles) {
     // gbase[d * tiles + t]: keys with digit d in the tiles before t; gbase[256 * tiles + d]: keys with digit d
     constexpr int kWaves = kSortBlock / 64;
     __shared__ uint32_t wave_cnt[kWaves][256];
@@ -362,16 +350,8 @@ __global__ __launch_bounds__(kSortBlock) void radix_scatter_kernel(const uint64_
         }
         uint32_t total = 0, before_tile = 0;
         if (owner) {
-            if (FUSED) {
-                for (uint32_t t = 0; t < tiles; t++) {
-                    const uint32_t c = gbase[(uint64_t)tid * tiles + t];
-                    before_tile += t < blockIdx.x ? c : 0u;
-                    total += c;
-                }
-            } else {
-                total = gbase[256ull * tiles + tid];
-                before_tile = gbase[(uint64_t)tid * tiles + blockIdx.x];
-            }
+            total = gbase[256ull * tiles + tid];
+            before_tile = gbase[(uint64_t)tid * tiles + blockIdx.x];
         }
         uint32_t incl = run, dincl = total;
 #pragma unroll
@@ -422,12 +402,152 @@ __global__ __launch_bounds__(kSortBlock) void radix_scatter_kernel(const uint64_
             uint32_t dst = out_base[d] + p;
             keys_out[dst] = k;
             vals_out[dst] = svals[p];
-            if (FUSED && hist_next)
-                atomicAdd(&hist_next[(uint64_t)((uint32_t)(k >> (shift + 8)) & 255u) * tiles + dst / (uint32_t)kSortTile], 1u);
         }
     }
-    if (FUSED && hist_zero)
-        for (uint32_t k = blockIdx.x * kSortBlock + tid; k < 256u * tiles; k += gridDim.x * kSortBlock) hist_zero[k] = 0u;
+}
+
+// ---- sorts of at most kMergeTiles tiles: every tile sorted completely in LDS, then merged by rank ---------
+// Up to 2^17 keys the pass-by-pass sort is a chain of 24 small launches (its keys fit the L2 many times over), so
+// these sizes take two: tile_sort_kernel sorts each tile of 4096 keys through all n_bytes digits without leaving LDS
+// (the same wave-ballot ranking as the scatter kernel, the tile ping-ponging between registers and LDS), and
+// tile_merge_kernel gives every key its final position: its position in its own tile plus, for every other tile, the
+// number of keys there that must come before it (binary searches; keys <= in earlier tiles, < in later ones, which
+// keeps equal keys in their original order).  O(n * tiles * log) reads of an L2-resident array: cheap up to 32 tiles.
+constexpr uint32_t kMergeTiles = 32;
+
+__global__ __launch_bounds__(kSortBlock) void tile_sort_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                                                               uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+                                                               uint64_t n, int n_bytes) {
+    constexpr int kWaves = kSortBlock / 64;
+    __shared__ uint32_t wave_cnt[kWaves][256];
+    __shared__ uint32_t bin_start[256];
+    __shared__ uint32_t wave_tot[4];
+    __shared__ uint64_t skeys[kSortTile];
+    __shared__ uint32_t svals[kSortTile];
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const uint64_t base = (uint64_t)blockIdx.x * kSortTile;
+    const uint32_t wpos = (uint32_t)wave * (64 * kSortItems);  // this wave's first position in the tile
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+
+    uint64_t key[kSortItems];
+    uint32_t val[kSortItems];
+#pragma unroll
+    for (int j = 0; j < kSortItems; j++) {
+        const uint64_t i = base + wpos + (uint64_t)j * 64 + lane;
+        key[j] = (i < n) ? keys_in[i] : ~0ull;  // padding sorts behind every real key and keeps its place there
+        val[j] = (i < n) ? (vals_in ? vals_in[i] : (uint32_t)i) : 0u;
+    }
+    for (int pass = 0; pass < n_bytes; pass++) {
+        const int shift = pass * 8;
+        for (int k = tid; k < kWaves * 256; k += kSortBlock) (&wave_cnt[0][0])[k] = 0;
+        __syncthreads();
+        uint32_t rank[kSortItems];
+#pragma unroll
+        for (int j = 0; j < kSortItems; j++) {
+            const uint32_t d = (uint32_t)(key[j] >> shift) & 255u;
+            uint64_t same = ~0ull;
+#pragma unroll
+            for (int b = 0; b < 8; b++) {
+                const bool bit = (d >> b) & 1u;
+                const uint64_t bal = __ballot(bit);
+                same &= bit ? bal : ~bal;
+            }
+            const uint32_t below = __popcll(same & lt_mask);
+            uint32_t old = 0;
+            if (below == 0) {
+                old = wave_cnt[wave][d];
+                wave_cnt[wave][d] = old + __popcll(same);
+            }
+            old = __shfl(old, __ffsll((long long)same) - 1);
+            rank[j] = old + below;
+        }
+        __syncthreads();
+        {   // thread d < 256: offsets of each wave inside digit d, then the exclusive scan over the digits
+            const bool owner = tid < 256;
+            uint32_t run = 0;
+            if (owner) {
+#pragma unroll
+                for (int w = 0; w < kWaves; w++) {
+                    const uint32_t c = wave_cnt[w][tid];
+                    wave_cnt[w][tid] = run;
+                    run += c;
+                }
+            }
+            uint32_t incl = run;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t up = __shfl_up(incl, o);
+                if (lane >= o) incl += up;
+            }
+            if (owner && lane == 63) wave_tot[wave] = incl;
+            __syncthreads();
+            if (owner) {
+                uint32_t wsum = 0;
+                for (int w = 0; w < wave; w++) wsum += wave_tot[w];
+                bin_start[tid] = wsum + incl - run;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < kSortItems; j++) {
+            const uint32_t d = (uint32_t)(key[j] >> shift) & 255u;
+            const uint32_t pos = bin_start[d] + wave_cnt[wave][d] + rank[j];
+            skeys[pos] = key[j];
+            svals[pos] = val[j];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < kSortItems; j++) {
+            key[j] = skeys[wpos + j * 64 + lane];
+            val[j] = svals[wpos + j * 64 + lane];
+        }
+        __syncthreads();  // the next pass overwrites the tile
+    }
+#pragma unroll
+    for (int j = 0; j < kSortItems; j++) {
+        const uint64_t i = base + wpos + (uint64_t)j * 64 + lane;
+        if (i < n) {
+            keys_out[i] = key[j];
+            vals_out[i] = val[j];
+        }
+    }
+}
+
+// 32 lanes per key of the tile-sorted array: lane t searches tile t and the counts are added up across the lanes, so the
+// searches of one key (independent chains of 12 dependent loads) run side by side.  Measured at 81 920 keys: 41 us,
+// against 48 us with one thread per key searching the tiles in turn and 62 us for workgroups that copy the matching
+// stretch of every tile to LDS first (one such workgroup fills a CU's LDS and runs alone there).
+__global__ __launch_bounds__(kBlock) void tile_merge_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                                            uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+                                                            uint32_t n, uint32_t tiles, uint64_t mask) {
+    const uint32_t t = threadIdx.x & 31u;
+    const uint32_t i = blockIdx.x * (kBlock / 32) + (threadIdx.x >> 5);
+    const bool live = i < n;
+    const uint64_t full = live ? keys[i] : 0ull, k = full & mask;
+    const uint32_t mine = i / (uint32_t)kSortTile;
+    uint32_t before = 0;
+    if (live && t < tiles && t != mine) {
+        const uint32_t first = t * (uint32_t)kSortTile;
+        const uint32_t count = n - first < (uint32_t)kSortTile ? n - first : (uint32_t)kSortTile;
+        // keys of tile t that come before this one: <= k when the tile lies before mine, < k when it lies behind
+        uint32_t lo = 0, hi = count;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            const uint64_t m = keys[first + mid] & mask;
+            const bool is_before = t < mine ? m <= k : m < k;
+            if (is_before) lo = mid + 1;
+            else hi = mid;
+        }
+        before = lo;
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) before += __shfl_xor(before, o);  // within the key's 32 lanes
+    if (live && t == 0) {
+        const uint32_t rank = (i - mine * (uint32_t)kSortTile) + before;
+        keys_out[rank] = full;
+        vals_out[rank] = vals[i];
+    }
 }
 
 // ---- device-wide prefix sums of uint32 ------------------------------------------------
@@ -1149,22 +1269,13 @@ int radix_sort_workspace_device(rthip_ctx* ctx, uint64_t n, int n_bytes, hipStre
     uint64_t* keys[2] = {(uint64_t*)w.keys[0].p, (uint64_t*)w.keys[1].p};
     uint32_t* vals[2] = {(uint32_t*)w.vals[0].p, (uint32_t*)w.vals[1].p};
     int cur = *cur_io;
-    if (tiles <= kFusedTiles) {
-        // three tables in turn: pass p reads table p % 3, counts the next digit into table (p + 1) % 3 and clears
-        // table (p + 2) % 3, which pass p + 1 counts into
-        const size_t table = 256ull * tiles;
-        RT_TRY(rthip_reserve(ctx, w.block_hist, (3 * table + 256) * 4));
-        uint32_t* h = (uint32_t*)w.block_hist.p;
-        RT_HIP(ctx, hipMemsetAsync(h, 0, 3 * table * 4, s));
-        radix_hist_kernel<<<tiles, kSortBlock, 0, s>>>(keys[cur], n, 0, h, tiles);
+    if (tiles <= kMergeTiles && !ctx->sort_by_passes) {
+        tile_sort_kernel<<<tiles, kSortBlock, 0, s>>>(keys[cur], identity_vals ? nullptr : vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, n_bytes);
         RT_HIP(ctx, hipGetLastError());
-        for (int pass = 0; pass < n_bytes; pass++) {
-            const bool last = pass + 1 == n_bytes;
-            radix_scatter_kernel<true><<<tiles, kSortBlock, 0, s>>>(keys[cur], (pass == 0 && identity_vals) ? nullptr : vals[cur],
-                                                                keys[cur ^ 1], vals[cur ^ 1], n, pass * 8,
-                                                                h + (size_t)(pass % 3) * table, tiles,
-                                                                last ? nullptr : h + (size_t)((pass + 1) % 3) * table,
-                                                                last ? nullptr : h + (size_t)((pass + 2) % 3) * table);
+        cur ^= 1;
+        if (tiles > 1) {
+            const uint64_t mask = n_bytes >= 8 ? ~0ull : ((1ull << (8 * n_bytes)) - 1ull);
+            tile_merge_kernel<<<div_up(n, kBlock / 32), kBlock, 0, s>>>(keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], (uint32_t)n, tiles, mask);
             RT_HIP(ctx, hipGetLastError());
             cur ^= 1;
         }
@@ -1180,9 +1291,8 @@ int radix_sort_workspace_device(rthip_ctx* ctx, uint64_t n, int n_bytes, hipStre
         radix_hist_kernel<<<tiles, kSortBlock, 0, s>>>(keys[cur], n, shift, (uint32_t*)w.block_hist.p, tiles);
         RT_HIP(ctx, hipGetLastError());
         radix_offsets_kernel<<<256, kBlock, 0, s>>>((uint32_t*)w.block_hist.p, tiles);
-        radix_scatter_kernel<false><<<tiles, kSortBlock, 0, s>>>(keys[cur], (pass == 0 && identity_vals) ? nullptr : vals[cur],
-                                                             keys[cur ^ 1], vals[cur ^ 1], n, shift,
-                                                             (const uint32_t*)w.block_hist.p, tiles, nullptr, nullptr);
+        radix_scatter_kernel<<<tiles, kSortBlock, 0, s>>>(keys[cur], (pass == 0 && identity_vals) ? nullptr : vals[cur], keys[cur ^ 1],
+                                                      vals[cur ^ 1], n, shift, (const uint32_t*)w.block_hist.p, tiles);
         RT_HIP(ctx, hipGetLastError());
         cur ^= 1;
     }
@@ -1255,9 +1365,7 @@ int lbvh_reserve_workspace(rthip_ctx* ctx, uint64_t n, LbvhWorkspace* ws) {
     RT_TRY(rthip_reserve(ctx, w.keys[1], n * 8));
     RT_TRY(rthip_reserve(ctx, w.vals[0], n * 4));
     RT_TRY(rthip_reserve(ctx, w.vals[1], n * 4));
-    // the one-kernel-per-pass sort of small inputs keeps three histogram tables (radix_sort_workspace_device)
-    const uint64_t fused_elems = tiles <= kFusedTiles ? 3ull * 256 * tiles : 0;
-    RT_TRY(rthip_reserve(ctx, w.block_hist, ((hist_elems > fused_elems ? hist_elems : fused_elems) + 256) * 4));
+    RT_TRY(rthip_reserve(ctx, w.block_hist, (hist_elems + 256) * 4));
     RT_TRY(rthip_reserve(ctx, w.scan_tmp, (scan_tmp_elems(hist_elems) + scan_tmp_elems(n)) * 4));
     RT_TRY(rthip_reserve(ctx, w.prio, n));
     RT_TRY(rthip_reserve(ctx, w.child, 2 * n * sizeof(ChildRec)));
@@ -1400,12 +1508,12 @@ int lbvh_static_workspace_init(rthip_ctx* ctx) {
     const uint64_t n = kStaticBuildMaxBoxes;
     const uint32_t tiles = div_up(n, kSortTile);
     const uint64_t hist_elems = 256ull * tiles;
-    const size_t hist_bytes = (hist_elems + 256) * 4, fused_bytes = (3ull * 256 * kFusedTiles + 256) * 4;
+    const size_t hist_bytes = (hist_elems + 256) * 4;
     LbvhWorkspace& w = ctx->ws_static;
     size_t off = 0;
     bool ok = carve(w.keys[0], base, off, n * 8) && carve(w.keys[1], base, off, n * 8) && carve(w.vals[0], base, off, n * 4) &&
               carve(w.vals[1], base, off, n * 4) &&
-              carve(w.block_hist, base, off, hist_bytes > fused_bytes ? hist_bytes : fused_bytes) &&
+              carve(w.block_hist, base, off, hist_bytes) &&
               carve(w.scan_tmp, base, off, (scan_tmp_elems(hist_elems) + scan_tmp_elems(n)) * 4) &&
               carve(w.prio, base, off, n) && carve(w.child, base, off, 2 * n * sizeof(ChildRec)) &&
               carve(w.child_topo, base, off, 2 * n * sizeof(TopoRec)) && carve(w.flags, base, off, n * 4) &&

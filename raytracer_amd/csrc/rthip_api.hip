@@ -134,6 +134,8 @@ int rthip_create(rthip_ctx** out_ctx, int device_id) {
     ctx->device = device_id;
     const char* fence = getenv("RTHIP_REFIT_FENCE");
     ctx->refit_fence = (fence && fence[0] >= '0' && fence[0] <= '2') ? fence[0] - '0' : 2;
+    const char* by_passes = getenv("RTHIP_SORT_BY_PASSES");
+    ctx->sort_by_passes = (by_passes && by_passes[0] == '1') ? 1 : 0;
     const char* wide = getenv("RTHIP_UPPER_DEVICE_WIDE");
     ctx->upper_device_wide = (wide && wide[0] == '1') ? 1 : 0;
     const char* mode = getenv("RTHIP_CAST");
