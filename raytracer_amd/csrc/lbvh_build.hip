@@ -203,10 +203,13 @@ __device__ __forceinline__ uint32_t morton_axis(float c, float mn, float ext) {
 __global__ __launch_bounds__(kBlock) void morton_kernel(const float* __restrict__ aabb6, uint64_t n,
                                                         const uint32_t* __restrict__ bounds,
                                                         uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                                                        uint32_t* __restrict__ zero) {
+                                                        uint32_t* __restrict__ zero, unsigned long long* __restrict__ zero64) {
     uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
-    if (zero) zero[i] = 0u;  // the climbs' arrival counters, cleared on the way (one launch fewer)
+    if (zero) {  // the climbs' arrival counters and hand-over words, cleared on the way (one launch fewer)
+        zero[i] = 0u;
+        zero64[i] = 0ull;
+    }
     float mn[3], ext[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
@@ -408,25 +411,29 @@ __global__ __launch_bounds__(kSortBlock) void radix_scatter_kernel(const uint64_
 
 // ---- sorts of at most kMergeTiles tiles: every tile sorted completely in LDS, then merged by rank ---------
 // Up to 2^17 keys the pass-by-pass sort is a chain of 24 small launches (its keys fit the L2 many times over), so
-// these sizes take two: tile_sort_kernel sorts each tile of 4096 keys through all n_bytes digits without leaving LDS
-// (the same wave-ballot ranking as the scatter kernel, the tile ping-ponging between registers and LDS), and
-// tile_merge_kernel gives every key its final position: its position in its own tile plus, for every other tile, the
-// number of keys there that must come before it (binary searches; keys <= in earlier tiles, < in later ones, which
-// keeps equal keys in their original order).  O(n * tiles * log) reads of an L2-resident array: cheap up to 32 tiles.
-constexpr uint32_t kMergeTiles = 32;
+// these sizes take two.  tile_sort_kernel sorts each tile of 1024 keys through all n_bytes digits without leaving LDS
+// (the same wave-ballot ranking as the scatter kernel, the tile ping-ponging between registers and LDS; small tiles,
+// so that a sort of 80 000 keys is spread over 80 CUs and a pass is one wave per SIMD).  tile_merge_kernel gives every
+// key its final position: its position in its own tile plus, for every other tile, the number of keys there that must
+// come before it (keys <= in earlier tiles, < in later ones, which keeps equal keys in their original order).
+constexpr int kSmallSortBlock = 256;
+constexpr int kSmallTile = kSmallSortBlock * kSortItems;  // 1024 keys
+constexpr uint32_t kMergeTiles = 128;
+constexpr int kMergeBatch = 4;   // tiles a wave ranks against side by side
+constexpr int kMergeSeg = 128;   // keys of a tile's matching stretch held in LDS
 
-__global__ __launch_bounds__(kSortBlock) void tile_sort_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
-                                                               uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
-                                                               uint64_t n, int n_bytes) {
-    constexpr int kWaves = kSortBlock / 64;
+__global__ __launch_bounds__(kSmallSortBlock) void tile_sort_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                                                                    uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+                                                                    uint64_t n, int n_bytes) {
+    constexpr int kWaves = kSmallSortBlock / 64;
     __shared__ uint32_t wave_cnt[kWaves][256];
     __shared__ uint32_t bin_start[256];
-    __shared__ uint32_t wave_tot[4];
-    __shared__ uint64_t skeys[kSortTile];
-    __shared__ uint32_t svals[kSortTile];
+    __shared__ uint32_t wave_tot[kWaves];
+    __shared__ uint64_t skeys[kSmallTile];
+    __shared__ uint32_t svals[kSmallTile];
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const uint64_t base = (uint64_t)blockIdx.x * kSortTile;
+    const uint64_t base = (uint64_t)blockIdx.x * kSmallTile;
     const uint32_t wpos = (uint32_t)wave * (64 * kSortItems);  // this wave's first position in the tile
     const uint64_t lt_mask = (1ull << lane) - 1ull;
 
@@ -440,8 +447,10 @@ __global__ __launch_bounds__(kSortBlock) void tile_sort_kernel(const uint64_t* _
     }
     for (int pass = 0; pass < n_bytes; pass++) {
         const int shift = pass * 8;
-        for (int k = tid; k < kWaves * 256; k += kSortBlock) (&wave_cnt[0][0])[k] = 0;
-        __syncthreads();
+        // a wave's counters are its own until the barrier below (the previous pass's readers of them are behind that
+        // pass's later barriers), so clearing them needs no barrier
+#pragma unroll
+        for (int q = 0; q < 4; q++) wave_cnt[wave][q * 64 + lane] = 0;
         uint32_t rank[kSortItems];
 #pragma unroll
         for (int j = 0; j < kSortItems; j++) {
@@ -463,16 +472,13 @@ __global__ __launch_bounds__(kSortBlock) void tile_sort_kernel(const uint64_t* _
             rank[j] = old + below;
         }
         __syncthreads();
-        {   // thread d < 256: offsets of each wave inside digit d, then the exclusive scan over the digits
-            const bool owner = tid < 256;
+        {   // thread d: offsets of each wave inside digit d, then the exclusive scan over the digits
             uint32_t run = 0;
-            if (owner) {
 #pragma unroll
-                for (int w = 0; w < kWaves; w++) {
-                    const uint32_t c = wave_cnt[w][tid];
-                    wave_cnt[w][tid] = run;
-                    run += c;
-                }
+            for (int w = 0; w < kWaves; w++) {
+                const uint32_t c = wave_cnt[w][tid];
+                wave_cnt[w][tid] = run;
+                run += c;
             }
             uint32_t incl = run;
 #pragma unroll
@@ -480,13 +486,11 @@ __global__ __launch_bounds__(kSortBlock) void tile_sort_kernel(const uint64_t* _
                 const uint32_t up = __shfl_up(incl, o);
                 if (lane >= o) incl += up;
             }
-            if (owner && lane == 63) wave_tot[wave] = incl;
+            if (lane == 63) wave_tot[wave] = incl;
             __syncthreads();
-            if (owner) {
-                uint32_t wsum = 0;
-                for (int w = 0; w < wave; w++) wsum += wave_tot[w];
-                bin_start[tid] = wsum + incl - run;
-            }
+            uint32_t wsum = 0;
+            for (int w = 0; w < wave; w++) wsum += wave_tot[w];
+            bin_start[tid] = wsum + incl - run;
         }
         __syncthreads();
 #pragma unroll
@@ -502,7 +506,7 @@ __global__ __launch_bounds__(kSortBlock) void tile_sort_kernel(const uint64_t* _
             key[j] = skeys[wpos + j * 64 + lane];
             val[j] = svals[wpos + j * 64 + lane];
         }
-        __syncthreads();  // the next pass overwrites the tile
+        // no barrier: the next pass writes the tile only after its own three barriers
     }
 #pragma unroll
     for (int j = 0; j < kSortItems; j++) {
@@ -514,37 +518,114 @@ __global__ __launch_bounds__(kSortBlock) void tile_sort_kernel(const uint64_t* _
     }
 }
 
-// 32 lanes per key of the tile-sorted array: lane t searches tile t and the counts are added up across the lanes, so the
-// searches of one key (independent chains of 12 dependent loads) run side by side.  Measured at 81 920 keys: 41 us,
-// against 48 us with one thread per key searching the tiles in turn and 62 us for workgroups that copy the matching
-// stretch of every tile to LDS first (one such workgroup fills a CU's LDS and runs alone there).
-__global__ __launch_bounds__(kBlock) void tile_merge_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals,
-                                                            uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
-                                                            uint32_t n, uint32_t tiles, uint64_t mask) {
-    const uint32_t t = threadIdx.x & 31u;
-    const uint32_t i = blockIdx.x * (kBlock / 32) + (threadIdx.x >> 5);
-    const bool live = i < n;
-    const uint64_t full = live ? keys[i] : 0ull, k = full & mask;
-    const uint32_t mine = i / (uint32_t)kSortTile;
-    uint32_t before = 0;
-    if (live && t < tiles && t != mine) {
-        const uint32_t first = t * (uint32_t)kSortTile;
-        const uint32_t count = n - first < (uint32_t)kSortTile ? n - first : (uint32_t)kSortTile;
-        // keys of tile t that come before this one: <= k when the tile lies before mine, < k when it lies behind
-        uint32_t lo = 0, hi = count;
-        while (lo < hi) {
-            const uint32_t mid = (lo + hi) >> 1;
-            const uint64_t m = keys[first + mid] & mask;
-            const bool is_before = t < mine ? m <= k : m < k;
-            if (is_before) lo = mid + 1;
-            else hi = mid;
-        }
-        before = lo;
+// keys of a sorted stretch that come before k: `<=` when the stretch's tile lies before k's tile, `<` when behind
+__device__ __forceinline__ uint32_t rank_in_global(const uint64_t* __restrict__ keys, uint32_t count, uint64_t k, bool or_equal, uint64_t mask) {
+    uint32_t lo = 0, hi = count;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        const uint64_t m = keys[mid] & mask;
+        if (or_equal ? m <= k : m < k) lo = mid + 1;
+        else hi = mid;
     }
+    return lo;
+}
+
+// A workgroup ranks 64 neighbouring keys of one sorted tile against all the other tiles, a quarter of the tiles per
+// wave.  Neighbouring keys have neighbouring ranks: a wave first finds where its first and its last key fall in each of
+// its tiles (one lane per tile and end, binary searches in global memory), which bounds the stretch of the tile that
+// can lie between its keys -- as long as the 64 keys themselves on average.  Then, kMergeBatch tiles at a time, it
+// copies those stretches to LDS with coalesced loads and every lane ranks its key there.  Against one binary search of
+// the whole tile per key and tile (12 dependent, fully divergent loads each; 41 us for 81 920 keys) this leaves two
+// searches per 64 keys and tile.  A stretch of kMergeSeg keys or more (tiles with very different key ranges) is
+// searched in global memory.
+__global__ __launch_bounds__(256) void tile_merge_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                                         uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+                                                         uint32_t n, uint32_t tiles, uint64_t mask) {
+    __shared__ uint32_t ends[4][2][32];
+    __shared__ uint64_t seg[4][kMergeBatch][kMergeSeg];
+    __shared__ uint32_t partial[4][64];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t i0 = blockIdx.x * 64u, i = i0 + lane;
+    const bool live = i < n;
+    const uint32_t last_lane = (n - i0 < 64u ? n - i0 : 64u) - 1u;
+    const uint64_t full = keys[live ? i : i0], k = full & mask;
+    const uint64_t k_first = __shfl(k, 0), k_last = __shfl(k, (int)last_lane);
+    const uint32_t mine = i0 / (uint32_t)kSmallTile;
+    const uint32_t per_wave = (tiles + 3u) / 4u, t0 = wave * per_wave;  // this wave's tiles: t0 .. t0 + per_wave - 1
+
+    {   // where the first (lanes 0-31) and the last key (lanes 32-63) fall in tile t0 + (lane & 31)
+        const uint32_t tt = lane & 31u, t = t0 + tt, e = lane >> 5;
+        uint32_t r = 0;
+        if (tt < per_wave && t < tiles && t != mine) {
+            const uint32_t first = t * (uint32_t)kSmallTile;
+            const uint32_t count = n - first < (uint32_t)kSmallTile ? n - first : (uint32_t)kSmallTile;
+            r = rank_in_global(keys + first, count, e ? k_last : k_first, t < mine, mask);
+        }
+        ends[wave][e][tt] = r;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+
+    uint32_t before = 0;
+    for (uint32_t tb = 0; tb < per_wave; tb += kMergeBatch) {
+        // A stretch of up to kMergeSeg - 1 keys goes to LDS, padded with all-ones words; a key k is ranked by the
+        // longest prefix of words below kk = k (+ 1 for tiles before this one, where equal keys come first too): the
+        // padding is below no kk, so the search needs no length.
+        uint32_t lo[kMergeBatch], len[kMergeBatch];
+        uint64_t a[kMergeBatch], b[kMergeBatch], kk[kMergeBatch];
+        bool every[kMergeBatch];
 #pragma unroll
-    for (int o = 16; o > 0; o >>= 1) before += __shfl_xor(before, o);  // within the key's 32 lanes
-    if (live && t == 0) {
-        const uint32_t rank = (i - mine * (uint32_t)kSortTile) + before;
+        for (int u = 0; u < kMergeBatch; u++) {
+            const uint32_t tt = tb + u, t = t0 + tt;
+            const bool valid = tt < per_wave && t < tiles && t != mine;
+            lo[u] = valid ? ends[wave][0][tt & 31u] : 0u;
+            len[u] = valid ? ends[wave][1][tt & 31u] - lo[u] : 0u;
+            const bool or_equal = t < mine;
+            kk[u] = k + (or_equal ? 1ull : 0ull);
+            every[u] = or_equal && k == ~0ull;  // k + 1 wrapped: every key of an earlier tile comes first
+            const uint64_t* src = keys + (uint64_t)t * kSmallTile + lo[u];
+            a[u] = b[u] = ~0ull;
+            if (len[u] < (uint32_t)kMergeSeg) {
+                if (lane < len[u]) a[u] = src[lane] & mask;
+                if (lane + 64u < len[u]) b[u] = src[lane + 64u] & mask;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kMergeBatch; u++) {
+            seg[wave][u][lane] = a[u];
+            seg[wave][u][lane + 64u] = b[u];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+        uint32_t pos[kMergeBatch];
+#pragma unroll
+        for (int u = 0; u < kMergeBatch; u++) pos[u] = 0;
+#pragma unroll
+        for (uint32_t step = kMergeSeg / 2; step >= 1u; step >>= 1) {
+#pragma unroll
+            for (int u = 0; u < kMergeBatch; u++) {
+                const uint32_t p = pos[u] + step;  // <= kMergeSeg - 1
+                if (seg[wave][u][p - 1u] < kk[u]) pos[u] = p;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kMergeBatch; u++) {
+            if (len[u] >= (uint32_t)kMergeSeg) {  // uniform over the wave
+                const uint32_t t = t0 + tb + u;
+                pos[u] = rank_in_global(keys + (uint64_t)t * kSmallTile + lo[u], len[u], k, t < mine, mask);
+            } else if (every[u]) {
+                pos[u] = len[u];
+            }
+            before += lo[u] + pos[u];
+        }
+        __builtin_amdgcn_wave_barrier();  // the next batch overwrites the stretches
+    }
+    partial[wave][lane] = before;
+    __syncthreads();
+    if (wave == 0 && live) {
+        const uint32_t rank = (i - mine * (uint32_t)kSmallTile) + partial[0][lane] + partial[1][lane] + partial[2][lane] + partial[3][lane];
         keys_out[rank] = full;
         vals_out[rank] = vals[i];
     }
@@ -654,13 +735,14 @@ __device__ __forceinline__ uint8_t gap_priority_of(const uint64_t* keys, uint64_
 // Each climb is two kernels.  *_local: a workgroup owns kChunk consecutive sorted leaves.  A gap whose node lies
 // entirely inside the chunk (it is bounded on both sides, inside the chunk, by gaps of smaller priority) is "local":
 // both of its children are produced by this workgroup, so their hand-off goes through LDS.  A thread that reaches a
-// parent that is not local stores its record in HBM, counts itself at the parent and is done.  *_upper finishes the
-// nodes that span chunks (a few per cent of all): one thread per gap whose two children both arrived in the local
-// kernel (the second child to be counted there puts the gap on a list), hand-offs through HBM.
+// parent that is not local hands its record over in HBM and is done.  *_upper finishes the nodes that span chunks (a
+// few per cent of all): one thread per node whose two children both arrived in the local kernel (the second child to
+// arrive in the topology climb puts the node on a list that both upper kernels start from), hand-offs through HBM.
 //
-// Hand-offs through HBM (upper kernels).  Every access to a record and to the counter is a device-scope atomic, so
-// what the hand-off needs beyond per-location coherence is ORDER: record before count, count before the sibling's
-// record.  MODE 2 (the default): the wave drains its record stores (s_waitcnt vmcnt(0): device-scope stores are
+// Hand-offs through HBM.  Topology climb: the record is one 64-bit word and travels inside an atomic exchange (see
+// topo_pack).  Box climb (the record is 32 bytes): every access to a record and to the counter is a device-scope
+// atomic, so what the hand-off needs beyond per-location coherence is ORDER: record before count, count before the
+// sibling's record.  MODE 2 (the default): the wave drains its record stores (s_waitcnt vmcnt(0): device-scope stores are
 // acknowledged once they are visible device-wide on gfx950) before a relaxed counter add, and reads the sibling after
 // the add has returned; the asm statement is a compiler barrier as well.  That is the hardware's ordering, not one the
 // HIP memory model promises for relaxed atomics.  MODE 0 (RTHIP_REFIT_FENCE=0) is the model's own form: a device-
@@ -670,8 +752,7 @@ __device__ __forceinline__ uint8_t gap_priority_of(const uint64_t* keys, uint64_
 // for 10^7 triangles, 0.25 / 0.23 ms for 81 920.  MODE 1 (RTHIP_REFIT_FENCE=1, diagnostic): plain accesses bracketed
 // by __threadfence().
 //
-// One arrival counter per gap serves both climbs and both kernels of each, in 4-bit fields: topology local +1,
-// topology upper +16, boxes local +256, boxes upper +4096.
+// The box climb's arrival counter of a gap is shared by its two kernels; the first arrival finds 0.
 constexpr int kChunk = 512;  // sorted leaves per workgroup, one per thread
 
 struct alignas(8) TopoRec {  // what a child leaves at its parent in the topology climb
@@ -714,17 +795,23 @@ __device__ __forceinline__ void child_load(const ChildRec* slot, float* box, uin
     *far_end = (uint32_t)w3;
     *dl = (uint32_t)(w3 >> 32);
 }
-template <bool FENCE>
-__device__ __forceinline__ void topo_store(TopoRec* slot, uint32_t far_end, uint32_t dl) {
-    const uint64_t w = (uint64_t)far_end | ((uint64_t)dl << 32);
-    if (FENCE) *(uint64_t*)slot = w;
-    else __hip_atomic_store((uint64_t*)slot, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// Topology climb, parents that span chunks: a child's whole record is ONE 64-bit word -- far end of its range + 1 (so
+// that no record is 0), left-spine length (at most the tree's height: 63 bit levels + 33 levels of an equal-code run)
+// and the priority of the gap beyond its far end, which the parent needs to find ITS parent -- and the hand-over is one
+// atomic exchange on the parent's word: the first child to arrive gets 0 back and is done, the second gets its
+// sibling's record and carries on.  One memory round trip per level, and no ordering between different locations to
+// rely on: the data travels inside the atomic.
+__device__ __forceinline__ unsigned long long topo_pack(uint32_t far_end, uint32_t dl, uint32_t far_prio) {
+    return (unsigned long long)(far_end + 1u) | ((unsigned long long)dl << 32) | ((unsigned long long)far_prio << 48);
 }
-template <bool FENCE>
-__device__ __forceinline__ void topo_load(const TopoRec* slot, uint32_t* far_end, uint32_t* dl) {
-    const uint64_t w = FENCE ? *(volatile uint64_t*)slot : __hip_atomic_load((uint64_t*)slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    *far_end = (uint32_t)w;
-    *dl = (uint32_t)(w >> 32);
+__device__ __forceinline__ void topo_unpack(unsigned long long w, uint32_t* far_end, uint32_t* dl, uint32_t* far_prio) {
+    *far_end = (uint32_t)w - 1u;
+    *dl = (uint32_t)(w >> 32) & 0xffffu;
+    *far_prio = (uint32_t)(w >> 48) & 0xffu;
+}
+// a node that spans chunks and is complete: where an upper kernel starts from
+__device__ __forceinline__ uint4 start_pack(uint32_t gap, uint32_t l, uint32_t r, uint32_t dl, uint32_t pl, uint32_t pr) {
+    return make_uint4(gap, l, r, dl | (pl << 16) | (pr << 24));
 }
 
 // merge with a sibling: the LEFT child's box is the first argument of every Min / Max (lbvh.c:58)
@@ -770,11 +857,11 @@ struct ClimbArgs {
     const uint32_t* sorted_idx;
     const float* aabb6;
     ChildRec* child;           // box climb: records for parents that span chunks
-    TopoRec* child_topo;       // topology climb: the same
+    unsigned long long* topo_slot;  // topology climb: one hand-over word per gap (topo_pack), zero before the climb
     uint32_t* flags;           // arrival counters
     uint32_t* cnt_l;           // topology climb: left-spine length per leaf; box climb: their tile-wise inclusive scan
     const uint32_t* tile_sums; // box climb: exclusive sums of the scan tiles (nullptr: cnt_l holds the whole scan)
-    uint32_t* starters;        // gaps whose two children both arrived in the local kernel
+    uint4* starters;           // nodes that span chunks whose two children both arrived in the local kernel (start_pack)
     uint32_t* start_count;
     float4* nodes;             // box climb: the pre-order records
     uint32_t paired;
@@ -853,7 +940,9 @@ __device__ __forceinline__ void climb_local(uint32_t c0, const ClimbArgs& A) {
     __syncthreads();
 
     const uint32_t i = c0 + (uint32_t)tid;
-    uint32_t my_start = 0xffffffffu, my_slot = 0;
+    uint4 my_start = make_uint4(0u, 0u, 0u, 0u);
+    bool have_start = false;
+    uint32_t my_slot = 0;
     if (i < n) {
         uint32_t l = i, r = i, dl = 0;
         float box[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -881,19 +970,24 @@ __device__ __forceinline__ void climb_local(uint32_t c0, const ClimbArgs& A) {
             if (!BOXES && side == 1) A.cnt_l[l] = dl;  // a right child tops the left spine that starts at l
             const uint32_t far_end = parent_right ? l : r;
             if (!local) {  // the parent spans chunks: leave the record for the upper kernel
+                const uint32_t far_prio = (parent_right ? pr_l : pr_r) & 0x7fu;  // of the gap beyond the far end
                 if (BOXES) {
                     ChildRec mine;
 #pragma unroll
                     for (int k = 0; k < 6; k++) mine.box[k] = box[k];
                     mine.far_end = far_end;
-                    mine.dl = dl;
+                    mine.dl = dl | (far_prio << 16);
                     A.child[2 * (uint64_t)parent + side] = mine;
                     atomicAdd(&A.flags[parent], 256u);
                 } else {
-                    TopoRec mine = {far_end, dl};
-                    A.child_topo[2 * (uint64_t)parent + side] = mine;
-                    // the second child to be counted knows that the parent is complete: it goes on the upper kernels' list
-                    if (atomicAdd(&A.flags[parent], 1u) == 1u) my_start = parent;
+                    const unsigned long long sib = atomicExch(&A.topo_slot[parent], topo_pack(far_end, dl, far_prio));
+                    if (sib != 0ull) {  // second to arrive: the parent is complete and goes on the upper kernels' list
+                        uint32_t s_far, s_dl, s_prio;
+                        topo_unpack(sib, &s_far, &s_dl, &s_prio);
+                        my_start = side == 0 ? start_pack(parent, l, s_far, dl + 1u, pr_l & 0x7fu, s_prio)
+                                             : start_pack(parent, s_far, r, s_dl + 1u, s_prio, pr_r & 0x7fu);
+                        have_start = true;
+                    }
                 }
                 break;
             }
@@ -937,11 +1031,11 @@ __device__ __forceinline__ void climb_local(uint32_t c0, const ClimbArgs& A) {
         }
     }
     if (!BOXES) {  // hand the complete gaps to the upper kernels: one device-wide atomic per workgroup
-        if (my_start != 0xffffffffu) my_slot = atomicAdd(&n_start, 1u);
+        if (have_start) my_slot = atomicAdd(&n_start, 1u);
         __syncthreads();
         if (tid == 0 && n_start != 0) base_start = atomicAdd(A.start_count, n_start);
         __syncthreads();
-        if (my_start != 0xffffffffu) A.starters[base_start + my_slot] = my_start;
+        if (have_start) A.starters[base_start + my_slot] = my_start;
     }
 }
 
@@ -950,60 +1044,75 @@ __global__ __launch_bounds__(kChunk) void climb_local_kernel(ClimbArgs A) {
     climb_local<BOXES>(blockIdx.x * (uint32_t)kChunk, A);
 }
 
-// MODE 3: the whole upper climb in ONE workgroup, for builds of up to kOneGroupUpper leaves, where the upper tree is a
-// couple of thousand nodes and the chain of hand-offs is all there is: all threads sit on one CU, so the hand-off is a
-// workgroup-scope release / acquire pair through the counter, which costs no cache maintenance.  Measured: 81 920
-// leaves 21 + 35 us for the two upper climbs instead of 28 + 41 us device-wide; at 10^6 leaves (20 000 upper nodes on
-// 1024 threads) 146 + 301 us instead of 55 + 60 us, hence the limit.
-constexpr uint64_t kOneGroupUpper = 1ull << 17;
-constexpr int kOneGroupThreads = 1024;
-
-template <int MODE, bool BOXES>
-__global__ __launch_bounds__(MODE == 3 ? kOneGroupThreads : kBlock) void climb_upper_kernel(ClimbArgs A) {
-    // one thread per gap whose two children were both delivered by the local kernel
-    constexpr uint32_t kMine = BOXES ? 4096u : 16u;   // this kernel's arrivals
-    constexpr int kShift = BOXES ? 8 : 0;             // this climb's two 4-bit fields
+// The topology climb above the chunks: one thread per complete node on the list, one atomic exchange per level.
+__global__ __launch_bounds__(kBlock) void climb_upper_topo_kernel(ClimbArgs A) {
     const uint32_t n = A.n;
     const uint32_t count = *A.start_count;
     for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < count; t += gridDim.x * blockDim.x) {
-        uint32_t parent = A.starters[t];
-        uint32_t l, r, dl;
-        float box[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (BOXES) {
+        const uint4 e = A.starters[t];
+        uint32_t l = e.y, r = e.z, dl = e.w & 0xffffu, pl = (e.w >> 16) & 0xffu, pr = e.w >> 24;  // pl, pr: priorities of gaps l - 1 and r
+        for (;;) {
+            if (l == 0 && r == n - 1) {
+                A.cnt_l[0] = dl;
+                break;
+            }
+            const bool parent_right = (l == 0) || (r != n - 1 && pr > pl);
+            const uint32_t parent = parent_right ? r : l - 1;
+            if (!parent_right) A.cnt_l[l] = dl;  // a right child tops the left spine that starts at l
+            const unsigned long long sib =
+                atomicExch(&A.topo_slot[parent], topo_pack(parent_right ? l : r, dl, parent_right ? pl : pr));
+            if (sib == 0ull) break;  // first to arrive: the sibling carries on from here
+            uint32_t s_far, s_dl, s_prio;
+            topo_unpack(sib, &s_far, &s_dl, &s_prio);
+            if (parent_right) {
+                r = s_far;
+                dl = dl + 1;
+                pr = s_prio;
+            } else {
+                l = s_far;
+                dl = s_dl + 1;
+                pl = s_prio;
+            }
+        }
+    }
+}
+
+// MODE 3: the whole upper box climb in ONE workgroup, for builds of up to kOneGroupUpper leaves, where the upper tree
+// is a couple of thousand nodes and the chain of hand-offs is all there is: all threads sit on one CU, so the hand-off
+// is a workgroup-scope release / acquire pair through the counter, which costs no cache maintenance.  Measured: 81 920
+// leaves 35 us instead of 41 us device-wide; at 10^6 leaves (20 000 upper nodes on 1024 threads) 301 us instead of
+// 60 us, hence the limit.
+constexpr uint64_t kOneGroupUpper = 1ull << 17;
+constexpr int kOneGroupThreads = 1024;
+
+// The box climb above the chunks.  A 32-byte record does not fit an atomic, so here the hand-off is record, then
+// counter, then the sibling's record (see the modes above).  The records carry the priority of the gap beyond the
+// child's far end (upper half of the dl word), so a level needs no other load before its hand-off.
+template <int MODE>
+__global__ __launch_bounds__(MODE == 3 ? kOneGroupThreads : kBlock) void climb_upper_kernel(ClimbArgs A) {
+    constexpr uint32_t kMine = 4096u;  // this kernel's arrivals; the local kernel's count in steps of 256
+    const uint32_t n = A.n;
+    const uint32_t count = *A.start_count;
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < count; t += gridDim.x * blockDim.x) {
+        const uint4 e = A.starters[t];
+        uint32_t parent = e.x;
+        uint32_t l = e.y, r = e.z, dl = e.w & 0xffffu, pl = (e.w >> 16) & 0xffu, pr = e.w >> 24;
+        float box[6];
+        {
             const ChildRec a = A.child[2 * (uint64_t)parent], b = A.child[2 * (uint64_t)parent + 1];  // left, right
 #pragma unroll
             for (int k = 0; k < 6; k++) box[k] = a.box[k];
             merge_sibling(box, b.box, true);
-            l = a.far_end;
-            r = b.far_end;
-            dl = a.dl + 1;
-        } else {
-            const TopoRec a = A.child_topo[2 * (uint64_t)parent], b = A.child_topo[2 * (uint64_t)parent + 1];
-            l = a.far_end;
-            r = b.far_end;
-            dl = a.dl + 1;
         }
-        // Every level is a chain of memory round trips (this kernel is bound by their latency, not by bytes), so what does
-        // not depend on each other is asked for together: the two priorities that name the parent and the prefix that
-        // places the node just finished.
         for (;;) {
-            const bool root = l == 0 && r == n - 1;
-            const uint32_t pr_r = (r != n - 1) ? (uint32_t)A.prio[r] : 0u;
-            const uint32_t pr_l = (l != 0) ? (uint32_t)A.prio[l - 1] : 0u;
-            if (BOXES) {
-                const uint32_t pre = l + spine_prefix(A.cnt_l, A.tile_sums, l) - dl;
-                put_node(A.nodes, pre, box, pre + 2u * (r - l + 1u) - 1u, 0u, A.paired);
-            }
-            if (root) {
-                if (!BOXES) A.cnt_l[0] = dl;
-                break;
-            }
-            const bool parent_right = (l == 0) || (r != n - 1 && pr_r > pr_l);
+            const uint32_t pre = l + spine_prefix(A.cnt_l, A.tile_sums, l) - dl;
+            put_node(A.nodes, pre, box, pre + 2u * (r - l + 1u) - 1u, 0u, A.paired);
+            if (l == 0 && r == n - 1) break;
+            const bool parent_right = (l == 0) || (r != n - 1 && pr > pl);
             parent = parent_right ? r : l - 1;
             const uint32_t side = parent_right ? 0u : 1u;
-            if (!BOXES && side == 1) A.cnt_l[l] = dl;
-            if (BOXES) child_store<MODE == 1 || MODE == 3>(&A.child[2 * (uint64_t)parent + side], box, parent_right ? l : r, dl);
-            else topo_store<MODE == 1 || MODE == 3>(&A.child_topo[2 * (uint64_t)parent + side], parent_right ? l : r, dl);
+            child_store<MODE == 1 || MODE == 3>(&A.child[2 * (uint64_t)parent + side], box, parent_right ? l : r,
+                                                dl | ((parent_right ? pl : pr) << 16));
             uint32_t old;
             if (MODE == 3) {
                 old = __hip_atomic_fetch_add(&A.flags[parent], kMine, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1014,24 +1123,21 @@ __global__ __launch_bounds__(MODE == 3 ? kOneGroupThreads : kBlock) void climb_u
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 old = atomicAdd(&A.flags[parent], kMine);
             }
-            old >>= kShift;
-            if ((old & 15u) + ((old >> 4) & 15u) == 0u) break;  // first to arrive: the sibling carries on from here
+            if (old == 0u) break;  // first to arrive: the sibling carries on from here
             if (MODE == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the sibling's record, released before its count
             if (MODE == 1) __threadfence();
             uint32_t s_far, s_dl;
-            if (BOXES) {
-                float sbox[6];
-                child_load<MODE == 1 || MODE == 3>(&A.child[2 * (uint64_t)parent + (1u - side)], sbox, &s_far, &s_dl);
-                merge_sibling(box, sbox, side == 0);
-            } else {
-                topo_load<MODE == 1 || MODE == 3>(&A.child_topo[2 * (uint64_t)parent + (1u - side)], &s_far, &s_dl);
-            }
+            float sbox[6];
+            child_load<MODE == 1 || MODE == 3>(&A.child[2 * (uint64_t)parent + (1u - side)], sbox, &s_far, &s_dl);
+            merge_sibling(box, sbox, side == 0);
             if (side == 0) {
                 r = s_far;
                 dl = dl + 1;
+                pr = s_dl >> 16;
             } else {
                 l = s_far;
-                dl = s_dl + 1;
+                dl = (s_dl & 0xffffu) + 1;
+                pl = s_dl >> 16;
             }
         }
     }
@@ -1269,13 +1375,14 @@ int radix_sort_workspace_device(rthip_ctx* ctx, uint64_t n, int n_bytes, hipStre
     uint64_t* keys[2] = {(uint64_t*)w.keys[0].p, (uint64_t*)w.keys[1].p};
     uint32_t* vals[2] = {(uint32_t*)w.vals[0].p, (uint32_t*)w.vals[1].p};
     int cur = *cur_io;
-    if (tiles <= kMergeTiles && !ctx->sort_by_passes) {
-        tile_sort_kernel<<<tiles, kSortBlock, 0, s>>>(keys[cur], identity_vals ? nullptr : vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, n_bytes);
+    const uint32_t small_tiles = div_up(n, kSmallTile);
+    if (small_tiles <= kMergeTiles && !ctx->sort_by_passes) {
+        tile_sort_kernel<<<small_tiles, kSmallSortBlock, 0, s>>>(keys[cur], identity_vals ? nullptr : vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, n_bytes);
         RT_HIP(ctx, hipGetLastError());
         cur ^= 1;
-        if (tiles > 1) {
+        if (small_tiles > 1) {
             const uint64_t mask = n_bytes >= 8 ? ~0ull : ((1ull << (8 * n_bytes)) - 1ull);
-            tile_merge_kernel<<<div_up(n, kBlock / 32), kBlock, 0, s>>>(keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], (uint32_t)n, tiles, mask);
+            tile_merge_kernel<<<div_up(n, 64), 256, 0, s>>>(keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], (uint32_t)n, small_tiles, mask);
             RT_HIP(ctx, hipGetLastError());
             cur ^= 1;
         }
@@ -1369,9 +1476,9 @@ int lbvh_reserve_workspace(rthip_ctx* ctx, uint64_t n, LbvhWorkspace* ws) {
     RT_TRY(rthip_reserve(ctx, w.scan_tmp, (scan_tmp_elems(hist_elems) + scan_tmp_elems(n)) * 4));
     RT_TRY(rthip_reserve(ctx, w.prio, n));
     RT_TRY(rthip_reserve(ctx, w.child, 2 * n * sizeof(ChildRec)));
-    RT_TRY(rthip_reserve(ctx, w.child_topo, 2 * n * sizeof(TopoRec)));
+    RT_TRY(rthip_reserve(ctx, w.child_topo, n * 8));
     RT_TRY(rthip_reserve(ctx, w.flags, n * 4));
-    RT_TRY(rthip_reserve(ctx, w.starters, n * 4));
+    RT_TRY(rthip_reserve(ctx, w.starters, (n / 2 + 1) * sizeof(uint4)));  // a leaf delivers to at most one such node, a node takes two
     RT_TRY(rthip_reserve(ctx, w.cnt_l, n * 4));
     RT_TRY(rthip_reserve(ctx, w.bounds, 64));
     return RTHIP_OK;
@@ -1399,11 +1506,11 @@ int lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, float4* 
     A.prio = (uint8_t*)w.prio.p;
     A.aabb6 = d_aabb6;
     A.child = (ChildRec*)w.child.p;
-    A.child_topo = (TopoRec*)w.child_topo.p;
+    A.topo_slot = (unsigned long long*)w.child_topo.p;
     A.flags = (uint32_t*)w.flags.p;
     A.cnt_l = (uint32_t*)w.cnt_l.p;
     A.tile_sums = nullptr;
-    A.starters = (uint32_t*)w.starters.p;
+    A.starters = (uint4*)w.starters.p;
     A.start_count = (uint32_t*)w.flags.p + (n - 1);
     A.nodes = d_nodes;
     A.paired = paired ? 1u : 0u;
@@ -1430,7 +1537,7 @@ int lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, float4* 
     }
     ctx->bounds_of = nullptr;
     // values: see identity_vals; the arrival counters of the n - 1 gaps + the starter count are cleared on the way
-    morton_kernel<<<div_up(n, kBlock), kBlock, 0, s>>>(d_aabb6, n, bounds, keys[0], nullptr, (uint32_t*)w.flags.p);
+    morton_kernel<<<div_up(n, kBlock), kBlock, 0, s>>>(d_aabb6, n, bounds, keys[0], nullptr, (uint32_t*)w.flags.p, A.topo_slot);
     RT_HIP(ctx, hipGetLastError());
     if (d_codes_unsorted)
         RT_HIP(ctx, hipMemcpyAsync(d_codes_unsorted, keys[0], n * 8, hipMemcpyDeviceToDevice, s));
@@ -1445,24 +1552,19 @@ int lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, float4* 
     const uint32_t chunks = div_up(n, kChunk);
     uint32_t ublocks = div_up(n - 1, kBlock);
     if (ublocks > 2048) ublocks = 2048;
-#define RT_UPPER(BOXES)                                                                  \
-    do {                                                                                 \
-        if (n <= kOneGroupUpper && !ctx->upper_device_wide) climb_upper_kernel<3, BOXES><<<1, kOneGroupThreads, 0, s>>>(A); \
-        else if (ctx->refit_fence == 1) climb_upper_kernel<1, BOXES><<<ublocks, kBlock, 0, s>>>(A); \
-        else if (ctx->refit_fence == 2) climb_upper_kernel<2, BOXES><<<ublocks, kBlock, 0, s>>>(A); \
-        else climb_upper_kernel<0, BOXES><<<ublocks, kBlock, 0, s>>>(A);                 \
-    } while (0)
-    // topology: gap priorities, left-spine lengths, the list of gaps the upper kernels start from
+    // topology: gap priorities, left-spine lengths, the list of nodes the upper kernels start from
     climb_local_kernel<false><<<chunks, kChunk, 0, s>>>(A);
     RT_HIP(ctx, hipGetLastError());
-    RT_UPPER(false);
+    climb_upper_topo_kernel<<<ublocks, kBlock, 0, s>>>(A);
     RT_HIP(ctx, hipGetLastError());
     RT_TRY(scan_u32_tiles(ctx, (uint32_t*)w.cnt_l.p, n, scan_tmp + scan_tmp_elems(hist_elems), s, &A.tile_sums));
     // boxes: every node's record goes to its pre-order place
     climb_local_kernel<true><<<chunks, kChunk, 0, s>>>(A);
     RT_HIP(ctx, hipGetLastError());
-    RT_UPPER(true);
-#undef RT_UPPER
+    if (n <= kOneGroupUpper && !ctx->upper_device_wide) climb_upper_kernel<3><<<1, kOneGroupThreads, 0, s>>>(A);
+    else if (ctx->refit_fence == 1) climb_upper_kernel<1><<<ublocks, kBlock, 0, s>>>(A);
+    else if (ctx->refit_fence == 2) climb_upper_kernel<2><<<ublocks, kBlock, 0, s>>>(A);
+    else climb_upper_kernel<0><<<ublocks, kBlock, 0, s>>>(A);
     RT_HIP(ctx, hipGetLastError());
     return RTHIP_OK;
 }
@@ -1516,8 +1618,8 @@ int lbvh_static_workspace_init(rthip_ctx* ctx) {
               carve(w.block_hist, base, off, hist_bytes) &&
               carve(w.scan_tmp, base, off, (scan_tmp_elems(hist_elems) + scan_tmp_elems(n)) * 4) &&
               carve(w.prio, base, off, n) && carve(w.child, base, off, 2 * n * sizeof(ChildRec)) &&
-              carve(w.child_topo, base, off, 2 * n * sizeof(TopoRec)) && carve(w.flags, base, off, n * 4) &&
-              carve(w.starters, base, off, n * 4) && carve(w.cnt_l, base, off, n * 4) && carve(w.bounds, base, off, 64);
+              carve(w.child_topo, base, off, n * 8) && carve(w.flags, base, off, n * 4) &&
+              carve(w.starters, base, off, (n / 2 + 1) * sizeof(uint4)) && carve(w.cnt_l, base, off, n * 4) && carve(w.bounds, base, off, 64);
     if (!ok) return rthip_fail(ctx, RTHIP_E_LIMIT, "the static workspace of %zu bytes is too small for %llu boxes", kStaticBytes, (unsigned long long)n);
     ctx->ws_static_ready = true;
     return RTHIP_OK;

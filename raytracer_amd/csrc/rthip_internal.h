@@ -33,7 +33,7 @@ struct LbvhWorkspace {
     DevBuf scan_aux;    // the same for scan_inclusive_u32_device
     DevBuf prio;        // uint8[n-1]  split priority of every gap
     DevBuf child;       // ChildRec[2(n-1)]  box climb: records for parents that span chunks
-    DevBuf child_topo;  // TopoRec[2(n-1)]   topology climb: the same
+    DevBuf child_topo;  // uint64[n-1]       topology climb: one hand-over word per gap
     DevBuf flags;       // uint32[n-1] arrival counters (+ the starter count)
     DevBuf starters;    // gaps whose two children both arrived in the chunk-local kernel (start list of the upper kernels)
     DevBuf cnt_l;       // uint32[n]   left-spine lengths, then their tile-wise inclusive scan
