@@ -755,11 +755,6 @@ __device__ __forceinline__ uint8_t gap_priority_of(const uint64_t* keys, uint64_
 // The box climb's arrival counter of a gap is shared by its two kernels; the first arrival finds 0.
 constexpr int kChunk = 512;  // sorted leaves per workgroup, one per thread
 
-struct alignas(8) TopoRec {  // what a child leaves at its parent in the topology climb
-    uint32_t far_end;
-    uint32_t dl;
-};
-
 template <bool FENCE>
 __device__ __forceinline__ void child_store(ChildRec* slot, const float* box, uint32_t far_end, uint32_t dl) {
     uint64_t w0 = (uint64_t)__float_as_uint(box[0]) | ((uint64_t)__float_as_uint(box[1]) << 32);
@@ -875,20 +870,20 @@ __device__ __forceinline__ void climb_local(uint32_t c0, const ClimbArgs& A) {
     // Gaps that do not exist (-1, >= n-1) read as 0, below every real priority (>= 1).
     __shared__ uint8_t win[kChunk + 8];
     __shared__ uint32_t lflag[kChunk];
-    __shared__ uint64_t lrec_raw[(BOXES ? sizeof(ChildRec) : sizeof(TopoRec)) * 2 * kChunk / 8];
+    __shared__ uint64_t lrec_raw[BOXES ? sizeof(ChildRec) * 2 * kChunk / 8 : 1];
     __shared__ uint32_t wmin_l[kChunk / 64], wmin_r[kChunk / 64];
     __shared__ uint32_t n_start, base_start;  // gaps that this workgroup found complete for the upper kernels
     ChildRec* lrec_box = (ChildRec*)lrec_raw;
-    TopoRec* lrec_topo = (TopoRec*)lrec_raw;
 
     const uint32_t n = A.n;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     if (tid == 0) n_start = 0;
 
+    const uint32_t i = c0 + (uint32_t)tid;
     {
         const int64_t g = (int64_t)c0 - 1 + tid;
         const bool exists = g >= 0 && g + 1 < (int64_t)n;
-        uint8_t p = 0;
+        uint8_t p = 0, pe = 0;
         if (exists) {
             if (BOXES || A.prio_ready) p = A.prio[g];
             else {
@@ -896,10 +891,8 @@ __device__ __forceinline__ void climb_local(uint32_t c0, const ClimbArgs& A) {
                 if (tid >= 1) A.prio[g] = p;  // entry 0 is the previous chunk's last gap: that chunk writes it
             }
         }
-        win[tid] = p;
         if (tid == 0) {
             const int64_t ge = (int64_t)c0 - 1 + kChunk;
-            uint8_t pe = 0;
             if (ge + 1 < (int64_t)n) {
                 if (BOXES || A.prio_ready) pe = A.prio[ge];
                 else {
@@ -907,8 +900,9 @@ __device__ __forceinline__ void climb_local(uint32_t c0, const ClimbArgs& A) {
                     A.prio[ge] = pe;
                 }
             }
-            win[kChunk] = pe;
         }
+        win[tid] = p;
+        if (tid == 0) win[kChunk] = pe;
     }
     lflag[tid] = 0;
     __syncthreads();
@@ -939,7 +933,6 @@ __device__ __forceinline__ void climb_local(uint32_t c0, const ClimbArgs& A) {
     }
     __syncthreads();
 
-    const uint32_t i = c0 + (uint32_t)tid;
     uint4 my_start = make_uint4(0u, 0u, 0u, 0u);
     bool have_start = false;
     uint32_t my_slot = 0;
@@ -970,28 +963,23 @@ __device__ __forceinline__ void climb_local(uint32_t c0, const ClimbArgs& A) {
             if (!BOXES && side == 1) A.cnt_l[l] = dl;  // a right child tops the left spine that starts at l
             const uint32_t far_end = parent_right ? l : r;
             if (!local) {  // the parent spans chunks: leave the record for the upper kernel
-                const uint32_t far_prio = (parent_right ? pr_l : pr_r) & 0x7fu;  // of the gap beyond the far end
                 if (BOXES) {
+                    const uint32_t far_prio = (parent_right ? pr_l : pr_r) & 0x7fu;  // of the gap beyond the far end
                     ChildRec mine;
 #pragma unroll
                     for (int k = 0; k < 6; k++) mine.box[k] = box[k];
                     mine.far_end = far_end;
                     mine.dl = dl | (far_prio << 16);
                     A.child[2 * (uint64_t)parent + side] = mine;
-                    atomicAdd(&A.flags[parent], 256u);
-                } else {
-                    const unsigned long long sib = atomicExch(&A.topo_slot[parent], topo_pack(far_end, dl, far_prio));
-                    if (sib != 0ull) {  // second to arrive: the parent is complete and goes on the upper kernels' list
-                        uint32_t s_far, s_dl, s_prio;
-                        topo_unpack(sib, &s_far, &s_dl, &s_prio);
-                        my_start = side == 0 ? start_pack(parent, l, s_far, dl + 1u, pr_l & 0x7fu, s_prio)
-                                             : start_pack(parent, s_far, r, s_dl + 1u, s_prio, pr_r & 0x7fu);
-                        have_start = true;
-                    }
+                    atomicAdd(&A.flags[parent], 1u);
+                } else {  // handed over after the loop, so that the lanes still climbing do not wait for this round trip
+                    my_start = start_pack(parent, l, r, dl, pr_l & 0x7fu, pr_r & 0x7fu);
+                    have_start = true;
                 }
                 break;
             }
             const uint32_t slot = parent - c0;
+            uint32_t s_far, s_dl;
             if (BOXES) {
                 ChildRec mine;
 #pragma unroll
@@ -999,26 +987,23 @@ __device__ __forceinline__ void climb_local(uint32_t c0, const ClimbArgs& A) {
                 mine.far_end = far_end;
                 mine.dl = dl;
                 lrec_box[2 * slot + side] = mine;
-            } else {
-                TopoRec mine = {far_end, dl};
-                lrec_topo[2 * slot + side] = mine;
-            }
-            // order the LDS record before the LDS counter and the counter before the sibling's record; LDS only:
-            // a fence that also covered global memory would make every level wait for the node stores below it
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-            const uint32_t old = atomicAdd(&lflag[slot], 1u);
-            if (old == 0) break;  // first to arrive: the sibling's thread carries on from here
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-            uint32_t s_far, s_dl;
-            if (BOXES) {
+                // order the LDS record before the LDS counter and the counter before the sibling's record; LDS only:
+                // a fence that also covered global memory would make every level wait for the node stores below it
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+                const uint32_t old = atomicAdd(&lflag[slot], 1u);
+                if (old == 0) break;  // first to arrive: the sibling's thread carries on from here
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
                 const ChildRec sib = lrec_box[2 * slot + (1u - side)];
                 merge_sibling(box, sib.box, side == 0);
                 s_far = sib.far_end;
                 s_dl = sib.dl;
             } else {
-                const TopoRec sib = lrec_topo[2 * slot + (1u - side)];
-                s_far = sib.far_end;
-                s_dl = sib.dl;
+                // the topology record of a node inside the chunk fits one LDS word (far end relative to the chunk + 1,
+                // left-spine length) and is handed over by one atomic exchange: 0 back means first to arrive
+                const uint32_t sib = atomicExch(&lflag[slot], (far_end - c0 + 1u) | (dl << 16));
+                if (sib == 0u) break;
+                s_far = c0 + (sib & 0xffffu) - 1u;
+                s_dl = sib >> 16;
             }
             if (side == 0) {
                 r = s_far;
@@ -1030,7 +1015,20 @@ __device__ __forceinline__ void climb_local(uint32_t c0, const ClimbArgs& A) {
             if (BOXES) put_inner(A.nodes, A.cnt_l, A.tile_sums, box, l, r, dl, A.paired);
         }
     }
-    if (!BOXES) {  // hand the complete gaps to the upper kernels: one device-wide atomic per workgroup
+    if (!BOXES) {
+        if (have_start) {  // this thread's node has a parent that spans chunks (my_start: the node itself so far)
+            const uint32_t parent = my_start.x, l = my_start.y, r = my_start.z;
+            const uint32_t dl = my_start.w & 0xffffu, pl = (my_start.w >> 16) & 0xffu, pr = my_start.w >> 24;
+            const bool left = parent == r;  // this node is the parent's left child
+            const unsigned long long sib = atomicExch(&A.topo_slot[parent], topo_pack(left ? l : r, dl, left ? pl : pr));
+            have_start = sib != 0ull;  // second to arrive: the parent is complete and goes on the upper kernels' list
+            if (have_start) {
+                uint32_t s_far, s_dl, s_prio;
+                topo_unpack(sib, &s_far, &s_dl, &s_prio);
+                my_start = left ? start_pack(parent, l, s_far, dl + 1u, pl, s_prio) : start_pack(parent, s_far, r, s_dl + 1u, s_prio, pr);
+            }
+        }
+        // hand the complete nodes to the upper kernels: one device-wide atomic per workgroup
         if (have_start) my_slot = atomicAdd(&n_start, 1u);
         __syncthreads();
         if (tid == 0 && n_start != 0) base_start = atomicAdd(A.start_count, n_start);
@@ -1090,7 +1088,7 @@ constexpr int kOneGroupThreads = 1024;
 // child's far end (upper half of the dl word), so a level needs no other load before its hand-off.
 template <int MODE>
 __global__ __launch_bounds__(MODE == 3 ? kOneGroupThreads : kBlock) void climb_upper_kernel(ClimbArgs A) {
-    constexpr uint32_t kMine = 4096u;  // this kernel's arrivals; the local kernel's count in steps of 256
+    constexpr uint32_t kMine = 1u;
     const uint32_t n = A.n;
     const uint32_t count = *A.start_count;
     for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < count; t += gridDim.x * blockDim.x) {
