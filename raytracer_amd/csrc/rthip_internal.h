@@ -37,7 +37,7 @@ struct LbvhWorkspace {
     DevBuf flags;       // uint32[n-1] arrival counters (+ the starter count)
     DevBuf starters;    // gaps whose two children both arrived in the chunk-local kernel (start list of the upper kernels)
     DevBuf cnt_l;       // uint32[n]   left-spine lengths, then their tile-wise inclusive scan
-    DevBuf bounds;      // uint32[6]   ordered-int centroid bounds
+    DevBuf bounds;      // ordered-int centroid bounds, in several copies that the Morton kernel folds
 };
 
 // One LBVH in HBM, pre-order, 2 x float4 per node:
