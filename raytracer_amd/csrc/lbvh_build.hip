@@ -255,15 +255,16 @@ __global__ __launch_bounds__(kBlock) void morton_kernel(const float* __restrict_
 // ---- K3: LSD radix sort, 8 bits per pass, stable ---------------------------------------
 // Replaces radsort(...) at lbvh.c:120.  Equal codes keep ascending primitive index.
 
-__global__ __launch_bounds__(kSortBlock) void radix_hist_kernel(const uint64_t* __restrict__ keys, uint64_t n, int shift,
-                                                                uint32_t* __restrict__ block_hist, uint32_t tiles) {
+template <int BLOCK>  // threads per workgroup; a tile is BLOCK * kSortItems keys
+__global__ __launch_bounds__(BLOCK) void radix_hist_kernel(const uint64_t* __restrict__ keys, uint64_t n, int shift,
+                                                           uint32_t* __restrict__ block_hist, uint32_t tiles) {
     __shared__ uint32_t hist[256];
     if (threadIdx.x < 256) hist[threadIdx.x] = 0;
     __syncthreads();
-    uint64_t base = (uint64_t)blockIdx.x * kSortTile;
+    uint64_t base = (uint64_t)blockIdx.x * (BLOCK * kSortItems);
 #pragma unroll
     for (int j = 0; j < kSortItems; j++) {
-        uint64_t i = base + (uint64_t)j * kSortBlock + threadIdx.x;
+        uint64_t i = base + (uint64_t)j * BLOCK + threadIdx.x;
         if (i < n) atomicAdd(&hist[(uint32_t)(keys[i] >> shift) & 255u], 1u);
     }
     __syncthreads();
@@ -311,15 +312,19 @@ __global__ __launch_bounds__(kBlock) void radix_offsets_kernel(uint32_t* __restr
     if (tid == 0) block_hist[256ull * tiles + blockIdx.x] = carry;
 }
 
-// Each workgroup ranks its 4096 keys by the current digit (wave-level match-any on
+// Each workgroup ranks the keys of its tile by the current digit (wave-level match-any on
 // ballots, wave-private LDS counters), sorts the tile in LDS and writes every digit
 // bucket to its place in the output with consecutive lanes on consecutive addresses.
-__global__ __launch_bounds__(kSortBlock) void radix_scatter_kernel(const uint64_t* __restrict__ keys_in,
-                                                                   const uint32_t* __restrict__ vals_in,
-                                                                   uint64_t* __restrict__ keys_out,
-                                                                   uint32_t* __restrict__ vals_out, uint64_t n, int shift,
-                                                                   const uint32_t* __restrict__ gbase, uint32_t tiles) {
+// Tiles of 4096 keys (1024 threads); of 1024 keys (256 threads) for inputs so small that the large tiles would leave
+// most CUs idle (see radix_sort_workspace_device).
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void radix_scatter_kernel(const uint64_t* __restrict__ keys_in,
+                                                              const uint32_t* __restrict__ vals_in,
+                                                              uint64_t* __restrict__ keys_out,
+                                                              uint32_t* __restrict__ vals_out, uint64_t n, int shift,
+                                                              const uint32_t* __restrict__ gbase, uint32_t tiles) {
     // gbase[d * tiles + t]: keys with digit d in the tiles before t; gbase[256 * tiles + d]: keys with digit d
+    constexpr int kSortBlock = BLOCK, kSortTile = BLOCK * kSortItems;  // shadow the file-scope values of the large tile
     constexpr int kWaves = kSortBlock / 64;
     __shared__ uint32_t wave_cnt[kWaves][256];
     __shared__ uint32_t bin_start[256];
@@ -334,11 +339,20 @@ __global__ __launch_bounds__(kSortBlock) void radix_scatter_kernel(const uint64_
 
     for (int k = tid; k < kWaves * 256; k += kSortBlock) (&wave_cnt[0][0])[k] = 0;
 
+    // everything the tile needs from global memory is asked for here, in one round trip: keys, values, and the two
+    // offsets of "its" digit that each of the first 256 threads will use after the ranking
     uint64_t key[kSortItems];
+    uint32_t val[kSortItems];
 #pragma unroll
     for (int j = 0; j < kSortItems; j++) {
         uint64_t i = wbase + (uint64_t)j * 64 + lane;
         key[j] = (i < n) ? keys_in[i] : ~0ull;
+        val[j] = (i < n) ? (vals_in ? vals_in[i] : (uint32_t)i) : 0u;
+    }
+    uint32_t total = 0, before_tile = 0;
+    if (tid < 256) {
+        total = gbase[256ull * tiles + tid];
+        before_tile = gbase[(uint64_t)tid * tiles + blockIdx.x];
     }
     __syncthreads();
 
@@ -376,11 +390,6 @@ __global__ __launch_bounds__(kSortBlock) void radix_scatter_kernel(const uint64_
                 run += c;
             }
         }
-        uint32_t total = 0, before_tile = 0;
-        if (owner) {
-            total = gbase[256ull * tiles + tid];
-            before_tile = gbase[(uint64_t)tid * tiles + blockIdx.x];
-        }
         uint32_t incl = run, dincl = total;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -413,9 +422,8 @@ __global__ __launch_bounds__(kSortBlock) void radix_scatter_kernel(const uint64_
     for (int j = 0; j < kSortItems; j++) {
         uint32_t d = (uint32_t)(key[j] >> shift) & 255u;
         uint32_t pos = bin_start[d] + wave_cnt[wave][d] + rank[j];
-        uint64_t i = wbase + (uint64_t)j * 64 + lane;
         skeys[pos] = key[j];
-        svals[pos] = (i < n) ? (vals_in ? vals_in[i] : (uint32_t)i) : 0u;
+        svals[pos] = val[j];
     }
     __syncthreads();
 
@@ -1393,7 +1401,11 @@ size_t scan_tmp_elems(uint64_t n) {
 int radix_sort_workspace_device(rthip_ctx* ctx, uint64_t n, int n_bytes, hipStream_t s, int* cur_io, LbvhWorkspace* ws,
                                 bool identity_vals) {
     LbvhWorkspace& w = ws ? *ws : ctx->ws;
-    const uint32_t tiles = div_up(n, kSortTile);
+    // Sizes just above the merge path sort in tiles of 1024 keys, which spreads a pass over more CUs.  Measured (whole
+    // build, 1024- against 4096-key tiles): 200 000 keys 0.224 / 0.241 ms, 500 000 0.274 / 0.276, 10^6 0.369 / 0.334,
+    // 4 * 10^6 1.02 / 0.83 -- the four times larger tile histogram soon costs more than the spread gains.
+    const bool small_tile = n <= ctx->sort_small_tile_max;
+    const uint32_t tiles = small_tile ? div_up(n, kSmallTile) : div_up(n, kSortTile);
     RT_TRY(rthip_reserve(ctx, w.block_hist, (256ull * tiles + 256) * 4));
     uint64_t* keys[2] = {(uint64_t*)w.keys[0].p, (uint64_t*)w.keys[1].p};
     uint32_t* vals[2] = {(uint32_t*)w.vals[0].p, (uint32_t*)w.vals[1].p};
@@ -1418,11 +1430,16 @@ int radix_sort_workspace_device(rthip_ctx* ctx, uint64_t n, int n_bytes, hipStre
     // counts but not yet their inclusive ones, so every look-back walks far, one device-scope load latency per step.
     for (int pass = 0; pass < n_bytes; pass++) {
         const int shift = pass * 8;
-        radix_hist_kernel<<<tiles, kSortBlock, 0, s>>>(keys[cur], n, shift, (uint32_t*)w.block_hist.p, tiles);
+        uint32_t* hist = (uint32_t*)w.block_hist.p;
+        const uint32_t* v_in = (pass == 0 && identity_vals) ? nullptr : vals[cur];
+        if (small_tile) radix_hist_kernel<kSmallSortBlock><<<tiles, kSmallSortBlock, 0, s>>>(keys[cur], n, shift, hist, tiles);
+        else radix_hist_kernel<kSortBlock><<<tiles, kSortBlock, 0, s>>>(keys[cur], n, shift, hist, tiles);
         RT_HIP(ctx, hipGetLastError());
-        radix_offsets_kernel<<<256, kBlock, 0, s>>>((uint32_t*)w.block_hist.p, tiles);
-        radix_scatter_kernel<<<tiles, kSortBlock, 0, s>>>(keys[cur], (pass == 0 && identity_vals) ? nullptr : vals[cur], keys[cur ^ 1],
-                                                      vals[cur ^ 1], n, shift, (const uint32_t*)w.block_hist.p, tiles);
+        radix_offsets_kernel<<<256, kBlock, 0, s>>>(hist, tiles);
+        if (small_tile)
+            radix_scatter_kernel<kSmallSortBlock><<<tiles, kSmallSortBlock, 0, s>>>(keys[cur], v_in, keys[cur ^ 1], vals[cur ^ 1], n, shift, hist, tiles);
+        else
+            radix_scatter_kernel<kSortBlock><<<tiles, kSortBlock, 0, s>>>(keys[cur], v_in, keys[cur ^ 1], vals[cur ^ 1], n, shift, hist, tiles);
         RT_HIP(ctx, hipGetLastError());
         cur ^= 1;
     }
@@ -1488,7 +1505,7 @@ int instance_aabbs_device(rthip_ctx* ctx, const DevInstance* d_inst, uint32_t n,
 
 int lbvh_reserve_workspace(rthip_ctx* ctx, uint64_t n, LbvhWorkspace* ws) {
     LbvhWorkspace& w = ws ? *ws : ctx->ws;
-    const uint32_t tiles = div_up(n, kSortTile);
+    const uint32_t tiles = n <= ctx->sort_small_tile_max ? div_up(n, kSmallTile) : div_up(n, kSortTile);
     const uint64_t hist_elems = 256ull * tiles;
     RT_TRY(rthip_reserve(ctx, w.keys[0], n * 8));
 
@@ -1496,7 +1513,7 @@ int lbvh_reserve_workspace(rthip_ctx* ctx, uint64_t n, LbvhWorkspace* ws) {
     RT_TRY(rthip_reserve(ctx, w.vals[0], n * 4));
     RT_TRY(rthip_reserve(ctx, w.vals[1], n * 4));
     RT_TRY(rthip_reserve(ctx, w.block_hist, (hist_elems + 256) * 4));
-    RT_TRY(rthip_reserve(ctx, w.scan_tmp, (scan_tmp_elems(hist_elems) + scan_tmp_elems(n)) * 4));
+    RT_TRY(rthip_reserve(ctx, w.scan_tmp, scan_tmp_elems(n) * 4));
     RT_TRY(rthip_reserve(ctx, w.prio, n));
     RT_TRY(rthip_reserve(ctx, w.child, 2 * n * sizeof(ChildRec)));
     RT_TRY(rthip_reserve(ctx, w.child_topo, n * 8));
@@ -1515,8 +1532,6 @@ int lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, float4* 
                                             (unsigned long long)n);
     LbvhWorkspace& w = ws ? *ws : ctx->ws;
     if (ws) ctx->bounds_of = nullptr;  // bounds left by a triangle pass are in the context's own workspace
-    const uint32_t tiles = div_up(n, kSortTile);
-    const uint64_t hist_elems = 256ull * tiles;
     RT_TRY(lbvh_reserve_workspace(ctx, n, &w));
 
     uint32_t* bounds = (uint32_t*)w.bounds.p;
@@ -1580,7 +1595,7 @@ int lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, float4* 
     RT_HIP(ctx, hipGetLastError());
     climb_upper_topo_kernel<<<ublocks, kBlock, 0, s>>>(A);
     RT_HIP(ctx, hipGetLastError());
-    RT_TRY(scan_u32_tiles(ctx, (uint32_t*)w.cnt_l.p, n, scan_tmp + scan_tmp_elems(hist_elems), s, &A.tile_sums));
+    RT_TRY(scan_u32_tiles(ctx, (uint32_t*)w.cnt_l.p, n, scan_tmp, s, &A.tile_sums));
     // boxes: every node's record goes to its pre-order place
     climb_local_kernel<true><<<chunks, kChunk, 0, s>>>(A);
     RT_HIP(ctx, hipGetLastError());
@@ -1631,7 +1646,7 @@ int lbvh_static_workspace_init(rthip_ctx* ctx) {
     }
     unsigned char* base = (unsigned char*)g_scratch_ptr[ctx->device];
     const uint64_t n = kStaticBuildMaxBoxes;
-    const uint32_t tiles = div_up(n, kSortTile);
+    const uint32_t tiles = div_up(n, kSmallTile);  // the finer of the two tilings
     const uint64_t hist_elems = 256ull * tiles;
     const size_t hist_bytes = (hist_elems + 256) * 4;
     LbvhWorkspace& w = ctx->ws_static;
@@ -1639,7 +1654,7 @@ int lbvh_static_workspace_init(rthip_ctx* ctx) {
     bool ok = carve(w.keys[0], base, off, n * 8) && carve(w.keys[1], base, off, n * 8) && carve(w.vals[0], base, off, n * 4) &&
               carve(w.vals[1], base, off, n * 4) &&
               carve(w.block_hist, base, off, hist_bytes) &&
-              carve(w.scan_tmp, base, off, (scan_tmp_elems(hist_elems) + scan_tmp_elems(n)) * 4) &&
+              carve(w.scan_tmp, base, off, scan_tmp_elems(n) * 4) &&
               carve(w.prio, base, off, n) && carve(w.child, base, off, 2 * n * sizeof(ChildRec)) &&
               carve(w.child_topo, base, off, n * 8) && carve(w.flags, base, off, n * 4) &&
               carve(w.starters, base, off, (n / 2 + 1) * sizeof(uint4)) && carve(w.cnt_l, base, off, n * 4) && carve(w.bounds, base, off, kBoundBytes);
