@@ -670,14 +670,23 @@ __global__ __launch_bounds__(kBlock) void scan_tile_kernel(uint32_t* __restrict_
                                                            uint32_t* __restrict__ sums) {
     __shared__ uint32_t wave_tot[kBlock / 64];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    static_assert(kScanItems == 8, "a thread's items are two 16-byte vectors");
     uint64_t base = (uint64_t)blockIdx.x * kScanTile + (uint64_t)tid * kScanItems;
+    // a thread's eight values as two 16-byte accesses wherever the array allows it: with 4-byte accesses every
+    // instruction of a wave touches all 16 of its cache lines (10^7 values: 43 us against 16)
+    const bool vec = base + kScanItems <= n && ((uintptr_t)data & 15u) == 0;
     uint32_t v[kScanItems];
+    if (vec) {
+        const uint4 a = ((const uint4*)(data + base))[0], b = ((const uint4*)(data + base))[1];
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+        v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < kScanItems; j++) v[j] = (base + j < n) ? data[base + j] : 0u;
+    }
     uint32_t run = 0;
 #pragma unroll
-    for (int j = 0; j < kScanItems; j++) {
-        v[j] = (base + j < n) ? data[base + j] : 0u;
-        run += v[j];
-    }
+    for (int j = 0; j < kScanItems; j++) run += v[j];
     uint32_t incl = run;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -692,12 +701,21 @@ __global__ __launch_bounds__(kBlock) void scan_tile_kernel(uint32_t* __restrict_
         total += wave_tot[w];
     }
     uint32_t acc = wsum + incl - run;  // exclusive prefix of this thread's first item
+    uint32_t o[kScanItems];
 #pragma unroll
     for (int j = 0; j < kScanItems; j++) {
         uint32_t x = v[j];
         if (INCLUSIVE) acc += x;
-        if (base + j < n) data[base + j] = acc;
+        o[j] = acc;
         if (!INCLUSIVE) acc += x;
+    }
+    if (vec) {
+        ((uint4*)(data + base))[0] = make_uint4(o[0], o[1], o[2], o[3]);
+        ((uint4*)(data + base))[1] = make_uint4(o[4], o[5], o[6], o[7]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < kScanItems; j++)
+            if (base + j < n) data[base + j] = o[j];
     }
     if (sums && tid == 0) sums[blockIdx.x] = total;
 }
@@ -1615,7 +1633,7 @@ int lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, float4* 
 namespace {
 
 constexpr size_t kStaticSlack = 1u << 20;  // block histograms, scan sums, bounds, alignment padding
-constexpr size_t kStaticBytes = kStaticBuildMaxBoxes * 120u + kStaticSlack;  // 117 bytes per box: keys, values, priorities, child slots, counters
+constexpr size_t kStaticBytes = kStaticBuildMaxBoxes * 120u + kStaticSlack;  // 113 bytes per box: keys, values, priorities, child slots, hand-over words, counters, lists
 static __device__ __align__(256) unsigned char scratch[kStaticBytes];
 
 constexpr int kMaxDevices = 64;
