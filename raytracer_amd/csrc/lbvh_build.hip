@@ -737,22 +737,36 @@ __global__ __launch_bounds__(kBlock) void scan_add_kernel(uint32_t* __restrict__
 __device__ __forceinline__ uint8_t gap_priority_of(const uint64_t* keys, uint64_t n, uint64_t g) {
     uint64_t k0 = keys[g], k1 = keys[g + 1];
     if (k0 != k1) return (uint8_t)__clzll((long long)(k0 ^ k1));
-    // run of equal codes [a, b): a = first index with key == k0, b = first index with key > k0
-    uint64_t lo = 0, hi = g;
+    // Run of equal codes [a, b): a = first index with key == k0, b = first index with key > k0.  Both ends are looked
+    // for outwards from the gap in doubling steps, then by bisection inside the last step: the runs that occur in
+    // practice are short (the two triangles of an axis-aligned quad share their box, hence their code), and a pair
+    // costs two loads next to the gap instead of two bisections of the whole array.
+    uint64_t in = g, step = 1;  // keys[in] == k0
+    while (in >= step && keys[in - step] == k0) {
+        in -= step;
+        step <<= 1;
+    }
+    uint64_t lo = in >= step ? in - step + 1 : 0, hi = in;  // the first key of the run is in [lo, hi]
     while (lo < hi) {
         uint64_t mid = (lo + hi) >> 1;
         if (keys[mid] < k0) lo = mid + 1;
         else hi = mid;
     }
-    uint64_t a = lo;
-    lo = g + 1;
-    hi = n;
+    const uint64_t a = lo;
+    in = g + 1;
+    step = 1;
+    while (in + step < n && keys[in + step] == k0) {
+        in += step;
+        step <<= 1;
+    }
+    lo = in + 1;  // the first key behind the run is in [lo, hi]
+    hi = in + step < n ? in + step : n;
     while (lo < hi) {
         uint64_t mid = (lo + hi) >> 1;
         if (keys[mid] > k0) hi = mid;
         else lo = mid + 1;
     }
-    uint64_t b = lo;
+    const uint64_t b = lo;
     uint64_t s = a, c = b - a;
     uint32_t depth = 0;
     for (;;) {
@@ -923,12 +937,16 @@ __device__ __forceinline__ void climb_local(uint32_t c0, const ClimbArgs& A) {
     __shared__ uint32_t lflag[kChunk];
     __shared__ uint64_t lrec_raw[BOXES ? sizeof(ChildRec) * 2 * kChunk / 8 : 1];
     __shared__ uint32_t wmin_l[kChunk / 64], wmin_r[kChunk / 64];
-    __shared__ uint32_t n_start, base_start;  // gaps that this workgroup found complete for the upper kernels
+    __shared__ uint32_t n_start, waves_done;  // nodes that this workgroup found complete for the upper kernels
+    __shared__ uint4 stage[BOXES ? 1 : kChunk];
     ChildRec* lrec_box = (ChildRec*)lrec_raw;
 
     const uint32_t n = A.n;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    if (tid == 0) n_start = 0;
+    if (tid == 0) {
+        n_start = 0;
+        waves_done = 0;
+    }
 
     const uint32_t i = c0 + (uint32_t)tid;
     {
@@ -1079,12 +1097,28 @@ __device__ __forceinline__ void climb_local(uint32_t c0, const ClimbArgs& A) {
                 my_start = left ? start_pack(parent, l, s_far, dl + 1u, pl, s_prio) : start_pack(parent, s_far, r, s_dl + 1u, s_prio, pr);
             }
         }
-        // hand the complete nodes to the upper kernels: one device-wide atomic per workgroup
-        if (have_start) my_slot = atomicAdd(&n_start, 1u);
-        __syncthreads();
-        if (tid == 0 && n_start != 0) base_start = atomicAdd(A.start_count, n_start);
-        __syncthreads();
-        if (have_start) A.starters[base_start + my_slot] = my_start;
+        // Hand the complete nodes to the upper kernels with one device-wide atomic per workgroup, without a workgroup
+        // barrier: a wave stages its nodes in LDS and is done; the last wave to get here (the one with the chunk's
+        // longest climb) takes the workgroup's place in the list and copies the staged nodes out.  The other waves'
+        // slots are free for the next workgroup in the meantime.
+        if (have_start) {
+            my_slot = atomicAdd(&n_start, 1u);
+            stage[my_slot] = my_start;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        uint32_t before = 0;
+        if (lane == 0) before = __hip_atomic_fetch_add(&waves_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        before = __shfl(before, 0);
+        if (before == blockDim.x / 64 - 1) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+            const uint32_t total = n_start;
+            if (total != 0) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(A.start_count, total);
+                base = __shfl(base, 0);
+                for (uint32_t k = lane; k < total; k += 64) A.starters[base + k] = stage[k];
+            }
+        }
     }
 }
 

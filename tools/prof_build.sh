@@ -5,5 +5,5 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_build_$N
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
-timeout -s KILL 180 rocprofv3 --kernel-trace --output-format csv -d $OUT -- python3 $ROOT/tools/probe_build.py $N > $OUT/run.log 2>&1 || { tail -5 $OUT/run.log; exit 1; }
+timeout -s KILL 180 rocprofv3 --kernel-trace --output-format csv -d $OUT -- python3 $ROOT/tools/probe_build.py $N $2 > $OUT/run.log 2>&1 || { tail -5 $OUT/run.log; exit 1; }
 python3 $ROOT/tools/build_breakdown.py $(find $OUT -name '*kernel_trace.csv' | head -1)
