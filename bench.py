@@ -54,9 +54,9 @@ def make_workload(name: str):
         return dict(world=w, cam=cam, sky=sky, width=1920, height=1080, samples=1, bounces=4,
                     label="10M-triangle soup (1 BLAS), 1920x1080, samples=1, bounces=4, sky on")
     if name == "heightfield":
-        w, cam, sky = scenes.heightfield_world(3163, seed=1)
+        w, cam, sky = scenes.heightfield_world(2236, seed=1)
         return dict(world=w, cam=cam, sky=sky, width=1920, height=1080, samples=1, bounces=4,
-                    label="10M-triangle displaced height field (3163^2 x 2 triangles, 1 indexed BLAS: a coherent surface), "
+                    label="10M-triangle displaced height field (2236^2 cells x 2 triangles, 1 indexed BLAS: a coherent surface), "
                           "1920x1080, samples=1, bounces=4, sky on")
     if name == "soup-rays":
         w, cam, sky = scenes.soup_world(10_000_000, seed=1)

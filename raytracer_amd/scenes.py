@@ -455,9 +455,9 @@ def soup_world(n_tris: int, seed: int = 1):
     return world, camera, True
 
 
-def heightfield_world(n_side: int = 3163, seed: int = 1):
+def heightfield_world(n_side: int = 2236, seed: int = 1):
     """Configuration 4's coherent variant: a displaced height field over [0,1]^2, n_side x n_side cells of two triangles
-    each (3163^2 x 2 = 10.0 M), one indexed mesh without normals.  Heights are a sum of five seeded sine octaves
+    each (2236^2 x 2 = 10.0 M), one indexed mesh without normals.  Heights are a sum of five seeded sine octaves
     (amplitude halving, frequency doubling), about +-0.12 around y = 0.2: a connected surface whose Morton order follows
     its triangle order, unlike the soup."""
     k = np.arange(n_side + 1, dtype=np.float64) / n_side

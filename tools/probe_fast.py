@@ -108,7 +108,7 @@ def main():
             w, cam, sky = scenes.soup_world(10_000_000, seed=1)
             bounces = 4
         elif name == "heightfield":
-            w, cam, sky = scenes.heightfield_world(3163, seed=1)
+            w, cam, sky = scenes.heightfield_world(2236, seed=1)
             bounces = 4
         tr = T.rt_make_tracer(T.RT_TracerSettings(max_bounces=bounces, sky=sky))
         T.rt_tracer_build_blas(tr, w)
