@@ -140,6 +140,59 @@ def test_hierarchy_hand_off_modes_build_the_same_tree(oracle):
             os.environ["RTHIP_REFIT_FENCE"] = old
 
 
+@pytest.mark.parametrize("n", [513, 1023, 1024, 1025, 2049, 4097, 65_537, 131_072, 131_073, 262_144, 262_145])
+def test_lbvh_sizes_at_the_seams_of_the_builder(oracle, n):
+    """Sizes just below, at and above the points where the builder changes its path: one workgroup (512), tiles of the
+    tile sort (1024), tile sort + merge against radix passes (131 072), small against large radix tiles (262 144), the
+    upper box climb in one workgroup (131 072).  Half of the boxes sit on a lattice (runs of equal codes, pairs among
+    them, as the two triangles of a quad give).  Every size against the oracle, and the same tree when the sort goes
+    pass by pass and when the upper climb runs device-wide."""
+    rng = np.random.default_rng(n)
+    cen = rng.random((n, 3)).astype(np.float32)
+    cen[: n // 2] = np.floor(cen[: n // 2] * 40) / 40
+    cen[1 : n // 4 : 2] = cen[0 : n // 4 - 1 : 2][: len(cen[1 : n // 4 : 2])]  # pairs with the same centre
+    half = np.full((n, 3), 0.001, dtype=np.float32)
+    boxes = np.concatenate([cen - half, cen + half], axis=1)
+    want = oracle.lbvh_build(boxes)[3]
+    saved = {k: os.environ.get(k) for k in ("RTHIP_SORT_BY_PASSES", "RTHIP_UPPER_DEVICE_WIDE", "RTHIP_SORT_SMALL_TILE_MAX")}
+    try:
+        for env in ({}, {"RTHIP_SORT_BY_PASSES": "1", "RTHIP_UPPER_DEVICE_WIDE": "1"}, {"RTHIP_SORT_BY_PASSES": "1", "RTHIP_SORT_SMALL_TILE_MAX": "0"}):
+            for k in saved:
+                os.environ.pop(k, None)
+            os.environ.update(env)
+            t = T.rt_make_tracer(T.RT_TracerSettings(max_bounces=1, sky=True), device_id=0)
+            try:
+                assert_same_tree(T.lbvh_build(t, boxes)[3], want, f"n = {n}, {env}")
+            finally:
+                T.rt_tracer_cleanup(t)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def test_lbvh_tile_merge_with_lopsided_tiles(oracle, gpu_tracer):
+    """The merge of the tile-sorted keys copies, for 64 neighbouring keys of one tile, the stretch of every other tile
+    that lies between them; a stretch of 128 keys or more is searched in global memory instead.  Here the tiles of 1024
+    keys are made to differ: spread over the whole range, packed into a thousandth of it, all equal, and spread again in
+    descending order, so that both paths and the equal-key rule (earlier tile first) are taken."""
+    rng = np.random.default_rng(5)
+    x = np.concatenate([
+        np.sort(rng.random(1024)),                      # spread
+        0.5 + np.sort(rng.random(1024)) * 1e-3,         # packed: 1024 keys between two neighbours of the first tile
+        np.full(1024, 0.5005),                          # one code 1024 times, inside the packed range
+        np.sort(rng.random(1024))[::-1],                # spread, descending
+        0.5 + rng.random(700) * 1e-3,                   # a last, partial tile, packed as well
+    ]).astype(np.float32)
+    cen = np.stack([x, np.full_like(x, 0.25), np.full_like(x, 0.75)], axis=1)
+    cen = np.concatenate([cen, np.array([[0, 0, 0], [1, 1, 1]], dtype=np.float32)])  # fix the bounds
+    half = np.full(cen.shape, 1e-4, dtype=np.float32)
+    boxes = np.concatenate([cen - half, cen + half], axis=1)
+    assert_same_tree(T.lbvh_build(gpu_tracer, boxes)[3], oracle.lbvh_build(boxes)[3], "lopsided tiles")
+
+
 def test_lbvh_ten_million_invariants(gpu_tracer):
     """The benchmark's largest build (10^7 triangles), checked on the GPU through size-independent properties:
     a well-formed pre-order tree, every primitive in exactly one leaf with its own box, every inner box the
