@@ -756,19 +756,22 @@ static glibc_rng g_test_rng;
 void ora_srand(uint32_t seed) { glibc_seed(&g_test_rng, seed); }
 int ora_rand(void) { return glibc_next(&g_test_rng); }
 
-/* Counter-based generator of the HIP kernels: two rounds of the splitmix64
- * finaliser; 31 random bits per draw, keyed by (seed, pixel, sample, draw). */
-static inline uint64_t mix64(uint64_t z) {
-    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
-    z ^= z >> 27; z *= 0x94D049BB133111EBull;
-    z ^= z >> 31;
-    return z;
+/* Counter-based generator of the HIP kernels: 31 random bits per draw, keyed by (seed, pixel, sample, draw), in 32-bit
+ * arithmetic throughout.  hash32 is a two-multiply integer hash; a path's key is two hashed words (a, b), draw d is
+ * hash32(a + d * 0x9E3779B9) ^ b. */
+static inline uint32_t hash32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du;
+    x ^= x >> 15; x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
 }
 static inline uint64_t counter_key(uint64_t seed, uint32_t pixel, uint32_t sample) {
-    return mix64(seed ^ mix64(((uint64_t)pixel << 32) | (uint64_t)sample));
+    const uint32_t a = hash32(pixel + hash32(sample ^ (uint32_t)seed));
+    const uint32_t b = hash32(a ^ (uint32_t)(seed >> 32) ^ 0x85ebca6bu);
+    return (uint64_t)a | ((uint64_t)b << 32);
 }
 static inline uint32_t counter_draw(uint64_t key, uint32_t draw) {
-    return (uint32_t)(mix64(key + ((uint64_t)draw + 1ull) * 0x9E3779B97F4A7C15ull) >> 33);
+    return (hash32((uint32_t)key + draw * 0x9E3779B9u) ^ (uint32_t)(key >> 32)) >> 1;
 }
 uint32_t ora_counter_rand(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t draw) {
     return counter_draw(counter_key(seed, pixel, sample), draw);

@@ -558,27 +558,33 @@ __device__ __forceinline__ void finish_hit(const DevScene& S, V3 o, V3 d, const 
 // ---- random numbers -------------------------------------------------------------------
 // The reference draws from one global rand() stream (src/common/common_math.h:310), which
 // ties the image to the serial pixel order.  Here every draw is a pure function of
-// (seed, pixel, sample, draw index): two rounds of the splitmix64 finaliser, 31 bits out,
-// converted exactly like (f32)rand()/(f32)RAND_MAX (RAND_MAX rounds to 2^31).
-__device__ __forceinline__ uint64_t mix64(uint64_t z) {
-    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
-    z ^= z >> 27; z *= 0x94D049BB133111EBull;
-    z ^= z >> 31;
-    return z;
+// (seed, pixel, sample, draw index), 31 bits out, converted exactly like (f32)rand()/(f32)RAND_MAX (RAND_MAX rounds
+// to 2^31).  All of it is 32-bit arithmetic: a 32-bit integer multiply runs at a quarter of the VALU rate here and a
+// 64-bit one is four of them, and a generator built on two 64-bit multiplies per draw (the splitmix64 finaliser, which
+// this one replaced) was half of what a pixel costs before its ray meets anything.  hash32 is a two-multiply integer
+// hash with low avalanche bias; a path's key is two hashed words (a, b) of (seed, pixel, sample), draw d is
+// hash32(a + d * 0x9E3779B9) ^ b.
+__device__ __forceinline__ uint32_t hash32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du;
+    x ^= x >> 15; x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
 }
 struct Rng {
-    uint64_t key;
-    uint32_t draw;
+    uint64_t key;   // a | b << 32
+    uint32_t draw;  // d * 0x9E3779B9, kept as a running sum
 };
 __device__ __forceinline__ Rng rng_make(uint64_t seed, uint32_t pixel, uint32_t sample) {
     Rng g;
-    g.key = mix64(seed ^ mix64(((uint64_t)pixel << 32) | (uint64_t)sample));
+    const uint32_t a = hash32(pixel + hash32(sample ^ (uint32_t)seed));
+    const uint32_t b = hash32(a ^ (uint32_t)(seed >> 32) ^ 0x85ebca6bu);
+    g.key = (uint64_t)a | ((uint64_t)b << 32);
     g.draw = 0;
     return g;
 }
 __device__ __forceinline__ float rand_unit(Rng& g) {
-    uint32_t v = (uint32_t)(mix64(g.key + ((uint64_t)g.draw + 1ull) * 0x9E3779B97F4A7C15ull) >> 33);
-    g.draw++;
+    const uint32_t v = (hash32((uint32_t)g.key + g.draw) ^ (uint32_t)(g.key >> 32)) >> 1;
+    g.draw += 0x9E3779B9u;
     return (float)(int)v / 2147483648.0f;
 }
 
