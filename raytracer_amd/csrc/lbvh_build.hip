@@ -226,7 +226,7 @@ __device__ __forceinline__ uint32_t morton_axis(float c, float mn, float ext) {
 __global__ __launch_bounds__(kBlock) void morton_kernel(const float* __restrict__ aabb6, uint64_t n,
                                                         const uint32_t* __restrict__ bounds,
                                                         uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                                                        uint32_t* __restrict__ zero, unsigned long long* __restrict__ zero64) {
+                                                        uint32_t* __restrict__ zero) {
     __shared__ uint32_t sb[6];
     bounds_fold(bounds, sb);  // once per workgroup of a bounded grid
     float mn[3], ext[3];
@@ -236,10 +236,7 @@ __global__ __launch_bounds__(kBlock) void morton_kernel(const float* __restrict_
         ext[k] = ord2f(sb[k + 3]) - mn[k];  // extents = max - min, lbvh.c:106
     }
     for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
-        if (zero) {  // the climbs' arrival counters and hand-over words, cleared on the way (one launch fewer)
-            zero[i] = 0u;
-            zero64[i] = 0ull;
-        }
+        if (zero) zero[i] = 0u;  // the climb's arrival counters, cleared on the way (one launch fewer)
         const float* b = aabb6 + 6 * i;
         uint64_t code = 0;
 #pragma unroll
@@ -784,41 +781,226 @@ __device__ __forceinline__ uint8_t gap_priority_of(const uint64_t* keys, uint64_
 }
 
 // ---- K5 + K6: hierarchy emission with box refit ------------------------------------------
-// lbvh_create_subtree, lbvh.c:44-72, bottom-up, in two climbs of the same shape.
+// lbvh_create_subtree, lbvh.c:44-72, without the recursion.
 //
-// The climb: one thread per sorted leaf.  A node is identified by its leaf range [l, r]; its parent is the gap that
-// bounds the range with the larger priority.  A child leaves a record in its parent's slot and bumps the parent's
-// arrival counter; the second child to arrive reads its sibling's record, becomes the parent and walks on.  Nobody
-// ever waits for anybody.
+// Shape.  The node that splits at gap g (between sorted leaves g and g + 1) covers the leaves from behind the nearest
+// gap of smaller priority on its left to the nearest gap of smaller priority on its right; its parent is the one of
+// those two gaps with the larger priority (gap_priority_of: two gaps of equal priority always have one of smaller
+// priority between them, so there are no ties to break).  In pre-order, a node with leaf range [l, r] sits at
+//     2 l + (number of its ancestors that have it in their LEFT subtree):
+// the l leaves before it, and of the l gaps before it those that are not its ancestors lie entirely to its left,
+// while those that are count as ancestors either way.  For leaf i that number is the number of gaps g >= i whose node
+// reaches down to leaf i, i.e. whose priority is smaller than that of every gap in [i, g): the records of a running
+// minimum that starts at gap i.  Priorities are below 128 (63 bit levels, 64 + the depth in an equal-code run), so the
+// set of records seen from gap i is a 128-bit mask M_i, and
+//     M_i = (M_{i+1} & bits below p_i) | bit p_i                                         (VisF below)
+// is a suffix scan with a small associative operator.  Three small kernels give every leaf S(i) = i + popcount(M_i),
+// its pre-order index being i + S(i); the inner node with range [l, r] and dl left edges down to leaf l sits at
+// l + S(l) - dl.  No climb, no hand-offs, no atomics for the shape.
 //
-// First climb (topology, no boxes): records hold {far end of the range, left-spine length}.  It yields the length of
-// the left spine that starts at every leaf (cnt_l), whose prefix sum gives every node its pre-order index:
-// leaf i sits at i + S(i), the inner node with range [l, r] and `dl` left edges below it at l + S(l) - dl.
-// Second climb (boxes): the same walk with the boxes merged on the way (merge_rng3_f32(left, right), lbvh.c:58); every
-// node's final 32-byte record goes straight to its pre-order place: no intermediate node arrays, no layout pass.
+// Boxes (merge_rng3_f32(left, right), lbvh.c:58) do need the children first: one bottom-up climb, one thread per sorted
+// leaf.  A node is identified by its leaf range; a child leaves a record in its parent's slot and bumps the parent's
+// arrival counter; the second child to arrive reads its sibling's record, becomes the parent, writes the parent's
+// final 32-byte record straight to its pre-order place and walks on.  Nobody ever waits for anybody.
 //
-// Each climb is two kernels.  *_local: a workgroup owns kChunk consecutive sorted leaves.  A gap whose node lies
+// The climb is two kernels.  climb_local: a workgroup owns kChunk consecutive sorted leaves.  A gap whose node lies
 // entirely inside the chunk (it is bounded on both sides, inside the chunk, by gaps of smaller priority) is "local":
 // both of its children are produced by this workgroup, so their hand-off goes through LDS.  A thread that reaches a
-// parent that is not local hands its record over in HBM and is done.  *_upper finishes the nodes that span chunks (a
-// few per cent of all): one thread per node whose two children both arrived in the local kernel (the second child to
-// arrive in the topology climb puts the node on a list that both upper kernels start from), hand-offs through HBM.
+// parent that is not local leaves its record in HBM, counts itself there and is done; the second child to be counted
+// puts the parent on a list.  climb_upper finishes the nodes that span chunks (a few per cent of all): one thread per
+// node on the list, hand-offs through HBM.
 //
-// Hand-offs through HBM.  Topology climb: the record is one 64-bit word and travels inside an atomic exchange (see
-// topo_pack).  Box climb (the record is 32 bytes): every access to a record and to the counter is a device-scope
-// atomic, so what the hand-off needs beyond per-location coherence is ORDER: record before count, count before the
-// sibling's record.  MODE 2 (the default): the wave drains its record stores (s_waitcnt vmcnt(0): device-scope stores are
-// acknowledged once they are visible device-wide on gfx950) before a relaxed counter add, and reads the sibling after
-// the add has returned; the asm statement is a compiler barrier as well.  That is the hardware's ordering, not one the
-// HIP memory model promises for relaxed atomics.  MODE 0 (RTHIP_REFIT_FENCE=0) is the model's own form: a device-
-// scope release read-modify-write on the counter, and an acquire fence before the second child to arrive reads the
-// sibling's record (the first reads nothing).  Same trees bit for bit (tests run all three); its release writes the
-// L2 back and its acquire invalidates it at every level of a latency-bound chain: measured 2.15 ms instead of 1.84 ms
-// for 10^7 triangles, 0.25 / 0.23 ms for 81 920.  MODE 1 (RTHIP_REFIT_FENCE=1, diagnostic): plain accesses bracketed
-// by __threadfence().
-//
-// The box climb's arrival counter of a gap is shared by its two kernels; the first arrival finds 0.
+// Hand-offs through HBM.  Every access to a record and to the counter is a device-scope atomic, so what the hand-off
+// needs beyond per-location coherence is ORDER: record before count, count before the sibling's record.  MODE 2 (the
+// default): the wave drains its record stores (s_waitcnt vmcnt(0): device-scope stores are acknowledged once they are
+// visible device-wide on gfx950) before a relaxed counter add, and reads the sibling after the add has returned; the
+// asm statement is a compiler barrier as well.  That is the hardware's ordering, not one the HIP memory model promises
+// for relaxed atomics.  MODE 0 (RTHIP_REFIT_FENCE=0) is the model's own form: a device-scope release read-modify-write
+// on the counter, and an acquire fence before the second child to arrive reads the sibling's record (the first reads
+// nothing).  Same trees bit for bit (tests run all three); its release writes the L2 back and its acquire invalidates
+// it at every level of a latency-bound chain (+8 % at 10^7 triangles).  MODE 1 (RTHIP_REFIT_FENCE=1, diagnostic):
+// plain accesses bracketed by __threadfence().
 constexpr int kChunk = 512;  // sorted leaves per workgroup, one per thread
+
+// ---- the records of a running minimum, as a scan ------------------------------------------------------------------
+// f(M) = (M & bits below t) | B: what a stretch of gaps does to the mask of the records seen from behind its right end.
+// The mask is two 64-bit words: priorities below 64 (bit levels), and 64 and above (depths inside equal-code runs).
+struct VisF {
+    uint32_t t;     // 128: keeps everything (the empty stretch)
+    uint64_t lo, hi;
+};
+__device__ __forceinline__ uint64_t below_lo(uint32_t t) { return t >= 64u ? ~0ull : ((1ull << t) - 1ull); }
+__device__ __forceinline__ uint64_t below_hi(uint32_t t) { return t <= 64u ? 0ull : (t >= 128u ? ~0ull : ((1ull << (t - 64u)) - 1ull)); }
+__device__ __forceinline__ VisF vis_identity() { return VisF{128u, 0ull, 0ull}; }
+// the stretch `left` followed on its right by the stretch `right` (right acts on the mask first)
+__device__ __forceinline__ VisF vis_join(const VisF& left, const VisF& right) {
+    VisF r;
+    r.t = left.t < right.t ? left.t : right.t;
+    r.lo = (right.lo & below_lo(left.t)) | left.lo;
+    r.hi = (right.hi & below_hi(left.t)) | left.hi;
+    return r;
+}
+// one gap of priority p (1 .. 127) in front of the stretch F
+__device__ __forceinline__ VisF vis_push(uint32_t p, const VisF& F) {
+    VisF r;
+    r.t = p < F.t ? p : F.t;
+    r.lo = (F.lo & below_lo(p)) | (p < 64u ? 1ull << p : 0ull);
+    r.hi = (F.hi & below_hi(p)) | (p >= 64u ? 1ull << (p - 64u) : 0ull);
+    return r;
+}
+__device__ __forceinline__ uint32_t vis_count(const VisF& F) { return (uint32_t)(__popcll(F.lo) + __popcll(F.hi)); }
+__device__ __forceinline__ uint64_t shfl_down_u64(uint64_t v, int o) {
+    const uint32_t a = __shfl_down((uint32_t)v, o), b = __shfl_down((uint32_t)(v >> 32), o);
+    return (uint64_t)a | ((uint64_t)b << 32);
+}
+__device__ __forceinline__ VisF vis_shfl_down(const VisF& F, int o) {
+    VisF r;
+    r.t = __shfl_down(F.t, o);
+    r.lo = shfl_down_u64(F.lo, o);
+    r.hi = shfl_down_u64(F.hi, o);
+    return r;
+}
+// Every thread of the workgroup owns a stretch, thread 0 the leftmost.  Returns what lies to the RIGHT of the thread's
+// stretch inside the workgroup; *total: the whole workgroup's stretch (valid in every thread).  THREADS / 64 <= 16.
+template <int THREADS>
+__device__ __forceinline__ VisF vis_block_suffix(const VisF& mine, VisF* total) {
+    constexpr int kWaves = THREADS / 64;
+    __shared__ VisF wave_f[kWaves];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    VisF incl = mine;  // lanes [lane, 63] of this wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const VisF other = vis_shfl_down(incl, o);
+        if (lane + o < 64) incl = vis_join(incl, other);
+    }
+    VisF right = vis_shfl_down(incl, 1);
+    if (lane == 63) right = vis_identity();
+    __syncthreads();  // wave_f may still be read from an earlier call
+    if (lane == 0) wave_f[wave] = incl;
+    __syncthreads();
+    VisF later = vis_identity(), all = vis_identity();  // the waves behind this one; all waves
+    for (int w = kWaves - 1; w >= 0; w--) {
+        if (w > wave) later = vis_join(wave_f[w], later);
+        all = vis_join(wave_f[w], all);
+    }
+    *total = all;
+    return vis_join(right, later);
+}
+
+constexpr int kVisItems = 8;
+constexpr int kVisTile = kBlock * kVisItems;  // 2048 gaps per workgroup
+constexpr uint32_t kVisFusedTiles = kBlock;   // up to this many tiles, pass 3 finds the mask behind its tile by itself
+
+// Pass 1: priorities of a tile's gaps (written for the box climb) and the tile's stretch.
+__global__ __launch_bounds__(kBlock) void vis_tile_kernel(const uint64_t* __restrict__ keys, uint32_t n, uint8_t* __restrict__ prio,
+                                                          VisF* __restrict__ tile_f) {
+    __shared__ uint8_t sp[kVisTile];
+    const uint32_t base = blockIdx.x * (uint32_t)kVisTile;
+#pragma unroll
+    for (int j = 0; j < kVisItems; j++) {  // consecutive threads on consecutive gaps
+        const uint32_t g = base + (uint32_t)j * kBlock + threadIdx.x;
+        uint8_t p = 0;
+        if (g + 1 < n) {
+            p = gap_priority_of(keys, n, g);
+            prio[g] = p;
+        }
+        sp[j * kBlock + threadIdx.x] = p;
+    }
+    __syncthreads();
+    VisF mine = vis_identity();
+#pragma unroll
+    for (int j = kVisItems - 1; j >= 0; j--) {
+        const uint32_t g = base + threadIdx.x * kVisItems + (uint32_t)j;
+        if (g + 1 < n) mine = vis_push(sp[threadIdx.x * kVisItems + j], mine);
+    }
+    VisF total;
+    (void)vis_block_suffix<kBlock>(mine, &total);
+    if (threadIdx.x == 0) tile_f[blockIdx.x] = total;
+}
+
+// Pass 2 (one workgroup; only for more than kVisFusedTiles tiles): the mask of the records seen from behind every
+// tile's right end.  A thread takes up to kVisPerThread neighbouring tiles, loaded at once.
+constexpr int kVisTilesBlock = 1024;
+constexpr uint32_t kVisPerThread = 8;
+__global__ __launch_bounds__(kVisTilesBlock) void vis_tiles_kernel(const VisF* __restrict__ tile_f, uint32_t tiles, ulonglong2* __restrict__ tile_in) {
+    const uint32_t per = (tiles + kVisTilesBlock - 1) / kVisTilesBlock;
+    const uint32_t first = threadIdx.x * per;
+    VisF mine = vis_identity();
+    if (per <= kVisPerThread) {
+        VisF f[kVisPerThread];
+#pragma unroll
+        for (uint32_t k = 0; k < kVisPerThread; k++) f[k] = (k < per && first + k < tiles) ? tile_f[first + k] : vis_identity();
+#pragma unroll
+        for (int k = (int)kVisPerThread - 1; k >= 0; k--) mine = vis_join(f[k], mine);
+        VisF total;
+        VisF right = vis_block_suffix<kVisTilesBlock>(mine, &total);
+#pragma unroll
+        for (int k = (int)kVisPerThread - 1; k >= 0; k--) {  // right: what lies behind tile first + k
+            if ((uint32_t)k < per && first + k < tiles) tile_in[first + k] = make_ulonglong2(right.lo, right.hi);  // applied to the empty mask
+            right = vis_join(f[k], right);
+        }
+        return;
+    }
+    for (uint32_t k = per; k-- > 0;)
+        if (first + k < tiles) mine = vis_join(tile_f[first + k], mine);
+    VisF total;
+    VisF right = vis_block_suffix<kVisTilesBlock>(mine, &total);
+    for (uint32_t k = per; k-- > 0;) {
+        if (first + k >= tiles) continue;
+        tile_in[first + k] = make_ulonglong2(right.lo, right.hi);
+        right = vis_join(tile_f[first + k], right);
+    }
+}
+
+// Pass 3: S(i) = i + records seen from gap i, for the leaves of a tile (the last leaf has no gap: S = n - 1).
+// tile_in == nullptr: at most kVisFusedTiles tiles, and the workgroup joins the tiles behind its own itself.
+__global__ __launch_bounds__(kBlock) void vis_leaf_kernel(const uint8_t* __restrict__ prio, uint32_t n, const VisF* __restrict__ tile_f,
+                                                          uint32_t tiles, const ulonglong2* __restrict__ tile_in, uint32_t* __restrict__ spine) {
+    const uint32_t g0 = blockIdx.x * (uint32_t)kVisTile + threadIdx.x * kVisItems;
+    uint32_t p[kVisItems];
+    if (g0 + kVisItems < n) {  // all eight gaps exist: one 8-byte load (prio is 256-byte aligned, g0 a multiple of 8)
+        const uint2 v = *(const uint2*)(prio + g0);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            p[j] = (v.x >> (8 * j)) & 0xffu;
+            p[j + 4] = (v.y >> (8 * j)) & 0xffu;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < kVisItems; j++) p[j] = (g0 + j + 1 < n) ? prio[g0 + j] : 0u;
+    }
+    VisF behind;  // a function that ignores its argument: the mask behind this tile
+    if (tile_in) {
+        const ulonglong2 in = tile_in[blockIdx.x];
+        behind = VisF{0u, in.x, in.y};
+    } else {
+        const uint32_t t = blockIdx.x + 1u + threadIdx.x;
+        VisF total;
+        (void)vis_block_suffix<kBlock>(t < tiles ? tile_f[t] : vis_identity(), &total);
+        behind = VisF{0u, total.lo, total.hi};
+    }
+    VisF mine = vis_identity();
+#pragma unroll
+    for (int j = kVisItems - 1; j >= 0; j--)
+        if (g0 + j + 1 < n) mine = vis_push(p[j], mine);
+    VisF total;
+    VisF right = vis_join(vis_block_suffix<kBlock>(mine, &total), behind);
+    uint32_t out[kVisItems];
+#pragma unroll
+    for (int j = kVisItems - 1; j >= 0; j--) {
+        const uint32_t i = g0 + (uint32_t)j;
+        if (i + 1 < n) right = vis_push(p[j], right);
+        out[j] = i + (i + 1 < n ? vis_count(right) : 0u);
+    }
+    if (g0 + kVisItems <= n) {
+        ((uint4*)(spine + g0))[0] = make_uint4(out[0], out[1], out[2], out[3]);
+        ((uint4*)(spine + g0))[1] = make_uint4(out[4], out[5], out[6], out[7]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < kVisItems; j++)
+            if (g0 + j < n) spine[g0 + j] = out[j];
+    }
+}
 
 template <bool FENCE>
 __device__ __forceinline__ void child_store(ChildRec* slot, const float* box, uint32_t far_end, uint32_t dl) {
@@ -855,24 +1037,6 @@ __device__ __forceinline__ void child_load(const ChildRec* slot, float* box, uin
     *far_end = (uint32_t)w3;
     *dl = (uint32_t)(w3 >> 32);
 }
-// Topology climb, parents that span chunks: a child's whole record is ONE 64-bit word -- far end of its range + 1 (so
-// that no record is 0), left-spine length (at most the tree's height: 63 bit levels + 33 levels of an equal-code run)
-// and the priority of the gap beyond its far end, which the parent needs to find ITS parent -- and the hand-over is one
-// atomic exchange on the parent's word: the first child to arrive gets 0 back and is done, the second gets its
-// sibling's record and carries on.  One memory round trip per level, and no ordering between different locations to
-// rely on: the data travels inside the atomic.
-__device__ __forceinline__ unsigned long long topo_pack(uint32_t far_end, uint32_t dl, uint32_t far_prio) {
-    return (unsigned long long)(far_end + 1u) | ((unsigned long long)dl << 32) | ((unsigned long long)far_prio << 48);
-}
-__device__ __forceinline__ void topo_unpack(unsigned long long w, uint32_t* far_end, uint32_t* dl, uint32_t* far_prio) {
-    *far_end = (uint32_t)w - 1u;
-    *dl = (uint32_t)(w >> 32) & 0xffffu;
-    *far_prio = (uint32_t)(w >> 48) & 0xffu;
-}
-// a node that spans chunks and is complete: where an upper kernel starts from
-__device__ __forceinline__ uint4 start_pack(uint32_t gap, uint32_t l, uint32_t r, uint32_t dl, uint32_t pl, uint32_t pr) {
-    return make_uint4(gap, l, r, dl | (pl << 16) | (pr << 24));
-}
 
 // merge with a sibling: the LEFT child's box is the first argument of every Min / Max (lbvh.c:58)
 __device__ __forceinline__ void merge_sibling(float* box, const float* sbox, bool sibling_is_right) {
@@ -899,47 +1063,38 @@ __device__ __forceinline__ void put_node(float4* __restrict__ nodes, uint32_t pr
     }
 }
 
-// S(i): inclusive prefix sum of the left-spine lengths up to leaf i (the tile scan, plus the sums of the tiles before)
-__device__ __forceinline__ uint32_t spine_prefix(const uint32_t* __restrict__ scan, const uint32_t* __restrict__ tile_sums, uint32_t i) {
-    return scan[i] + (tile_sums ? tile_sums[i / (uint32_t)kScanTile] : 0u);
-}
 // the finished inner node with leaf range [l, r] and dl left edges down to leaf l
-__device__ __forceinline__ void put_inner(float4* __restrict__ nodes, const uint32_t* __restrict__ scan, const uint32_t* __restrict__ tile_sums,
-                                          const float* box, uint32_t l, uint32_t r, uint32_t dl, uint32_t paired) {
-    const uint32_t pre = l + spine_prefix(scan, tile_sums, l) - dl;
+__device__ __forceinline__ void put_inner(float4* __restrict__ nodes, const uint32_t* __restrict__ spine, const float* box, uint32_t l,
+                                          uint32_t r, uint32_t dl, uint32_t paired) {
+    const uint32_t pre = l + spine[l] - dl;
     put_node(nodes, pre, box, pre + 2u * (r - l + 1u) - 1u, 0u, paired);
 }
 
 struct ClimbArgs {
     uint32_t n;
-    const uint64_t* keys;      // sorted Morton codes (topology climb: the gap priorities are taken from them)
-    uint8_t* prio;             // gap priorities: written by the topology climb, read by the box climb
+    const uint8_t* prio;       // gap priorities
     const uint32_t* sorted_idx;
     const float* aabb6;
-    ChildRec* child;           // box climb: records for parents that span chunks
-    unsigned long long* topo_slot;  // topology climb: one hand-over word per gap (topo_pack), zero before the climb
-    uint32_t* flags;           // arrival counters
-    uint32_t* cnt_l;           // topology climb: left-spine length per leaf; box climb: their tile-wise inclusive scan
-    const uint32_t* tile_sums; // box climb: exclusive sums of the scan tiles (nullptr: cnt_l holds the whole scan)
-    uint4* starters;           // nodes that span chunks whose two children both arrived in the local kernel (start_pack)
+    ChildRec* child;           // records for parents that span chunks; the dl word also carries, in its upper half, the
+                               // priority of the gap beyond the child's far end (which the parent needs to find ITS parent)
+    uint32_t* flags;           // arrival counters, zero before the climb
+    const uint32_t* spine;     // S(i) of every leaf
+    uint32_t* starters;        // gaps of the nodes that span chunks and got both children from the local kernel
     uint32_t* start_count;
-    float4* nodes;             // box climb: the pre-order records
+    float4* nodes;             // the pre-order records
     uint32_t paired;
-    bool prio_ready;           // topology climb: prio already holds the priorities (the one-workgroup build)
 };
 
-// The chunk-local part of a climb.  BOXES = false: topology (fills cnt_l, prio, the starter list); true: boxes.
-template <bool BOXES>
+// The chunk-local part of the climb.
 __device__ __forceinline__ void climb_local(uint32_t c0, const ClimbArgs& A) {
     // window of gap priorities: entry k is gap c0 - 1 + k, k = 0 .. kChunk; bit 7 marks a local gap.
     // Gaps that do not exist (-1, >= n-1) read as 0, below every real priority (>= 1).
     __shared__ uint8_t win[kChunk + 8];
     __shared__ uint32_t lflag[kChunk];
-    __shared__ uint64_t lrec_raw[BOXES ? sizeof(ChildRec) * 2 * kChunk / 8 : 1];
+    __shared__ ChildRec lrec[2 * kChunk];
     __shared__ uint32_t wmin_l[kChunk / 64], wmin_r[kChunk / 64];
-    __shared__ uint32_t n_start, waves_done;  // nodes that this workgroup found complete for the upper kernels
-    __shared__ uint4 stage[BOXES ? 1 : kChunk];
-    ChildRec* lrec_box = (ChildRec*)lrec_raw;
+    __shared__ uint32_t n_start, waves_done;  // nodes that this workgroup found complete for the upper kernel
+    __shared__ uint32_t stage[kChunk];
 
     const uint32_t n = A.n;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -951,27 +1106,11 @@ __device__ __forceinline__ void climb_local(uint32_t c0, const ClimbArgs& A) {
     const uint32_t i = c0 + (uint32_t)tid;
     {
         const int64_t g = (int64_t)c0 - 1 + tid;
-        const bool exists = g >= 0 && g + 1 < (int64_t)n;
-        uint8_t p = 0, pe = 0;
-        if (exists) {
-            if (BOXES || A.prio_ready) p = A.prio[g];
-            else {
-                p = gap_priority_of(A.keys, n, (uint64_t)g);
-                if (tid >= 1) A.prio[g] = p;  // entry 0 is the previous chunk's last gap: that chunk writes it
-            }
-        }
+        win[tid] = (g >= 0 && g + 1 < (int64_t)n) ? A.prio[g] : (uint8_t)0;
         if (tid == 0) {
             const int64_t ge = (int64_t)c0 - 1 + kChunk;
-            if (ge + 1 < (int64_t)n) {
-                if (BOXES || A.prio_ready) pe = A.prio[ge];
-                else {
-                    pe = gap_priority_of(A.keys, n, (uint64_t)ge);
-                    A.prio[ge] = pe;
-                }
-            }
+            win[kChunk] = (ge + 1 < (int64_t)n) ? A.prio[ge] : (uint8_t)0;
         }
-        win[tid] = p;
-        if (tid == 0) win[kChunk] = pe;
     }
     lflag[tid] = 0;
     __syncthreads();
@@ -1002,25 +1141,21 @@ __device__ __forceinline__ void climb_local(uint32_t c0, const ClimbArgs& A) {
     }
     __syncthreads();
 
-    uint4 my_start = make_uint4(0u, 0u, 0u, 0u);
+    uint32_t my_start = 0;
     bool have_start = false;
-    uint32_t my_slot = 0;
     if (i < n) {
         uint32_t l = i, r = i, dl = 0;
-        float box[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (BOXES) {
+        float box[6];
+        {
             const uint32_t prim = A.sorted_idx[i];
             const float* b = A.aabb6 + 6 * (uint64_t)prim;  // node->aabb = in_aabbs[id - 1], lbvh.c:53
 #pragma unroll
             for (int k = 0; k < 6; k++) box[k] = b[k];
-            const uint32_t pre = i + spine_prefix(A.cnt_l, A.tile_sums, i);
+            const uint32_t pre = i + A.spine[i];
             put_node(A.nodes, pre, box, pre + 1, prim + 1, A.paired);  // id = idx + 1, lbvh.c:116
         }
         for (;;) {
-            if (l == 0 && r == n - 1) {  // the root: top of the left spine that starts at leaf 0
-                if (!BOXES) A.cnt_l[0] = dl;
-                break;
-            }
+            if (l == 0 && r == n - 1) break;  // the root
             // Priorities of the two gaps that bound [l, r]; the parent is the one with the larger priority.
             // While the node is inside the chunk both gaps are inside the window.
             const uint32_t pr_r = (r != n - 1) ? (uint32_t)win[r + 1 - c0] : 0u;
@@ -1029,167 +1164,89 @@ __device__ __forceinline__ void climb_local(uint32_t c0, const ClimbArgs& A) {
             const uint32_t parent = parent_right ? r : l - 1;
             const uint32_t side = parent_right ? 0u : 1u;  // 0: this node is the LEFT child
             const bool local = ((parent_right ? pr_r : pr_l) & 0x80u) != 0;
-            if (!BOXES && side == 1) A.cnt_l[l] = dl;  // a right child tops the left spine that starts at l
             const uint32_t far_end = parent_right ? l : r;
-            if (!local) {  // the parent spans chunks: leave the record for the upper kernel
-                if (BOXES) {
-                    const uint32_t far_prio = (parent_right ? pr_l : pr_r) & 0x7fu;  // of the gap beyond the far end
-                    ChildRec mine;
+            ChildRec mine;
 #pragma unroll
-                    for (int k = 0; k < 6; k++) mine.box[k] = box[k];
-                    mine.far_end = far_end;
-                    mine.dl = dl | (far_prio << 16);
-                    A.child[2 * (uint64_t)parent + side] = mine;
-                    atomicAdd(&A.flags[parent], 1u);
-                } else {  // handed over after the loop, so that the lanes still climbing do not wait for this round trip
-                    my_start = start_pack(parent, l, r, dl, pr_l & 0x7fu, pr_r & 0x7fu);
+            for (int k = 0; k < 6; k++) mine.box[k] = box[k];
+            mine.far_end = far_end;
+            if (!local) {  // the parent spans chunks: leave the record for the upper kernel
+                const uint32_t far_prio = (parent_right ? pr_l : pr_r) & 0x7fu;  // of the gap beyond the far end
+                mine.dl = dl | (far_prio << 16);
+                A.child[2 * (uint64_t)parent + side] = mine;
+                // the second child to be counted knows that the parent is complete: it goes on the upper kernel's list
+                if (atomicAdd(&A.flags[parent], 1u) == 1u) {
+                    my_start = parent;
                     have_start = true;
                 }
                 break;
             }
             const uint32_t slot = parent - c0;
-            uint32_t s_far, s_dl;
-            if (BOXES) {
-                ChildRec mine;
-#pragma unroll
-                for (int k = 0; k < 6; k++) mine.box[k] = box[k];
-                mine.far_end = far_end;
-                mine.dl = dl;
-                lrec_box[2 * slot + side] = mine;
-                // order the LDS record before the LDS counter and the counter before the sibling's record; LDS only:
-                // a fence that also covered global memory would make every level wait for the node stores below it
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-                const uint32_t old = atomicAdd(&lflag[slot], 1u);
-                if (old == 0) break;  // first to arrive: the sibling's thread carries on from here
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-                const ChildRec sib = lrec_box[2 * slot + (1u - side)];
-                merge_sibling(box, sib.box, side == 0);
-                s_far = sib.far_end;
-                s_dl = sib.dl;
-            } else {
-                // the topology record of a node inside the chunk fits one LDS word (far end relative to the chunk + 1,
-                // left-spine length) and is handed over by one atomic exchange: 0 back means first to arrive
-                const uint32_t sib = atomicExch(&lflag[slot], (far_end - c0 + 1u) | (dl << 16));
-                if (sib == 0u) break;
-                s_far = c0 + (sib & 0xffffu) - 1u;
-                s_dl = sib >> 16;
-            }
-            if (side == 0) {
-                r = s_far;
-                dl = dl + 1;
-            } else {
-                l = s_far;
-                dl = s_dl + 1;
-            }
-            if (BOXES) put_inner(A.nodes, A.cnt_l, A.tile_sums, box, l, r, dl, A.paired);
-        }
-    }
-    if (!BOXES) {
-        if (have_start) {  // this thread's node has a parent that spans chunks (my_start: the node itself so far)
-            const uint32_t parent = my_start.x, l = my_start.y, r = my_start.z;
-            const uint32_t dl = my_start.w & 0xffffu, pl = (my_start.w >> 16) & 0xffu, pr = my_start.w >> 24;
-            const bool left = parent == r;  // this node is the parent's left child
-            const unsigned long long sib = atomicExch(&A.topo_slot[parent], topo_pack(left ? l : r, dl, left ? pl : pr));
-            have_start = sib != 0ull;  // second to arrive: the parent is complete and goes on the upper kernels' list
-            if (have_start) {
-                uint32_t s_far, s_dl, s_prio;
-                topo_unpack(sib, &s_far, &s_dl, &s_prio);
-                my_start = left ? start_pack(parent, l, s_far, dl + 1u, pl, s_prio) : start_pack(parent, s_far, r, s_dl + 1u, s_prio, pr);
-            }
-        }
-        // Hand the complete nodes to the upper kernels with one device-wide atomic per workgroup, without a workgroup
-        // barrier: a wave stages its nodes in LDS and is done; the last wave to get here (the one with the chunk's
-        // longest climb) takes the workgroup's place in the list and copies the staged nodes out.  The other waves'
-        // slots are free for the next workgroup in the meantime.
-        if (have_start) {
-            my_slot = atomicAdd(&n_start, 1u);
-            stage[my_slot] = my_start;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-        uint32_t before = 0;
-        if (lane == 0) before = __hip_atomic_fetch_add(&waves_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        before = __shfl(before, 0);
-        if (before == blockDim.x / 64 - 1) {
+            mine.dl = dl;
+            lrec[2 * slot + side] = mine;
+            // order the LDS record before the LDS counter and the counter before the sibling's record; LDS only:
+            // a fence that also covered global memory would make every level wait for the node stores below it
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            const uint32_t old = atomicAdd(&lflag[slot], 1u);
+            if (old == 0) break;  // first to arrive: the sibling's thread carries on from here
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-            const uint32_t total = n_start;
-            if (total != 0) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(A.start_count, total);
-                base = __shfl(base, 0);
-                for (uint32_t k = lane; k < total; k += 64) A.starters[base + k] = stage[k];
-            }
-        }
-    }
-}
-
-template <bool BOXES>
-__global__ __launch_bounds__(kChunk) void climb_local_kernel(ClimbArgs A) {
-    climb_local<BOXES>(blockIdx.x * (uint32_t)kChunk, A);
-}
-
-// The topology climb above the chunks: one thread per complete node on the list, one atomic exchange per level.
-__global__ __launch_bounds__(kBlock) void climb_upper_topo_kernel(ClimbArgs A) {
-    const uint32_t n = A.n;
-    const uint32_t count = *A.start_count;
-    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < count; t += gridDim.x * blockDim.x) {
-        const uint4 e = A.starters[t];
-        uint32_t l = e.y, r = e.z, dl = e.w & 0xffffu, pl = (e.w >> 16) & 0xffu, pr = e.w >> 24;  // pl, pr: priorities of gaps l - 1 and r
-        for (;;) {
-            if (l == 0 && r == n - 1) {
-                A.cnt_l[0] = dl;
-                break;
-            }
-            const bool parent_right = (l == 0) || (r != n - 1 && pr > pl);
-            const uint32_t parent = parent_right ? r : l - 1;
-            if (!parent_right) A.cnt_l[l] = dl;  // a right child tops the left spine that starts at l
-            const unsigned long long sib =
-                atomicExch(&A.topo_slot[parent], topo_pack(parent_right ? l : r, dl, parent_right ? pl : pr));
-            if (sib == 0ull) break;  // first to arrive: the sibling carries on from here
-            uint32_t s_far, s_dl, s_prio;
-            topo_unpack(sib, &s_far, &s_dl, &s_prio);
-            if (parent_right) {
-                r = s_far;
+            const ChildRec sib = lrec[2 * slot + (1u - side)];
+            merge_sibling(box, sib.box, side == 0);
+            if (side == 0) {
+                r = sib.far_end;
                 dl = dl + 1;
-                pr = s_prio;
             } else {
-                l = s_far;
-                dl = s_dl + 1;
-                pl = s_prio;
+                l = sib.far_end;
+                dl = sib.dl + 1;
             }
+            put_inner(A.nodes, A.spine, box, l, r, dl, A.paired);
+        }
+    }
+    // Hand the complete nodes to the upper kernel with one device-wide atomic per workgroup, without a workgroup
+    // barrier: a wave stages its nodes in LDS and is done; the last wave to get here takes the workgroup's place in
+    // the list and copies the staged nodes out.
+    if (have_start) stage[atomicAdd(&n_start, 1u)] = my_start;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    uint32_t before = 0;
+    if (lane == 0) before = __hip_atomic_fetch_add(&waves_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    before = __shfl(before, 0);
+    if (before == blockDim.x / 64 - 1) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+        const uint32_t total = n_start;
+        if (total != 0) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(A.start_count, total);
+            base = __shfl(base, 0);
+            for (uint32_t k = lane; k < total; k += 64) A.starters[base + k] = stage[k];
         }
     }
 }
 
-// MODE 3: the whole upper box climb in ONE workgroup, for builds of up to kOneGroupUpper leaves, where the upper tree
-// is a couple of thousand nodes and the chain of hand-offs is all there is: all threads sit on one CU, so the hand-off
-// is a workgroup-scope release / acquire pair through the counter, which costs no cache maintenance.  Measured: 81 920
+__global__ __launch_bounds__(kChunk) void climb_local_kernel(ClimbArgs A) { climb_local(blockIdx.x * (uint32_t)kChunk, A); }
+
+// MODE 3: the whole upper climb in ONE workgroup, for builds of up to kOneGroupUpper leaves, where the upper tree is a
+// couple of thousand nodes and the chain of hand-offs is all there is: all threads sit on one CU, so the hand-off is a
+// workgroup-scope release / acquire pair through the counter, which costs no cache maintenance.  Measured: 81 920
 // leaves 35 us instead of 41 us device-wide; at 10^6 leaves (20 000 upper nodes on 1024 threads) 301 us instead of
 // 60 us, hence the limit.
 constexpr uint64_t kOneGroupUpper = 1ull << 17;
 constexpr int kOneGroupThreads = 1024;
 
-// The box climb above the chunks.  A 32-byte record does not fit an atomic, so here the hand-off is record, then
-// counter, then the sibling's record (see the modes above).  The records carry the priority of the gap beyond the
-// child's far end (upper half of the dl word), so a level needs no other load before its hand-off.
+// The climb above the chunks: one thread per complete node on the list.
 template <int MODE>
 __global__ __launch_bounds__(MODE == 3 ? kOneGroupThreads : kBlock) void climb_upper_kernel(ClimbArgs A) {
-    constexpr uint32_t kMine = 1u;
     const uint32_t n = A.n;
     const uint32_t count = *A.start_count;
     for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < count; t += gridDim.x * blockDim.x) {
-        const uint4 e = A.starters[t];
-        uint32_t parent = e.x;
-        uint32_t l = e.y, r = e.z, dl = e.w & 0xffffu, pl = (e.w >> 16) & 0xffu, pr = e.w >> 24;
+        uint32_t parent = A.starters[t];
+        const ChildRec a = A.child[2 * (uint64_t)parent], b = A.child[2 * (uint64_t)parent + 1];  // left, right
+        uint32_t l = a.far_end, r = b.far_end, dl = (a.dl & 0xffffu) + 1u;
+        uint32_t pl = a.dl >> 16, pr = b.dl >> 16;  // priorities of gaps l - 1 and r (0: there is none)
         float box[6];
-        {
-            const ChildRec a = A.child[2 * (uint64_t)parent], b = A.child[2 * (uint64_t)parent + 1];  // left, right
 #pragma unroll
-            for (int k = 0; k < 6; k++) box[k] = a.box[k];
-            merge_sibling(box, b.box, true);
-        }
+        for (int k = 0; k < 6; k++) box[k] = a.box[k];
+        merge_sibling(box, b.box, true);
         for (;;) {
-            const uint32_t pre = l + spine_prefix(A.cnt_l, A.tile_sums, l) - dl;
-            put_node(A.nodes, pre, box, pre + 2u * (r - l + 1u) - 1u, 0u, A.paired);
+            put_inner(A.nodes, A.spine, box, l, r, dl, A.paired);
             if (l == 0 && r == n - 1) break;
             const bool parent_right = (l == 0) || (r != n - 1 && pr > pl);
             parent = parent_right ? r : l - 1;
@@ -1198,13 +1255,13 @@ __global__ __launch_bounds__(MODE == 3 ? kOneGroupThreads : kBlock) void climb_u
                                                 dl | ((parent_right ? pl : pr) << 16));
             uint32_t old;
             if (MODE == 3) {
-                old = __hip_atomic_fetch_add(&A.flags[parent], kMine, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+                old = __hip_atomic_fetch_add(&A.flags[parent], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
             } else if (MODE == 0) {  // release: the record is visible device-wide before the count
-                old = __hip_atomic_fetch_add(&A.flags[parent], kMine, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                old = __hip_atomic_fetch_add(&A.flags[parent], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             } else {
                 if (MODE == 1) __threadfence();
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                old = atomicAdd(&A.flags[parent], kMine);
+                old = atomicAdd(&A.flags[parent], 1u);
             }
             if (old == 0u) break;  // first to arrive: the sibling carries on from here
             if (MODE == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the sibling's record, released before its count
@@ -1230,19 +1287,18 @@ __global__ __launch_bounds__(MODE == 3 ? kOneGroupThreads : kBlock) void climb_u
 // Small trees (the demos' meshes and TLASes have 1 .. 12 primitives) are all launch overhead in the
 // pipeline above.  Here one 512-thread workgroup, one primitive per thread, runs the same steps with
 // the same device functions: centroid bounds, Morton codes, a stable sort in LDS (bitonic network on
-// (code, index) pairs), gap priorities, the topology climb (every gap is local), the prefix sum of the
-// left-spine lengths and the box climb that writes the pre-order records.
+// (code, index) pairs), gap priorities, every leaf's S (the scan of the running-minimum records, here one gap per
+// thread) and the box climb that writes the pre-order records.
 __global__ __launch_bounds__(kChunk) void lbvh_small_kernel(uint32_t n, const float* __restrict__ aabb6,
                                                             uint64_t* __restrict__ codes_unsorted,
                                                             uint64_t* __restrict__ keys_sorted,
                                                             uint32_t* __restrict__ vals_sorted, ClimbArgs A,
+                                                            uint8_t* __restrict__ prio_w, uint32_t* __restrict__ spine_w,
                                                             uint32_t box_bounds) {
     __shared__ uint64_t skey[kChunk];
     __shared__ uint32_t sidx[kChunk];
     __shared__ uint32_t sbounds[6];
-    __shared__ uint32_t wave_tot[kChunk / 64];
     const uint32_t t = threadIdx.x;
-    const int wave = t >> 6, lane = t & 63;
 
     if (t < 3) sbounds[t] = f2ord(3.402823466e+38f);
     else if (t < 6) sbounds[t] = f2ord(-3.402823466e+38f);
@@ -1295,26 +1351,21 @@ __global__ __launch_bounds__(kChunk) void lbvh_small_kernel(uint32_t n, const fl
         keys_sorted[t] = skey[t];
         vals_sorted[t] = sidx[t];
     }
-    if (t + 1 < n) A.prio[t] = gap_priority_of(skey, n, t);
-    __syncthreads();  // the climbs read prio and vals_sorted back from memory
-    climb_local<false>(0u, A);
-    __syncthreads();
-    {   // inclusive prefix sum of the left-spine lengths
-        const uint32_t v = (t < n) ? A.cnt_l[t] : 0u;
-        uint32_t incl = v;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            uint32_t up = __shfl_up(incl, o);
-            if (lane >= o) incl += up;
+    {   // S(t) = t + the records of the running minimum of the priorities that starts at gap t
+        uint32_t p = 0;
+        VisF mine = vis_identity();
+        if (t + 1 < n) {
+            p = gap_priority_of(skey, n, t);
+            prio_w[t] = (uint8_t)p;
+            mine = vis_push(p, mine);
         }
-        if (lane == 63) wave_tot[wave] = incl;
-        __syncthreads();
-        uint32_t before = 0;
-        for (int w = 0; w < wave; w++) before += wave_tot[w];
-        if (t < n) A.cnt_l[t] = before + incl;
+        VisF total;
+        const VisF right = vis_block_suffix<kChunk>(mine, &total);
+        if (t + 1 < n) mine = vis_push(p, right);
+        if (t < n) spine_w[t] = t + (t + 1 < n ? vis_count(mine) : 0u);
     }
-    __syncthreads();
-    climb_local<true>(0u, A);
+    __syncthreads();  // the climb reads prio, spine and vals_sorted back from memory
+    climb_local(0u, A);
 }
 
 // ---- K8: world box of every instance, rt_cpu_tlas_node_to_aabb, raytracer_cpu.c:131-147 ------
@@ -1418,23 +1469,6 @@ int scan_u32(rthip_ctx* ctx, uint32_t* d, uint64_t n, uint32_t* tmp, hipStream_t
     RT_TRY((scan_u32<false>(ctx, tmp, blocks, tmp + ((blocks + 63) & ~63u), s)));
     scan_add_kernel<<<blocks, kBlock, 0, s>>>(d, n, tmp);
     RT_HIP(ctx, hipGetLastError());
-    return RTHIP_OK;
-}
-
-// Inclusive prefix sum per tile of kScanTile values, with the exclusive sums of the tiles left in tmp (*tile_sums; nullptr
-// when one tile holds everything): the consumer adds the tile's sum itself instead of a pass over the data doing it.
-int scan_u32_tiles(rthip_ctx* ctx, uint32_t* d, uint64_t n, uint32_t* tmp, hipStream_t s, const uint32_t** tile_sums) {
-    uint32_t blocks = div_up(n, kScanTile);
-    if (blocks <= 1) {
-        scan_tile_kernel<true><<<1, kBlock, 0, s>>>(d, n, nullptr);
-        RT_HIP(ctx, hipGetLastError());
-        *tile_sums = nullptr;
-        return RTHIP_OK;
-    }
-    scan_tile_kernel<true><<<blocks, kBlock, 0, s>>>(d, n, tmp);
-    RT_HIP(ctx, hipGetLastError());
-    RT_TRY((scan_u32<false>(ctx, tmp, blocks, tmp + ((blocks + 63) & ~63u), s)));
-    *tile_sums = tmp;
     return RTHIP_OK;
 }
 
@@ -1565,13 +1599,12 @@ int lbvh_reserve_workspace(rthip_ctx* ctx, uint64_t n, LbvhWorkspace* ws) {
     RT_TRY(rthip_reserve(ctx, w.vals[0], n * 4));
     RT_TRY(rthip_reserve(ctx, w.vals[1], n * 4));
     RT_TRY(rthip_reserve(ctx, w.block_hist, (hist_elems + 256) * 4));
-    RT_TRY(rthip_reserve(ctx, w.scan_tmp, scan_tmp_elems(n) * 4));
-    RT_TRY(rthip_reserve(ctx, w.prio, n));
+    RT_TRY(rthip_reserve(ctx, w.prio, n + 8));
     RT_TRY(rthip_reserve(ctx, w.child, 2 * n * sizeof(ChildRec)));
-    RT_TRY(rthip_reserve(ctx, w.child_topo, n * 8));
+    RT_TRY(rthip_reserve(ctx, w.vis, (size_t)div_up(n, kVisTile) * (sizeof(ulonglong2) + sizeof(VisF))));
     RT_TRY(rthip_reserve(ctx, w.flags, n * 4));
-    RT_TRY(rthip_reserve(ctx, w.starters, (n / 2 + 1) * sizeof(uint4)));  // a leaf delivers to at most one such node, a node takes two
-    RT_TRY(rthip_reserve(ctx, w.cnt_l, n * 4));
+    RT_TRY(rthip_reserve(ctx, w.starters, (n / 2 + 1) * 4));  // a leaf delivers to at most one such node, a node takes two
+    RT_TRY(rthip_reserve(ctx, w.spine, n * 4 + 32));
     RT_TRY(rthip_reserve(ctx, w.bounds, kBoundBytes));
     return RTHIP_OK;
 }
@@ -1589,30 +1622,26 @@ int lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, float4* 
     uint32_t* bounds = (uint32_t*)w.bounds.p;
     uint64_t* keys[2] = {(uint64_t*)w.keys[0].p, (uint64_t*)w.keys[1].p};
     uint32_t* vals[2] = {(uint32_t*)w.vals[0].p, (uint32_t*)w.vals[1].p};
-    uint32_t* scan_tmp = (uint32_t*)w.scan_tmp.p;
+    uint8_t* prio = (uint8_t*)w.prio.p;
+    uint32_t* spine = (uint32_t*)w.spine.p;
 
     ClimbArgs A;
     A.n = (uint32_t)n;
-    A.prio = (uint8_t*)w.prio.p;
+    A.prio = prio;
     A.aabb6 = d_aabb6;
     A.child = (ChildRec*)w.child.p;
-    A.topo_slot = (unsigned long long*)w.child_topo.p;
     A.flags = (uint32_t*)w.flags.p;
-    A.cnt_l = (uint32_t*)w.cnt_l.p;
-    A.tile_sums = nullptr;
-    A.starters = (uint4*)w.starters.p;
+    A.spine = spine;
+    A.starters = (uint32_t*)w.starters.p;
     A.start_count = (uint32_t*)w.flags.p + (n - 1);
     A.nodes = d_nodes;
     A.paired = paired ? 1u : 0u;
-    A.prio_ready = false;
 
     if (n <= (uint64_t)kChunk) {  // one workgroup does everything
         ctx->bounds_of = nullptr;
-        A.keys = keys[1];
         A.sorted_idx = vals[1];
-        A.prio_ready = true;
         A.start_count = (uint32_t*)w.flags.p;  // never counted: no gap spans chunks
-        lbvh_small_kernel<<<1, kChunk, 0, s>>>((uint32_t)n, d_aabb6, keys[0], keys[1], vals[1], A, ctx->box_bounds);
+        lbvh_small_kernel<<<1, kChunk, 0, s>>>((uint32_t)n, d_aabb6, keys[0], keys[1], vals[1], A, prio, spine, ctx->box_bounds);
         RT_HIP(ctx, hipGetLastError());
         if (d_codes_unsorted) RT_HIP(ctx, hipMemcpyAsync(d_codes_unsorted, keys[0], n * 8, hipMemcpyDeviceToDevice, s));
         if (d_keys_sorted) RT_HIP(ctx, hipMemcpyAsync(d_keys_sorted, keys[1], n * 8, hipMemcpyDeviceToDevice, s));
@@ -1627,7 +1656,7 @@ int lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, float4* 
     }
     ctx->bounds_of = nullptr;
     // values: see identity_vals; the arrival counters of the n - 1 gaps + the starter count are cleared on the way
-    morton_kernel<<<div_up(n, kBlock) < 4096u ? div_up(n, kBlock) : 4096u, kBlock, 0, s>>>(d_aabb6, n, bounds, keys[0], nullptr, (uint32_t*)w.flags.p, A.topo_slot);
+    morton_kernel<<<div_up(n, kBlock) < 4096u ? div_up(n, kBlock) : 4096u, kBlock, 0, s>>>(d_aabb6, n, bounds, keys[0], nullptr, (uint32_t*)w.flags.p);
     RT_HIP(ctx, hipGetLastError());
     if (d_codes_unsorted)
         RT_HIP(ctx, hipMemcpyAsync(d_codes_unsorted, keys[0], n * 8, hipMemcpyDeviceToDevice, s));
@@ -1637,19 +1666,21 @@ int lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, float4* 
     if (d_keys_sorted) RT_HIP(ctx, hipMemcpyAsync(d_keys_sorted, keys[cur], n * 8, hipMemcpyDeviceToDevice, s));
     if (d_ids_sorted) RT_HIP(ctx, hipMemcpyAsync(d_ids_sorted, vals[cur], n * 4, hipMemcpyDeviceToDevice, s));
 
-    A.keys = keys[cur];
     A.sorted_idx = vals[cur];
     const uint32_t chunks = div_up(n, kChunk);
     uint32_t ublocks = div_up(n - 1, kBlock);
     if (ublocks > 2048) ublocks = 2048;
-    // topology: gap priorities, left-spine lengths, the list of nodes the upper kernels start from
-    climb_local_kernel<false><<<chunks, kChunk, 0, s>>>(A);
+    // shape: gap priorities and every leaf's S, by a suffix scan of the running-minimum records
+    const uint32_t vtiles = div_up(n, kVisTile);
+    ulonglong2* tile_in = (ulonglong2*)w.vis.p;
+    VisF* tile_f = (VisF*)(tile_in + vtiles);
+    vis_tile_kernel<<<vtiles, kBlock, 0, s>>>(keys[cur], (uint32_t)n, prio, tile_f);
     RT_HIP(ctx, hipGetLastError());
-    climb_upper_topo_kernel<<<ublocks, kBlock, 0, s>>>(A);
+    if (vtiles > kVisFusedTiles) vis_tiles_kernel<<<1, kVisTilesBlock, 0, s>>>(tile_f, vtiles, tile_in);
+    vis_leaf_kernel<<<vtiles, kBlock, 0, s>>>(prio, (uint32_t)n, tile_f, vtiles, vtiles > kVisFusedTiles ? tile_in : nullptr, spine);
     RT_HIP(ctx, hipGetLastError());
-    RT_TRY(scan_u32_tiles(ctx, (uint32_t*)w.cnt_l.p, n, scan_tmp, s, &A.tile_sums));
     // boxes: every node's record goes to its pre-order place
-    climb_local_kernel<true><<<chunks, kChunk, 0, s>>>(A);
+    climb_local_kernel<<<chunks, kChunk, 0, s>>>(A);
     RT_HIP(ctx, hipGetLastError());
     if (n <= kOneGroupUpper && !ctx->upper_device_wide) climb_upper_kernel<3><<<1, kOneGroupThreads, 0, s>>>(A);
     else if (ctx->refit_fence == 1) climb_upper_kernel<1><<<ublocks, kBlock, 0, s>>>(A);
@@ -1706,10 +1737,9 @@ int lbvh_static_workspace_init(rthip_ctx* ctx) {
     bool ok = carve(w.keys[0], base, off, n * 8) && carve(w.keys[1], base, off, n * 8) && carve(w.vals[0], base, off, n * 4) &&
               carve(w.vals[1], base, off, n * 4) &&
               carve(w.block_hist, base, off, hist_bytes) &&
-              carve(w.scan_tmp, base, off, scan_tmp_elems(n) * 4) &&
-              carve(w.prio, base, off, n) && carve(w.child, base, off, 2 * n * sizeof(ChildRec)) &&
-              carve(w.child_topo, base, off, n * 8) && carve(w.flags, base, off, n * 4) &&
-              carve(w.starters, base, off, (n / 2 + 1) * sizeof(uint4)) && carve(w.cnt_l, base, off, n * 4) && carve(w.bounds, base, off, kBoundBytes);
+              carve(w.prio, base, off, n + 8) && carve(w.child, base, off, 2 * n * sizeof(ChildRec)) &&
+              carve(w.vis, base, off, (size_t)div_up(n, kVisTile) * (sizeof(ulonglong2) + sizeof(VisF))) && carve(w.flags, base, off, n * 4) &&
+              carve(w.starters, base, off, (n / 2 + 1) * 4) && carve(w.spine, base, off, n * 4 + 32) && carve(w.bounds, base, off, kBoundBytes);
     if (!ok) return rthip_fail(ctx, RTHIP_E_LIMIT, "the static workspace of %zu bytes is too small for %llu boxes", kStaticBytes, (unsigned long long)n);
     ctx->ws_static_ready = true;
     return RTHIP_OK;

@@ -29,14 +29,13 @@ struct LbvhWorkspace {
     DevBuf keys[2];     // uint64[n]   Morton codes, ping-pong
     DevBuf vals[2];     // uint32[n]   0-based primitive index, ping-pong
     DevBuf block_hist;  // uint32[256 * tiles] per-tile digit counts, digit-major
-    DevBuf scan_tmp;    // uint32[...] block sums of the device-wide scans
-    DevBuf scan_aux;    // the same for scan_inclusive_u32_device
+    DevBuf scan_aux;    // uint32[...] block sums of the device-wide scans
     DevBuf prio;        // uint8[n-1]  split priority of every gap
     DevBuf child;       // ChildRec[2(n-1)]  box climb: records for parents that span chunks
-    DevBuf child_topo;  // uint64[n-1]       topology climb: one hand-over word per gap
+    DevBuf vis;         // per tile of 2048 gaps: what the tile does to the mask of running-minimum records, and the mask behind it
     DevBuf flags;       // uint32[n-1] arrival counters (+ the starter count)
-    DevBuf starters;    // gaps whose two children both arrived in the chunk-local kernel (start list of the upper kernels)
-    DevBuf cnt_l;       // uint32[n]   left-spine lengths, then their tile-wise inclusive scan
+    DevBuf starters;    // gaps whose two children both arrived in the chunk-local kernel (start list of the upper kernel)
+    DevBuf spine;       // uint32[n]   S(i) of every sorted leaf: its pre-order index is i + S(i)
     DevBuf bounds;      // ordered-int centroid bounds, in several copies that the Morton kernel folds
 };
 
