@@ -1698,7 +1698,7 @@ int lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, float4* 
 namespace {
 
 constexpr size_t kStaticSlack = 1u << 20;  // block histograms, scan sums, bounds, alignment padding
-constexpr size_t kStaticBytes = kStaticBuildMaxBoxes * 120u + kStaticSlack;  // 113 bytes per box: keys, values, priorities, child slots, hand-over words, counters, lists
+constexpr size_t kStaticBytes = kStaticBuildMaxBoxes * 120u + kStaticSlack;  // 99 bytes per box: keys, values, priorities, child slots, pre-order offsets, counters, lists
 static __device__ __align__(256) unsigned char scratch[kStaticBytes];
 
 constexpr int kMaxDevices = 64;
