@@ -16,9 +16,10 @@
 //   * so each subtree can find its parent locally: of the two gaps that bound its leaf
 //     range, the one with the larger priority (bottom-up walk, one thread per leaf, the
 //     second child to arrive at a node carries on);
-//   * pre-order index of leaf i = i + (number of inner nodes whose range starts at or
-//     before i) and the inner nodes on a left spine sit directly in front of its leaf,
-//     so one prefix sum places every node; skip = index + subtree size.
+//   * pre-order index of a node = 2 * (its first leaf) + (the number of its ancestors that
+//     hold it in their left subtree); for a leaf that number comes from a scan over the gap
+//     priorities, an inner node sits directly in front of its left child; skip = index +
+//     subtree size.
 //
 // Floating point: compiled with -ffp-contract=off; min/max are the reference's
 // ternaries (common_core.h:113-114) so that ties and signed zeros resolve the same way.
@@ -37,7 +38,8 @@ constexpr int kScanTile = kBlock * kScanItems;  // 2048 values per workgroup
 struct alignas(16) ChildRec {  // == ChildInfo: what a child leaves at its parent
     float box[6];
     uint32_t far_end;  // the end of the child's leaf range that is not the parent's gap
-    uint32_t dl;       // number of left-edges from the child down to its leftmost leaf
+    uint32_t lefts;    // low half: how many of the child's ancestors hold it in their LEFT subtree (its pre-order index
+                       // is 2 * first leaf + that); upper half, in records that go through HBM: a gap priority (ClimbArgs)
 };
 static_assert(sizeof(ChildRec) == 32, "ChildRec must be 32 bytes");
 
@@ -794,9 +796,10 @@ __device__ __forceinline__ uint8_t gap_priority_of(const uint64_t* keys, uint64_
 // minimum that starts at gap i.  Priorities are below 128 (63 bit levels, 64 + the depth in an equal-code run), so the
 // set of records seen from gap i is a 128-bit mask M_i, and
 //     M_i = (M_{i+1} & bits below p_i) | bit p_i                                         (VisF below)
-// is a suffix scan with a small associative operator.  Three small kernels give every leaf S(i) = i + popcount(M_i),
-// its pre-order index being i + S(i); the inner node with range [l, r] and dl left edges down to leaf l sits at
-// l + S(l) - dl.  No climb, no hand-offs, no atomics for the shape.
+// is a suffix scan with a small associative operator.  Three small kernels give every leaf popcount(M_i), one byte, its
+// pre-order index being 2 i + popcount(M_i).  An inner node sits directly in front of its left child, so the box climb
+// carries the count along (a parent's is its left child's minus one) and every node it finishes knows its place.  No
+// climb, no hand-offs, no atomics for the shape.
 //
 // Boxes (merge_rng3_f32(left, right), lbvh.c:58) do need the children first: one bottom-up climb, one thread per sorted
 // leaf.  A node is identified by its leaf range; a child leaves a record in its parent's slot and bumps the parent's
@@ -952,10 +955,10 @@ __global__ __launch_bounds__(kVisTilesBlock) void vis_tiles_kernel(const VisF* _
     }
 }
 
-// Pass 3: S(i) = i + records seen from gap i, for the leaves of a tile (the last leaf has no gap: S = n - 1).
+// Pass 3: the number of records seen from gap i, for the leaves of a tile (the last leaf has no gap: 0).
 // tile_in == nullptr: at most kVisFusedTiles tiles, and the workgroup joins the tiles behind its own itself.
 __global__ __launch_bounds__(kBlock) void vis_leaf_kernel(const uint8_t* __restrict__ prio, uint32_t n, const VisF* __restrict__ tile_f,
-                                                          uint32_t tiles, const ulonglong2* __restrict__ tile_in, uint32_t* __restrict__ spine) {
+                                                          uint32_t tiles, const ulonglong2* __restrict__ tile_in, uint8_t* __restrict__ lefts) {
     const uint32_t g0 = blockIdx.x * (uint32_t)kVisTile + threadIdx.x * kVisItems;
     uint32_t p[kVisItems];
     if (g0 + kVisItems < n) {  // all eight gaps exist: one 8-byte load (prio is 256-byte aligned, g0 a multiple of 8)
@@ -990,24 +993,24 @@ __global__ __launch_bounds__(kBlock) void vis_leaf_kernel(const uint8_t* __restr
     for (int j = kVisItems - 1; j >= 0; j--) {
         const uint32_t i = g0 + (uint32_t)j;
         if (i + 1 < n) right = vis_push(p[j], right);
-        out[j] = i + (i + 1 < n ? vis_count(right) : 0u);
+        out[j] = i + 1 < n ? vis_count(right) : 0u;  // at most 127
     }
-    if (g0 + kVisItems <= n) {
-        ((uint4*)(spine + g0))[0] = make_uint4(out[0], out[1], out[2], out[3]);
-        ((uint4*)(spine + g0))[1] = make_uint4(out[4], out[5], out[6], out[7]);
+    if (g0 + kVisItems <= n) {  // one 8-byte store (lefts is 256-byte aligned, g0 a multiple of 8)
+        *(uint2*)(lefts + g0) = make_uint2(out[0] | (out[1] << 8) | (out[2] << 16) | (out[3] << 24),
+                                           out[4] | (out[5] << 8) | (out[6] << 16) | (out[7] << 24));
     } else {
 #pragma unroll
         for (int j = 0; j < kVisItems; j++)
-            if (g0 + j < n) spine[g0 + j] = out[j];
+            if (g0 + j < n) lefts[g0 + j] = (uint8_t)out[j];
     }
 }
 
 template <bool FENCE>
-__device__ __forceinline__ void child_store(ChildRec* slot, const float* box, uint32_t far_end, uint32_t dl) {
+__device__ __forceinline__ void child_store(ChildRec* slot, const float* box, uint32_t far_end, uint32_t lefts) {
     uint64_t w0 = (uint64_t)__float_as_uint(box[0]) | ((uint64_t)__float_as_uint(box[1]) << 32);
     uint64_t w1 = (uint64_t)__float_as_uint(box[2]) | ((uint64_t)__float_as_uint(box[3]) << 32);
     uint64_t w2 = (uint64_t)__float_as_uint(box[4]) | ((uint64_t)__float_as_uint(box[5]) << 32);
-    uint64_t w3 = (uint64_t)far_end | ((uint64_t)dl << 32);
+    uint64_t w3 = (uint64_t)far_end | ((uint64_t)lefts << 32);
     uint64_t* p = (uint64_t*)slot;
     if (FENCE) {
         p[0] = w0; p[1] = w1; p[2] = w2; p[3] = w3;
@@ -1019,7 +1022,7 @@ __device__ __forceinline__ void child_store(ChildRec* slot, const float* box, ui
     }
 }
 template <bool FENCE>
-__device__ __forceinline__ void child_load(const ChildRec* slot, float* box, uint32_t* far_end, uint32_t* dl) {
+__device__ __forceinline__ void child_load(const ChildRec* slot, float* box, uint32_t* far_end, uint32_t* lefts) {
     uint64_t* p = (uint64_t*)slot;
     uint64_t w0, w1, w2, w3;
     if (FENCE) {
@@ -1035,7 +1038,7 @@ __device__ __forceinline__ void child_load(const ChildRec* slot, float* box, uin
     box[2] = __uint_as_float((uint32_t)w1); box[3] = __uint_as_float((uint32_t)(w1 >> 32));
     box[4] = __uint_as_float((uint32_t)w2); box[5] = __uint_as_float((uint32_t)(w2 >> 32));
     *far_end = (uint32_t)w3;
-    *dl = (uint32_t)(w3 >> 32);
+    *lefts = (uint32_t)(w3 >> 32);
 }
 
 // merge with a sibling: the LEFT child's box is the first argument of every Min / Max (lbvh.c:58)
@@ -1052,9 +1055,9 @@ __device__ __forceinline__ void merge_sibling(float* box, const float* sbox, boo
 // (min.x, max.x, min.y, max.y | min.z, max.z, skip, id), in which the two bounds of an axis sit in neighbouring
 // registers after the load -- what the packed subtract / multiply of the slab test want (trav_step in rt_device.h
 // reads it).
-__device__ __forceinline__ void put_node(float4* __restrict__ nodes, uint32_t pre, const float* box, uint32_t skip, uint32_t id,
-                                         uint32_t paired) {
-    if (paired) {
+template <bool PAIRED>
+__device__ __forceinline__ void put_node(float4* __restrict__ nodes, uint32_t pre, const float* box, uint32_t skip, uint32_t id) {
+    if (PAIRED) {
         nodes[2 * (uint64_t)pre] = make_float4(box[0], box[3], box[1], box[4]);
         nodes[2 * (uint64_t)pre + 1] = make_float4(box[2], box[5], __uint_as_float(skip), __uint_as_float(id));
     } else {
@@ -1063,11 +1066,11 @@ __device__ __forceinline__ void put_node(float4* __restrict__ nodes, uint32_t pr
     }
 }
 
-// the finished inner node with leaf range [l, r] and dl left edges down to leaf l
-__device__ __forceinline__ void put_inner(float4* __restrict__ nodes, const uint32_t* __restrict__ spine, const float* box, uint32_t l,
-                                          uint32_t r, uint32_t dl, uint32_t paired) {
-    const uint32_t pre = l + spine[l] - dl;
-    put_node(nodes, pre, box, pre + 2u * (r - l + 1u) - 1u, 0u, paired);
+// the finished inner node with leaf range [l, r] that `lefts` of its ancestors hold in their left subtree
+template <bool PAIRED>
+__device__ __forceinline__ void put_inner(float4* __restrict__ nodes, const float* box, uint32_t l, uint32_t r, uint32_t lefts) {
+    const uint32_t pre = 2u * l + lefts;
+    put_node<PAIRED>(nodes, pre, box, pre + 2u * (r - l + 1u) - 1u, 0u);
 }
 
 struct ClimbArgs {
@@ -1075,153 +1078,267 @@ struct ClimbArgs {
     const uint8_t* prio;       // gap priorities
     const uint32_t* sorted_idx;
     const float* aabb6;
-    ChildRec* child;           // records for parents that span chunks; the dl word also carries, in its upper half, the
+    ChildRec* child;           // records for parents that span chunks; the `lefts` word also carries, in its upper half, the
                                // priority of the gap beyond the child's far end (which the parent needs to find ITS parent)
     uint32_t* flags;           // arrival counters, zero before the climb
-    const uint32_t* spine;     // S(i) of every leaf
+    const uint8_t* lefts;      // of every sorted leaf: how many of its ancestors hold it in their left subtree
     uint32_t* starters;        // gaps of the nodes that span chunks and got both children from the local kernel
     uint32_t* start_count;
     float4* nodes;             // the pre-order records
-    uint32_t paired;
 };
 
-// The chunk-local part of the climb.
-__device__ __forceinline__ void climb_local(uint32_t c0, const ClimbArgs& A) {
+#ifdef RT_CLIMB_STAMP
+__device__ uint64_t g_climb_stamps[8 * 32768];  // dev build only: wall clock at the phases of the first workgroups
+#define CLIMB_STAMP(k) if (threadIdx.x == 0 && blockIdx.x < 32768u) g_climb_stamps[8 * blockIdx.x + (k)] = wall_clock64()
+#else
+#define CLIMB_STAMP(k)
+#endif
+
+// The chunk-local part of the climb.  What a thread reads for its leaf comes in two steps: LeafIn, then the box through
+// LeafIn::prim.
+struct ClimbLds {
+    ChildRec lrec[2 * kChunk];         // per local gap: what its left and its right child left there
+    uint32_t lflag[kChunk];            // per local gap: children arrived
+    uint16_t queue[3][kChunk / 2];     // the gaps (relative to c0) whose second child arrived in the generation before
+    uint16_t pend[kChunk];             // gap - c0 + 1 of the parents that span chunks at which this chunk left a record
+    uint16_t stage[kChunk];            // of those, the ones that this chunk found complete: for the upper kernel
+    uint32_t qn[3], n_pend, n_start;
+    uint32_t wmin_l[kChunk / 64], wmin_r[kChunk / 64];
     // window of gap priorities: entry k is gap c0 - 1 + k, k = 0 .. kChunk; bit 7 marks a local gap.
     // Gaps that do not exist (-1, >= n-1) read as 0, below every real priority (>= 1).
-    __shared__ uint8_t win[kChunk + 8];
-    __shared__ uint32_t lflag[kChunk];
-    __shared__ ChildRec lrec[2 * kChunk];
-    __shared__ uint32_t wmin_l[kChunk / 64], wmin_r[kChunk / 64];
-    __shared__ uint32_t n_start, waves_done;  // nodes that this workgroup found complete for the upper kernel
-    __shared__ uint32_t stage[kChunk];
+    uint8_t win[kChunk + 8];
+};
 
-    const uint32_t n = A.n;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    if (tid == 0) {
-        n_start = 0;
-        waves_done = 0;
+struct LeafIn {
+    uint32_t prim;      // the sorted leaf's primitive
+    uint32_t lefts;     // how many of its ancestors hold it in their left subtree
+    uint32_t prio;      // of gap c0 - 1 + thread (0: there is none)
+    uint32_t prio_end;  // thread 0: of gap c0 - 1 + kChunk
+};
+
+__device__ __forceinline__ LeafIn leaf_in(uint32_t c0, const ClimbArgs& A) {
+    LeafIn in = {0u, 0u, 0u, 0u};
+    const uint32_t n = A.n, i = c0 + threadIdx.x;
+    const int64_t g = (int64_t)c0 - 1 + threadIdx.x;
+    if (g >= 0 && g + 1 < (int64_t)n) in.prio = A.prio[g];
+    if (threadIdx.x == 0) {
+        const int64_t ge = (int64_t)c0 - 1 + kChunk;
+        if (ge + 1 < (int64_t)n) in.prio_end = A.prio[ge];
     }
-
-    const uint32_t i = c0 + (uint32_t)tid;
-    {
-        const int64_t g = (int64_t)c0 - 1 + tid;
-        win[tid] = (g >= 0 && g + 1 < (int64_t)n) ? A.prio[g] : (uint8_t)0;
-        if (tid == 0) {
-            const int64_t ge = (int64_t)c0 - 1 + kChunk;
-            win[kChunk] = (ge + 1 < (int64_t)n) ? A.prio[ge] : (uint8_t)0;
-        }
-    }
-    lflag[tid] = 0;
-    __syncthreads();
-
-    {   // local[k] <=> win[k] > min(win[0..k-1]) and win[k] > min(win[k+1..kChunk]), k = 1 .. kChunk-1; thread t owns entry t
-        const uint32_t e = win[tid];
-        uint32_t pre = e, suf = e;  // inclusive over the wave
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            uint32_t a = __shfl_up(pre, o), b = __shfl_down(suf, o);
-            if (lane >= o) pre = a < pre ? a : pre;
-            if (lane + o < 64) suf = b < suf ? b : suf;
-        }
-        if (lane == 63) wmin_l[wave] = pre;
-        if (lane == 0) wmin_r[wave] = suf;
-        __syncthreads();
-        uint32_t before = 0xffu, after = win[kChunk];  // minima over the entries before / after this one
-        for (int w = 0; w < kChunk / 64; w++) {
-            if (w < wave) before = wmin_l[w] < before ? wmin_l[w] : before;
-            if (w > wave) after = wmin_r[w] < after ? wmin_r[w] : after;
-        }
-        const uint32_t pl = __shfl_up(pre, 1), sr = __shfl_down(suf, 1);
-        if (lane > 0) before = pl < before ? pl : before;
-        if (lane < 63) after = sr < after ? sr : after;
-        const bool loc = tid >= 1 && e > before && e > after;
-        __syncthreads();
-        win[tid] = (uint8_t)(e | (loc ? 0x80u : 0u));
-    }
-    __syncthreads();
-
-    uint32_t my_start = 0;
-    bool have_start = false;
     if (i < n) {
-        uint32_t l = i, r = i, dl = 0;
-        float box[6];
-        {
-            const uint32_t prim = A.sorted_idx[i];
-            const float* b = A.aabb6 + 6 * (uint64_t)prim;  // node->aabb = in_aabbs[id - 1], lbvh.c:53
-#pragma unroll
-            for (int k = 0; k < 6; k++) box[k] = b[k];
-            const uint32_t pre = i + A.spine[i];
-            put_node(A.nodes, pre, box, pre + 1, prim + 1, A.paired);  // id = idx + 1, lbvh.c:116
-        }
-        for (;;) {
-            if (l == 0 && r == n - 1) break;  // the root
-            // Priorities of the two gaps that bound [l, r]; the parent is the one with the larger priority.
-            // While the node is inside the chunk both gaps are inside the window.
-            const uint32_t pr_r = (r != n - 1) ? (uint32_t)win[r + 1 - c0] : 0u;
-            const uint32_t pr_l = (l != 0) ? (uint32_t)win[l - c0] : 0u;
-            const bool parent_right = (l == 0) || (r != n - 1 && (pr_r & 0x7fu) > (pr_l & 0x7fu));
-            const uint32_t parent = parent_right ? r : l - 1;
-            const uint32_t side = parent_right ? 0u : 1u;  // 0: this node is the LEFT child
-            const bool local = ((parent_right ? pr_r : pr_l) & 0x80u) != 0;
-            const uint32_t far_end = parent_right ? l : r;
-            ChildRec mine;
-#pragma unroll
-            for (int k = 0; k < 6; k++) mine.box[k] = box[k];
-            mine.far_end = far_end;
-            if (!local) {  // the parent spans chunks: leave the record for the upper kernel
-                const uint32_t far_prio = (parent_right ? pr_l : pr_r) & 0x7fu;  // of the gap beyond the far end
-                mine.dl = dl | (far_prio << 16);
-                A.child[2 * (uint64_t)parent + side] = mine;
-                // the second child to be counted knows that the parent is complete: it goes on the upper kernel's list
-                if (atomicAdd(&A.flags[parent], 1u) == 1u) {
-                    my_start = parent;
-                    have_start = true;
-                }
-                break;
-            }
-            const uint32_t slot = parent - c0;
-            mine.dl = dl;
-            lrec[2 * slot + side] = mine;
-            // order the LDS record before the LDS counter and the counter before the sibling's record; LDS only:
-            // a fence that also covered global memory would make every level wait for the node stores below it
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-            const uint32_t old = atomicAdd(&lflag[slot], 1u);
-            if (old == 0) break;  // first to arrive: the sibling's thread carries on from here
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-            const ChildRec sib = lrec[2 * slot + (1u - side)];
-            merge_sibling(box, sib.box, side == 0);
-            if (side == 0) {
-                r = sib.far_end;
-                dl = dl + 1;
-            } else {
-                l = sib.far_end;
-                dl = sib.dl + 1;
-            }
-            put_inner(A.nodes, A.spine, box, l, r, dl, A.paired);
-        }
+        in.prim = A.sorted_idx[i];
+        in.lefts = A.lefts[i];
     }
-    // Hand the complete nodes to the upper kernel with one device-wide atomic per workgroup, without a workgroup
-    // barrier: a wave stages its nodes in LDS and is done; the last wave to get here takes the workgroup's place in
-    // the list and copies the staged nodes out.
-    if (have_start) stage[atomicAdd(&n_start, 1u)] = my_start;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    uint32_t before = 0;
-    if (lane == 0) before = __hip_atomic_fetch_add(&waves_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    before = __shfl(before, 0);
-    if (before == blockDim.x / 64 - 1) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-        const uint32_t total = n_start;
-        if (total != 0) {
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(A.start_count, total);
-            base = __shfl(base, 0);
-            for (uint32_t k = lane; k < total; k += 64) A.starters[base + k] = stage[k];
-        }
+    return in;
+}
+
+__device__ __forceinline__ void leaf_box(uint32_t c0, const ClimbArgs& A, const LeafIn& in, float* box) {
+    if (c0 + threadIdx.x < A.n) {
+        const float* b = A.aabb6 + 6 * (uint64_t)in.prim;  // node->aabb = in_aabbs[id - 1], lbvh.c:53
+#pragma unroll
+        for (int k = 0; k < 6; k++) box[k] = b[k];
     }
 }
 
-__global__ __launch_bounds__(kChunk) void climb_local_kernel(ClimbArgs A) { climb_local(blockIdx.x * (uint32_t)kChunk, A); }
+// Which gaps of the chunk are local.  Ends with a barrier.
+__device__ __forceinline__ void chunk_window(ClimbLds& L, const LeafIn& in) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (tid == 0) {
+        L.qn[0] = L.qn[1] = L.qn[2] = 0;
+        L.n_pend = 0;
+        L.n_start = 0;
+        L.win[kChunk] = (uint8_t)in.prio_end;
+    }
+    L.lflag[tid] = 0;
+    // local[k] <=> win[k] > min(win[0..k-1]) and win[k] > min(win[k+1..kChunk]), k = 1 .. kChunk-1; thread t owns entry t
+    const uint32_t e = in.prio;
+    uint32_t pre = e, suf = e;  // inclusive over the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t a = __shfl_up(pre, o), b = __shfl_down(suf, o);
+        if (lane >= o) pre = a < pre ? a : pre;
+        if (lane + o < 64) suf = b < suf ? b : suf;
+    }
+    if (lane == 63) L.wmin_l[wave] = pre;
+    if (lane == 0) L.wmin_r[wave] = suf;
+    __syncthreads();
+    uint32_t before = 0xffu, after = L.win[kChunk];  // minima over the entries before / after this one
+    for (int w = 0; w < kChunk / 64; w++) {
+        if (w < wave) before = L.wmin_l[w] < before ? L.wmin_l[w] : before;
+        if (w > wave) after = L.wmin_r[w] < after ? L.wmin_r[w] : after;
+    }
+    const uint32_t pl = __shfl_up(pre, 1), sr = __shfl_down(suf, 1);
+    if (lane > 0) before = pl < before ? pl : before;
+    if (lane < 63) after = sr < after ? sr : after;
+    const bool loc = tid >= 1 && e > before && e > after;
+    L.win[tid] = (uint8_t)(e | (loc ? 0x80u : 0u));
+    __syncthreads();
+}
+
+// A workgroup barrier that orders LDS accesses only.  __syncthreads() also waits for the wave's outstanding global
+// stores (vmcnt(0)): inside the generation loop that is a round trip to HBM per generation for stores nobody reads here.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// Appends `value` of the lanes that `want` to a list in LDS: one atomic per wave.  Call from wave-uniform control flow.
+__device__ __forceinline__ void wave_push(bool want, uint32_t value, uint32_t* count, uint16_t* list) {
+    const uint64_t mask = __ballot(want);
+    if (mask == 0) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    const int leader = __ffsll((long long)mask) - 1;
+    uint32_t base = 0;
+    if ((int)lane == leader) base = atomicAdd(count, (uint32_t)__popcll(mask));
+    base = __shfl(base, leader);
+    if (want) list[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = (uint16_t)value;
+}
+
+// A finished node [l, r] goes to its parent: the one of the two gaps that bound it with the larger priority.  Inside
+// the chunk it leaves its record in the parent's slot, and the second child to arrive puts the parent on the next
+// generation's queue; at a parent that spans chunks it leaves the record in HBM and notes the parent for the end of
+// the chunk.  Every lane of the wave calls this (the lists are appended to per wave); `active` says which have a node.
+// pr_l, pr_r: the window's entries for the gaps in front of leaf l and behind leaf r (0: there is none); a record left
+// inside the chunk carries the entry of the gap beyond its far end, so that only the leaves read the window.
+__device__ __forceinline__ void arrive(ClimbLds& L, uint32_t c0, const ClimbArgs& A, bool active, uint32_t l, uint32_t r,
+                                       uint32_t lefts, uint32_t pr_l, uint32_t pr_r, const float* box, uint32_t next_q) {
+    const uint32_t n = A.n;
+    bool queued = false, noted = false;
+    uint32_t where = 0;
+    if (active && !(l == 0 && r == n - 1)) {  // not the root
+        const bool parent_right = (l == 0) || (r != n - 1 && (pr_r & 0x7fu) > (pr_l & 0x7fu));
+        const uint32_t parent = parent_right ? r : l - 1;
+        const uint32_t side = parent_right ? 0u : 1u;  // 0: this node is the LEFT child
+        const bool local = ((parent_right ? pr_r : pr_l) & 0x80u) != 0;
+        ChildRec mine;
+#pragma unroll
+        for (int k = 0; k < 6; k++) mine.box[k] = box[k];
+        mine.far_end = parent_right ? l : r;
+        if (local) {
+            where = parent - c0;
+            mine.lefts = lefts | ((parent_right ? pr_l : pr_r) << 16);
+            L.lrec[2 * where + side] = mine;
+            queued = atomicAdd(&L.lflag[where], 1u) == 1u;  // the records are read after the next barrier
+        } else {
+            const uint32_t far_prio = (parent_right ? pr_l : pr_r) & 0x7fu;  // of the gap beyond the far end
+            mine.lefts = lefts | (far_prio << 16);
+            A.child[2 * (uint64_t)parent + side] = mine;
+            where = parent + 1u - c0;
+            noted = true;
+        }
+    }
+    wave_push(queued, where, &L.qn[next_q], L.queue[next_q]);
+    wave_push(noted, where, &L.n_pend, L.pend);
+}
+
+// The climb of one chunk from its leaves' boxes, generation by generation: the nodes whose second child arrived in one
+// generation are finished in the next by neighbouring lanes of the first waves, the other waves wait at the barrier.
+// (A thread that climbs from its leaf for as long as it is the second to arrive leaves all eight waves running with one
+// or two lanes each for most of the chunk's height: 13-17 us of a chunk's 20-27 us instead of 10-15.)  A chunk of
+// random triangles has 12 generations on average, 184, 115, 76, 50, ... nodes each, and a generation takes a microsecond
+// whatever its size: a couple of hundred dependent instructions and half a dozen LDS round trips of one wave.
+template <bool PAIRED>
+__device__ __forceinline__ void chunk_climb(ClimbLds& L, uint32_t c0, const ClimbArgs& A, const LeafIn& in, float* box) {
+    const uint32_t n = A.n;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    {
+        const uint32_t i = c0 + tid;
+        if (i < n) {
+            const uint32_t pre = 2u * i + in.lefts;
+            put_node<PAIRED>(A.nodes, pre, box, pre + 1, in.prim + 1);  // id = idx + 1, lbvh.c:116
+        }
+        // while a node is inside the chunk both gaps that bound it are inside the window
+        const uint32_t pr_l = (i < n && i != 0) ? (uint32_t)L.win[tid] : 0u;
+        const uint32_t pr_r = (i + 1 < n) ? (uint32_t)L.win[tid + 1] : 0u;
+        arrive(L, c0, A, i < n, i, i, in.lefts, pr_l, pr_r, box, 0u);
+    }
+#ifdef RT_CLIMB_STAMP
+    uint64_t gens = 0, first = 0;
+#endif
+    for (uint32_t cur = 0, nxt = 1, clr = 2;;) {
+        lds_barrier();
+#ifdef RT_CLIMB_STAMP
+        if (gens == 0) first = wall_clock64();
+        gens++;
+        if (threadIdx.x == 0 && blockIdx.x < 32768u) { g_climb_stamps[8 * blockIdx.x + 6] = gens; g_climb_stamps[8 * blockIdx.x + 7] = first; }
+#endif
+        const uint32_t count = L.qn[cur];  // at most kChunk / 2: the nodes of a generation are disjoint
+        const uint32_t slot = L.queue[cur][tid & (kChunk / 2 - 1)];  // asked for together with the count
+        if (count == 0) break;
+        if (tid == 0) L.qn[clr] = 0;  // last read in the generation before this one
+        uint32_t l = 0, r = 0, lefts = 0, pr_l = 0, pr_r = 0;
+        if (tid < count) {
+            const ChildRec a = L.lrec[2 * slot], b = L.lrec[2 * slot + 1];  // left, right
+#pragma unroll
+            for (int k = 0; k < 6; k++) box[k] = a.box[k];
+            merge_sibling(box, b.box, true);
+            l = a.far_end;
+            r = b.far_end;
+            lefts = (a.lefts & 0xffffu) - 1u;  // the parent sits directly in front of its left child
+            pr_l = a.lefts >> 16;
+            pr_r = b.lefts >> 16;
+            put_inner<PAIRED>(A.nodes, box, l, r, lefts);
+        }
+        arrive(L, c0, A, tid < count, l, r, lefts, pr_l, pr_r, box, nxt);
+        const uint32_t t = cur;
+        cur = nxt;
+        nxt = clr;
+        clr = t;
+    }
+    CLIMB_STAMP(3);
+    // The parents that span chunks: count this chunk's records there (all at once: a counter in HBM takes microseconds
+    // to answer); where it was the second to arrive the parent is complete and goes on the upper kernel's list, with
+    // one device-wide atomic per chunk.
+    {
+        const uint32_t pending = L.n_pend;  // at most kChunk
+        bool complete = false;
+        uint32_t where = 0;
+        if (tid < pending) {
+            where = L.pend[tid];
+            complete = atomicAdd(&A.flags[c0 + where - 1u], 1u) == 1u;
+        }
+        wave_push(complete, where, &L.n_start, L.stage);
+    }
+    lds_barrier();
+    const uint32_t total = L.n_start;
+    if (tid < 64u && total != 0) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(A.start_count, total);
+        base = __shfl(base, 0);
+        for (uint32_t k = lane; k < total; k += 64u) A.starters[base + k] = c0 + L.stage[k] - 1u;
+    }
+}
+
+template <bool PAIRED>
+__global__ __launch_bounds__(kChunk) void climb_local_kernel(ClimbArgs A) {
+    __shared__ ClimbLds L;
+    const uint32_t c0 = blockIdx.x * (uint32_t)kChunk;
+    CLIMB_STAMP(0);
+    const LeafIn in = leaf_in(c0, A);
+    chunk_window(L, in);
+    CLIMB_STAMP(1);
+    float box[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    leaf_box(c0, A, in, box);
+#ifdef RT_CLIMB_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    CLIMB_STAMP(2);
+#endif
+    chunk_climb<PAIRED>(L, c0, A, in, box);
+    CLIMB_STAMP(4);
+#ifdef RT_CLIMB_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    CLIMB_STAMP(5);
+#endif
+}
+
+#ifdef RT_CLIMB_STAMP
+}  // namespace
+extern "C" int rthip_debug_climb_stamps(uint64_t* host, size_t n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_climb_stamps), n * sizeof(uint64_t));
+}
+namespace {
+#endif
 
 // MODE 3: the whole upper climb in ONE workgroup, for builds of up to kOneGroupUpper leaves, where the upper tree is a
 // couple of thousand nodes and the chain of hand-offs is all there is: all threads sit on one CU, so the hand-off is a
@@ -1232,27 +1349,27 @@ constexpr uint64_t kOneGroupUpper = 1ull << 17;
 constexpr int kOneGroupThreads = 1024;
 
 // The climb above the chunks: one thread per complete node on the list.
-template <int MODE>
+template <int MODE, bool PAIRED>
 __global__ __launch_bounds__(MODE == 3 ? kOneGroupThreads : kBlock) void climb_upper_kernel(ClimbArgs A) {
     const uint32_t n = A.n;
     const uint32_t count = *A.start_count;
     for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < count; t += gridDim.x * blockDim.x) {
         uint32_t parent = A.starters[t];
         const ChildRec a = A.child[2 * (uint64_t)parent], b = A.child[2 * (uint64_t)parent + 1];  // left, right
-        uint32_t l = a.far_end, r = b.far_end, dl = (a.dl & 0xffffu) + 1u;
-        uint32_t pl = a.dl >> 16, pr = b.dl >> 16;  // priorities of gaps l - 1 and r (0: there is none)
+        uint32_t l = a.far_end, r = b.far_end, lefts = (a.lefts & 0xffffu) - 1u;
+        uint32_t pl = a.lefts >> 16, pr = b.lefts >> 16;  // priorities of gaps l - 1 and r (0: there is none)
         float box[6];
 #pragma unroll
         for (int k = 0; k < 6; k++) box[k] = a.box[k];
         merge_sibling(box, b.box, true);
         for (;;) {
-            put_inner(A.nodes, A.spine, box, l, r, dl, A.paired);
+            put_inner<PAIRED>(A.nodes, box, l, r, lefts);
             if (l == 0 && r == n - 1) break;
             const bool parent_right = (l == 0) || (r != n - 1 && pr > pl);
             parent = parent_right ? r : l - 1;
             const uint32_t side = parent_right ? 0u : 1u;
             child_store<MODE == 1 || MODE == 3>(&A.child[2 * (uint64_t)parent + side], box, parent_right ? l : r,
-                                                dl | ((parent_right ? pl : pr) << 16));
+                                                lefts | ((parent_right ? pl : pr) << 16));
             uint32_t old;
             if (MODE == 3) {
                 old = __hip_atomic_fetch_add(&A.flags[parent], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1266,18 +1383,18 @@ __global__ __launch_bounds__(MODE == 3 ? kOneGroupThreads : kBlock) void climb_u
             if (old == 0u) break;  // first to arrive: the sibling carries on from here
             if (MODE == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the sibling's record, released before its count
             if (MODE == 1) __threadfence();
-            uint32_t s_far, s_dl;
+            uint32_t s_far, s_lefts;
             float sbox[6];
-            child_load<MODE == 1 || MODE == 3>(&A.child[2 * (uint64_t)parent + (1u - side)], sbox, &s_far, &s_dl);
+            child_load<MODE == 1 || MODE == 3>(&A.child[2 * (uint64_t)parent + (1u - side)], sbox, &s_far, &s_lefts);
             merge_sibling(box, sbox, side == 0);
             if (side == 0) {
                 r = s_far;
-                dl = dl + 1;
-                pr = s_dl >> 16;
+                lefts = lefts - 1;
+                pr = s_lefts >> 16;
             } else {
                 l = s_far;
-                dl = (s_dl & 0xffffu) + 1;
-                pl = s_dl >> 16;
+                lefts = (s_lefts & 0xffffu) - 1;
+                pl = s_lefts >> 16;
             }
         }
     }
@@ -1289,11 +1406,12 @@ __global__ __launch_bounds__(MODE == 3 ? kOneGroupThreads : kBlock) void climb_u
 // the same device functions: centroid bounds, Morton codes, a stable sort in LDS (bitonic network on
 // (code, index) pairs), gap priorities, every leaf's S (the scan of the running-minimum records, here one gap per
 // thread) and the box climb that writes the pre-order records.
+template <bool PAIRED>
 __global__ __launch_bounds__(kChunk) void lbvh_small_kernel(uint32_t n, const float* __restrict__ aabb6,
                                                             uint64_t* __restrict__ codes_unsorted,
                                                             uint64_t* __restrict__ keys_sorted,
                                                             uint32_t* __restrict__ vals_sorted, ClimbArgs A,
-                                                            uint8_t* __restrict__ prio_w, uint32_t* __restrict__ spine_w,
+                                                            uint8_t* __restrict__ prio_w, uint8_t* __restrict__ lefts_w,
                                                             uint32_t box_bounds) {
     __shared__ uint64_t skey[kChunk];
     __shared__ uint32_t sidx[kChunk];
@@ -1362,10 +1480,15 @@ __global__ __launch_bounds__(kChunk) void lbvh_small_kernel(uint32_t n, const fl
         VisF total;
         const VisF right = vis_block_suffix<kChunk>(mine, &total);
         if (t + 1 < n) mine = vis_push(p, right);
-        if (t < n) spine_w[t] = t + (t + 1 < n ? vis_count(mine) : 0u);
+        if (t < n) lefts_w[t] = (uint8_t)(t + 1 < n ? vis_count(mine) : 0u);
     }
-    __syncthreads();  // the climb reads prio, spine and vals_sorted back from memory
-    climb_local(0u, A);
+    __syncthreads();  // the climb reads prio, lefts and vals_sorted back from memory
+    __shared__ ClimbLds L;
+    const LeafIn in = leaf_in(0u, A);
+    float box[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    leaf_box(0u, A, in, box);
+    chunk_window(L, in);
+    chunk_climb<PAIRED>(L, 0u, A, in, box);
 }
 
 // ---- K8: world box of every instance, rt_cpu_tlas_node_to_aabb, raytracer_cpu.c:131-147 ------
@@ -1604,7 +1727,7 @@ int lbvh_reserve_workspace(rthip_ctx* ctx, uint64_t n, LbvhWorkspace* ws) {
     RT_TRY(rthip_reserve(ctx, w.vis, (size_t)div_up(n, kVisTile) * (sizeof(ulonglong2) + sizeof(VisF))));
     RT_TRY(rthip_reserve(ctx, w.flags, n * 4));
     RT_TRY(rthip_reserve(ctx, w.starters, (n / 2 + 1) * 4));  // a leaf delivers to at most one such node, a node takes two
-    RT_TRY(rthip_reserve(ctx, w.spine, n * 4 + 32));
+    RT_TRY(rthip_reserve(ctx, w.lefts, n + 32));
     RT_TRY(rthip_reserve(ctx, w.bounds, kBoundBytes));
     return RTHIP_OK;
 }
@@ -1623,7 +1746,7 @@ int lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, float4* 
     uint64_t* keys[2] = {(uint64_t*)w.keys[0].p, (uint64_t*)w.keys[1].p};
     uint32_t* vals[2] = {(uint32_t*)w.vals[0].p, (uint32_t*)w.vals[1].p};
     uint8_t* prio = (uint8_t*)w.prio.p;
-    uint32_t* spine = (uint32_t*)w.spine.p;
+    uint8_t* lefts = (uint8_t*)w.lefts.p;
 
     ClimbArgs A;
     A.n = (uint32_t)n;
@@ -1631,17 +1754,17 @@ int lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, float4* 
     A.aabb6 = d_aabb6;
     A.child = (ChildRec*)w.child.p;
     A.flags = (uint32_t*)w.flags.p;
-    A.spine = spine;
+    A.lefts = lefts;
     A.starters = (uint32_t*)w.starters.p;
     A.start_count = (uint32_t*)w.flags.p + (n - 1);
     A.nodes = d_nodes;
-    A.paired = paired ? 1u : 0u;
 
     if (n <= (uint64_t)kChunk) {  // one workgroup does everything
         ctx->bounds_of = nullptr;
         A.sorted_idx = vals[1];
         A.start_count = (uint32_t*)w.flags.p;  // never counted: no gap spans chunks
-        lbvh_small_kernel<<<1, kChunk, 0, s>>>((uint32_t)n, d_aabb6, keys[0], keys[1], vals[1], A, prio, spine, ctx->box_bounds);
+        if (paired) lbvh_small_kernel<true><<<1, kChunk, 0, s>>>((uint32_t)n, d_aabb6, keys[0], keys[1], vals[1], A, prio, lefts, ctx->box_bounds);
+        else lbvh_small_kernel<false><<<1, kChunk, 0, s>>>((uint32_t)n, d_aabb6, keys[0], keys[1], vals[1], A, prio, lefts, ctx->box_bounds);
         RT_HIP(ctx, hipGetLastError());
         if (d_codes_unsorted) RT_HIP(ctx, hipMemcpyAsync(d_codes_unsorted, keys[0], n * 8, hipMemcpyDeviceToDevice, s));
         if (d_keys_sorted) RT_HIP(ctx, hipMemcpyAsync(d_keys_sorted, keys[1], n * 8, hipMemcpyDeviceToDevice, s));
@@ -1677,15 +1800,21 @@ int lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, float4* 
     vis_tile_kernel<<<vtiles, kBlock, 0, s>>>(keys[cur], (uint32_t)n, prio, tile_f);
     RT_HIP(ctx, hipGetLastError());
     if (vtiles > kVisFusedTiles) vis_tiles_kernel<<<1, kVisTilesBlock, 0, s>>>(tile_f, vtiles, tile_in);
-    vis_leaf_kernel<<<vtiles, kBlock, 0, s>>>(prio, (uint32_t)n, tile_f, vtiles, vtiles > kVisFusedTiles ? tile_in : nullptr, spine);
+    vis_leaf_kernel<<<vtiles, kBlock, 0, s>>>(prio, (uint32_t)n, tile_f, vtiles, vtiles > kVisFusedTiles ? tile_in : nullptr, lefts);
     RT_HIP(ctx, hipGetLastError());
     // boxes: every node's record goes to its pre-order place
-    climb_local_kernel<<<chunks, kChunk, 0, s>>>(A);
+    if (paired) climb_local_kernel<true><<<chunks, kChunk, 0, s>>>(A);
+    else climb_local_kernel<false><<<chunks, kChunk, 0, s>>>(A);
     RT_HIP(ctx, hipGetLastError());
-    if (n <= kOneGroupUpper && !ctx->upper_device_wide) climb_upper_kernel<3><<<1, kOneGroupThreads, 0, s>>>(A);
-    else if (ctx->refit_fence == 1) climb_upper_kernel<1><<<ublocks, kBlock, 0, s>>>(A);
-    else if (ctx->refit_fence == 2) climb_upper_kernel<2><<<ublocks, kBlock, 0, s>>>(A);
-    else climb_upper_kernel<0><<<ublocks, kBlock, 0, s>>>(A);
+    const int mode = (n <= kOneGroupUpper && !ctx->upper_device_wide) ? 3 : (int)ctx->refit_fence;
+#define RT_UPPER(MODE, GRID, BLOCK)                                               \
+    if (paired) climb_upper_kernel<MODE, true><<<GRID, BLOCK, 0, s>>>(A);         \
+    else climb_upper_kernel<MODE, false><<<GRID, BLOCK, 0, s>>>(A)
+    if (mode == 3) { RT_UPPER(3, 1, kOneGroupThreads); }
+    else if (mode == 1) { RT_UPPER(1, ublocks, kBlock); }
+    else if (mode == 2) { RT_UPPER(2, ublocks, kBlock); }
+    else { RT_UPPER(0, ublocks, kBlock); }
+#undef RT_UPPER
     RT_HIP(ctx, hipGetLastError());
     return RTHIP_OK;
 }
@@ -1698,7 +1827,7 @@ int lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, float4* 
 namespace {
 
 constexpr size_t kStaticSlack = 1u << 20;  // block histograms, scan sums, bounds, alignment padding
-constexpr size_t kStaticBytes = kStaticBuildMaxBoxes * 120u + kStaticSlack;  // 99 bytes per box: keys, values, priorities, child slots, pre-order offsets, counters, lists
+constexpr size_t kStaticBytes = kStaticBuildMaxBoxes * 120u + kStaticSlack;  // 96 bytes per box: keys, values, priorities, child slots, one byte of shape, counters, lists
 static __device__ __align__(256) unsigned char scratch[kStaticBytes];
 
 constexpr int kMaxDevices = 64;
@@ -1739,7 +1868,7 @@ int lbvh_static_workspace_init(rthip_ctx* ctx) {
               carve(w.block_hist, base, off, hist_bytes) &&
               carve(w.prio, base, off, n + 8) && carve(w.child, base, off, 2 * n * sizeof(ChildRec)) &&
               carve(w.vis, base, off, (size_t)div_up(n, kVisTile) * (sizeof(ulonglong2) + sizeof(VisF))) && carve(w.flags, base, off, n * 4) &&
-              carve(w.starters, base, off, (n / 2 + 1) * 4) && carve(w.spine, base, off, n * 4 + 32) && carve(w.bounds, base, off, kBoundBytes);
+              carve(w.starters, base, off, (n / 2 + 1) * 4) && carve(w.lefts, base, off, n + 32) && carve(w.bounds, base, off, kBoundBytes);
     if (!ok) return rthip_fail(ctx, RTHIP_E_LIMIT, "the static workspace of %zu bytes is too small for %llu boxes", kStaticBytes, (unsigned long long)n);
     ctx->ws_static_ready = true;
     return RTHIP_OK;

@@ -177,7 +177,7 @@ void rthip_destroy(rthip_ctx* ctx) {
     for (auto& m : ctx->meshes) release_mesh(m);
     LbvhWorkspace& w = ctx->ws;
     DevBuf* all[] = {&w.aabb, &w.keys[0], &w.keys[1], &w.vals[0], &w.vals[1], &w.block_hist, &w.scan_aux, &w.prio,
-                     &w.child, &w.vis, &w.flags, &w.starters, &w.spine, &w.bounds, &ctx->blas_nodes, &ctx->tri_v, &ctx->tri_n,
+                     &w.child, &w.vis, &w.flags, &w.starters, &w.lefts, &w.bounds, &ctx->blas_nodes, &ctx->tri_v, &ctx->tri_n,
                      &ctx->blas_wide, &ctx->tlas_wide, &ctx->wide_rank, &ctx->tlas_nodes, &ctx->inst, &ctx->mats, &ctx->inst_aabb, &ctx->counters, &ctx->work_ring, &ctx->scratch_a,
                      &ctx->scratch_b, &ctx->scratch_c, &ctx->scratch_d, &ctx->scratch_e, &ctx->frame, &ctx->hdr_stage,
                      &ctx->hdr_lengths, &ctx->hdr_offsets, &ctx->hdr_out, &ctx->hdr_size, &ctx->obj.cp, &ctx->obj.cn, &ctx->obj.ct,

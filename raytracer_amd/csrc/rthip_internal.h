@@ -35,7 +35,7 @@ struct LbvhWorkspace {
     DevBuf vis;         // per tile of 2048 gaps: what the tile does to the mask of running-minimum records, and the mask behind it
     DevBuf flags;       // uint32[n-1] arrival counters (+ the starter count)
     DevBuf starters;    // gaps whose two children both arrived in the chunk-local kernel (start list of the upper kernel)
-    DevBuf spine;       // uint32[n]   S(i) of every sorted leaf: its pre-order index is i + S(i)
+    DevBuf lefts;       // uint8[n]    of every sorted leaf: how many of its ancestors hold it in their left subtree (its pre-order index is 2 i + that)
     DevBuf bounds;      // ordered-int centroid bounds, in several copies that the Morton kernel folds
 };
 
