@@ -283,8 +283,11 @@ int rthip_lbvh_build(rthip_ctx* ctx, const float* aabb6, uint64_t n, uint64_t* o
 
 /* The same build with the boxes already in HBM and the tree left in HBM: what the
  * build benchmark times.  d_nodes must hold 2n-1 records.  Enqueues on `stream`
- * and returns without synchronising, except that a build larger than any before it first grows the
- * context's workspace (see rthip_lbvh_reserve). */
+ * and returns without synchronising, with two exceptions: a build larger than any before it first grows the
+ * context's workspace (see rthip_lbvh_reserve), and a build of more than 131 072 boxes waits for the stream once, half
+ * way through its sort (it sorts by the upper half of the Morton codes, finishes locally, and reads back one word that
+ * says whether that was enough; RTHIP_SORT_TOP_BYTES=8 in the environment, or a stream that is being captured, selects
+ * the sort by all eight bytes, which only enqueues). */
 int rthip_lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, rthip_node* d_nodes, void* stream);
 
 /* Grows the builder's workspace to what builds of up to n boxes (or triangles) need.  rthip_lbvh_build_device and

@@ -74,7 +74,7 @@ __device__ __forceinline__ float wave_max(float v) {
 // small and middle sizes (12 us of it at 81 920 triangles, 75 us at 10^6).
 constexpr int kBoundSlots = 16;
 constexpr int kBoundStride = 1056;  // uint32 from slot to slot
-constexpr size_t kBoundBytes = (size_t)kBoundSlots * kBoundStride * 4;
+constexpr size_t kBoundBytes = (size_t)kBoundSlots * kBoundStride * 4 + 256;  // + a flag word of the sort (lbvh_build_device)
 
 __device__ __forceinline__ void bounds_fold(const uint32_t* __restrict__ bounds, uint32_t* sb /* LDS, 6 words */) {
     if (threadIdx.x < 6) {
@@ -663,6 +663,86 @@ __global__ __launch_bounds__(256) void tile_merge_kernel(const uint64_t* __restr
     }
 }
 
+// ---- a sort by the upper digits only, finished locally --------------------------------------------------------
+// Morton codes of a real scene differ in their upper bits: after stable passes over the upper kTopDigits bytes only,
+// the keys that share all of those bits form short stretches (random points: 23 000 pairs in 10^7 keys; a surface: half
+// a dozen keys), already in their original order.  sort_fix_kernel finishes the sort inside every stretch of up to
+// kFixLong keys by ranking (a key's place is the stretch's first place plus the number of keys of the stretch that must
+// come before it: smaller low bits, or equal ones and an earlier position), in place: a stretch belongs to the
+// workgroup whose tile holds its first key, which reads all of it before anything is written; other workgroups look
+// only at its upper bits, which no write changes.  A longer stretch that is out of order (a dense object in a scene
+// thousands of times its size) is left alone and reported in *gave_up: the host then sorts by all eight bytes.
+constexpr int kFixTile = 2048;  // positions per workgroup
+constexpr int kFixLong = 128;   // stretches up to this long are finished here; also the halo read on either side of the tile
+constexpr int kFixWin = kFixTile + 2 * kFixLong;
+constexpr int kFixPer = (kFixTile + kFixLong + 255) / 256;  // positions of tile + right halo per thread
+
+__global__ __launch_bounds__(256) void sort_fix_kernel(uint64_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t n,
+                                                       uint32_t* __restrict__ gave_up) {
+    __shared__ uint32_t top[kFixWin], low[kFixWin];
+    __shared__ uint32_t any_out_of_order;
+    const int tid = threadIdx.x;
+    const int64_t w0 = (int64_t)blockIdx.x * kFixTile - kFixLong;  // window entry k is position w0 + k
+    if (tid == 0) any_out_of_order = 0;
+    for (int k = tid; k < kFixWin; k += 256) {
+        const int64_t p = w0 + k;
+        const bool inside = p >= 0 && p < (int64_t)n;
+        const uint64_t key = inside ? keys[p] : 0ull;
+        top[k] = inside ? (uint32_t)(key >> 32) : 0xffffffffu;  // no key has bit 63: equal to no real neighbour
+        low[k] = (uint32_t)key;
+    }
+    __syncthreads();
+    {
+        bool found = false;
+        for (int k = kFixLong + tid; k < kFixWin; k += 256) found |= top[k] == top[k - 1] && low[k - 1] > low[k];
+        if (found) any_out_of_order = 1;
+    }
+    __syncthreads();
+    if (!any_out_of_order) return;
+
+    // (Building the tile's new arrangement in LDS and writing it back with consecutive lanes was slower than these
+    // scattered stores: 52 against 33 us at 10^7 random keys, 126 against 98 us on a surface, for the LDS it takes.)
+    uint32_t to[kFixPer], val[kFixPer];
+#pragma unroll
+    for (int j = 0; j < kFixPer; j++) {
+        to[j] = 0xffffffffu;
+        const int k = kFixLong + tid + 256 * j;
+        const int64_t p = w0 + k;
+        if (k >= kFixWin || p >= (int64_t)n) continue;
+        const uint32_t t = top[k], mine_low = low[k];
+        if (top[k - 1] != t && (k + 1 >= kFixWin || top[k + 1] != t)) continue;  // a stretch of one key (most are)
+        // keys of the same stretch before and behind this one, counted up to the length that makes the stretch long
+        int before = 0, behind = 0;
+        while (before <= kFixLong && k - before - 1 >= 0 && top[k - before - 1] == t) before++;
+        while (before + behind <= kFixLong && k + behind + 1 < kFixWin && top[k + behind + 1] == t) behind++;
+        // the window's edges are at least kFixLong away from every key that a stretch of this tile can hold, so a scan
+        // that ends at an edge has seen a long stretch as well
+        const bool is_long = before + behind + 1 > kFixLong || k - before - 1 < 0 || k + behind + 1 >= kFixWin;
+        const bool in_tile = k < kFixLong + kFixTile;
+        if (is_long) {
+            if (in_tile && before > 0 && low[k - 1] > mine_low) atomicOr(gave_up, 1u);
+            continue;
+        }
+        const int first = k - before;
+        if (first < kFixLong || first >= kFixLong + kFixTile) continue;  // another workgroup's stretch
+        int rank = 0;
+        for (int q = first; q <= k + behind; q++) rank += (low[q] < mine_low || (low[q] == mine_low && q < k)) ? 1 : 0;
+        if (rank != before) {
+            to[j] = (uint32_t)(w0 + first + rank);
+            val[j] = vals[p];
+        }
+    }
+    __syncthreads();  // every value that moves has been read
+#pragma unroll
+    for (int j = 0; j < kFixPer; j++) {
+        if (to[j] != 0xffffffffu) {
+            const int k = kFixLong + tid + 256 * j;
+            keys[to[j]] = ((uint64_t)top[k] << 32) | low[k];
+            vals[to[j]] = val[j];
+        }
+    }
+}
+
 // ---- device-wide prefix sums of uint32 ------------------------------------------------
 template <bool INCLUSIVE>
 __global__ __launch_bounds__(kBlock) void scan_tile_kernel(uint32_t* __restrict__ data, uint64_t n,
@@ -824,6 +904,7 @@ __device__ __forceinline__ uint8_t gap_priority_of(const uint64_t* keys, uint64_
 // it at every level of a latency-bound chain (+8 % at 10^7 triangles).  MODE 1 (RTHIP_REFIT_FENCE=1, diagnostic):
 // plain accesses bracketed by __threadfence().
 constexpr int kChunk = 512;  // sorted leaves per workgroup, one per thread
+constexpr uint64_t kTopSortMin = 1ull << 17;  // builds of more boxes sort by the upper bytes first (lbvh_build_device)
 
 // ---- the records of a running minimum, as a scan ------------------------------------------------------------------
 // f(M) = (M & bits below t) | B: what a stretch of gaps does to the mask of the records seen from behind its right end.
@@ -1608,7 +1689,7 @@ size_t scan_tmp_elems(uint64_t n) {
 }  // namespace
 
 int radix_sort_workspace_device(rthip_ctx* ctx, uint64_t n, int n_bytes, hipStream_t s, int* cur_io, LbvhWorkspace* ws,
-                                bool identity_vals) {
+                                bool identity_vals, int first_byte) {
     LbvhWorkspace& w = ws ? *ws : ctx->ws;
     // Sizes just above the merge path sort in tiles of 1024 keys, which spreads a pass over more CUs.  Measured (whole
     // build, 1024- against 4096-key tiles): 200 000 keys 0.224 / 0.241 ms, 500 000 0.274 / 0.276, 10^6 0.369 / 0.334,
@@ -1620,7 +1701,7 @@ int radix_sort_workspace_device(rthip_ctx* ctx, uint64_t n, int n_bytes, hipStre
     uint32_t* vals[2] = {(uint32_t*)w.vals[0].p, (uint32_t*)w.vals[1].p};
     int cur = *cur_io;
     const uint32_t small_tiles = div_up(n, kSmallTile);
-    if (small_tiles <= kMergeTiles && !ctx->sort_by_passes) {
+    if (small_tiles <= kMergeTiles && !ctx->sort_by_passes && first_byte == 0) {
         tile_sort_kernel<<<small_tiles, kSmallSortBlock, 0, s>>>(keys[cur], identity_vals ? nullptr : vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, n_bytes);
         RT_HIP(ctx, hipGetLastError());
         cur ^= 1;
@@ -1637,10 +1718,10 @@ int radix_sort_workspace_device(rthip_ctx* ctx, uint64_t n, int n_bytes, hipStre
     // per-tile status words instead of the histogram and offsets kernels) was built and measured at 10^7 keys: 94 us
     // per pass against 61 + 18 + 6 here -- with ~600 tiles in flight a tile's predecessors have published their own
     // counts but not yet their inclusive ones, so every look-back walks far, one device-scope load latency per step.
-    for (int pass = 0; pass < n_bytes; pass++) {
+    for (int pass = first_byte; pass < n_bytes; pass++) {
         const int shift = pass * 8;
         uint32_t* hist = (uint32_t*)w.block_hist.p;
-        const uint32_t* v_in = (pass == 0 && identity_vals) ? nullptr : vals[cur];
+        const uint32_t* v_in = (pass == first_byte && identity_vals) ? nullptr : vals[cur];
         if (small_tile) radix_hist_kernel<kSmallSortBlock><<<tiles, kSmallSortBlock, 0, s>>>(keys[cur], n, shift, hist, tiles);
         else radix_hist_kernel<kSortBlock><<<tiles, kSortBlock, 0, s>>>(keys[cur], n, shift, hist, tiles);
         RT_HIP(ctx, hipGetLastError());
@@ -1784,8 +1865,34 @@ int lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, float4* 
     if (d_codes_unsorted)
         RT_HIP(ctx, hipMemcpyAsync(d_codes_unsorted, keys[0], n * 8, hipMemcpyDeviceToDevice, s));
 
+    // Above kTopSortMin keys: passes over the upper four bytes, the rest finished inside the short stretches of keys that
+    // share them (sort_fix_kernel).  Whether that was enough is one word read back from the device, so the call waits for
+    // the stream at this point (not while the stream is being captured: then all eight passes run); if a long stretch
+    // was out of order the codes are made again and sorted by all eight bytes, and builds of this many boxes skip the
+    // attempt from then on.
     int cur = 0;
-    RT_TRY(radix_sort_workspace_device(ctx, n, 8, s, &cur, &w, true));
+    bool sorted = false;
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    if (s) (void)hipStreamIsCapturing(s, &capturing);
+    if (n > kTopSortMin && ctx->sort_top_bytes < 8 && ctx->sort_top_gave_up_n != n && capturing == hipStreamCaptureStatusNone) {
+        uint32_t* gave_up = (uint32_t*)w.bounds.p + kBoundSlots * kBoundStride;  // a word behind the bounds' copies
+        RT_HIP(ctx, hipMemsetAsync(gave_up, 0, 4, s));
+        RT_TRY(radix_sort_workspace_device(ctx, n, 8, s, &cur, &w, true, 8 - ctx->sort_top_bytes));
+        sort_fix_kernel<<<div_up(n, kFixTile), 256, 0, s>>>(keys[cur], vals[cur], (uint32_t)n, gave_up);
+        RT_HIP(ctx, hipGetLastError());
+        uint32_t h_gave_up = 0;
+        RT_HIP(ctx, hipMemcpyAsync(&h_gave_up, gave_up, 4, hipMemcpyDeviceToHost, s));
+        RT_HIP(ctx, hipStreamSynchronize(s));
+        sorted = h_gave_up == 0;
+        if (!sorted) {
+            ctx->sort_top_gave_up_n = n;
+            if (getenv("RTHIP_TUNE_LOG")) fprintf(stderr, "rthip sort: a long stretch of keys with equal upper bytes was out of order: all eight passes\n");
+            morton_kernel<<<div_up(n, kBlock) < 4096u ? div_up(n, kBlock) : 4096u, kBlock, 0, s>>>(d_aabb6, n, bounds, keys[0], nullptr, (uint32_t*)w.flags.p);
+            RT_HIP(ctx, hipGetLastError());
+            cur = 0;
+        }
+    }
+    if (!sorted) RT_TRY(radix_sort_workspace_device(ctx, n, 8, s, &cur, &w, true));
     if (d_keys_sorted) RT_HIP(ctx, hipMemcpyAsync(d_keys_sorted, keys[cur], n * 8, hipMemcpyDeviceToDevice, s));
     if (d_ids_sorted) RT_HIP(ctx, hipMemcpyAsync(d_ids_sorted, vals[cur], n * 4, hipMemcpyDeviceToDevice, s));
 

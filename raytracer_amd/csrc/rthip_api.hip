@@ -136,6 +136,8 @@ int rthip_create(rthip_ctx** out_ctx, int device_id) {
     ctx->refit_fence = (fence && fence[0] >= '0' && fence[0] <= '2') ? fence[0] - '0' : 2;
     const char* by_passes = getenv("RTHIP_SORT_BY_PASSES");
     ctx->sort_by_passes = (by_passes && by_passes[0] == '1') ? 1 : 0;
+    const char* top_bytes = getenv("RTHIP_SORT_TOP_BYTES");
+    if (top_bytes && (top_bytes[0] == '4' || top_bytes[0] == '8')) ctx->sort_top_bytes = top_bytes[0] - '0';
     const char* small_tile = getenv("RTHIP_SORT_SMALL_TILE_MAX");
     if (small_tile && small_tile[0]) ctx->sort_small_tile_max = strtoull(small_tile, nullptr, 10);
     const char* wide = getenv("RTHIP_UPPER_DEVICE_WIDE");

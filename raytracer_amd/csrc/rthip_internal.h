@@ -127,6 +127,8 @@ struct rthip_ctx {
     uint32_t max_bounces = 8;
     int sky = 1;
     int counting = 0;
+    int sort_top_bytes = 4;     // large LBVH builds sort by this many upper key bytes and finish locally; 8: all passes (RTHIP_SORT_TOP_BYTES)
+    uint64_t sort_top_gave_up_n = 0;  // a build of this many boxes needed all eight passes after all: not tried again
     int sort_by_passes = 0;     // RTHIP_SORT_BY_PASSES=1: small sorts also go pass by pass through HBM (diagnostic)
     uint64_t sort_small_tile_max = 1ull << 18;  // sorts of up to this many keys use 1024-key tiles (RTHIP_SORT_SMALL_TILE_MAX)
     int upper_device_wide = 0;  // RTHIP_UPPER_DEVICE_WIDE=1: never run the upper climbs in one workgroup (diagnostic)
@@ -246,8 +248,9 @@ int lbvh_static_workspace_init(rthip_ctx* ctx);
 // Stable LSD radix sort of the n (uint64 key, uint32 value) pairs in ws.keys[*cur] / ws.vals[*cur] (the caller has
 // reserved both ping-pong pairs) by the key's low n_bytes bytes; *cur names the pair that holds the result.
 // identity_vals: the values are the positions 0 .. n-1 and need not be stored before the call (vals[*cur] is not read).
+// first_byte > 0: only the passes over bytes first_byte .. n_bytes-1 (a stable sort by those bytes alone).
 int radix_sort_workspace_device(rthip_ctx* ctx, uint64_t n, int n_bytes, hipStream_t stream, int* cur, LbvhWorkspace* ws = nullptr,
-                                bool identity_vals = false);
+                                bool identity_vals = false, int first_byte = 0);
 // In-place inclusive prefix sum of n uint32.
 int scan_inclusive_u32_device(rthip_ctx* ctx, uint32_t* d, uint64_t n, hipStream_t stream);
 

@@ -173,6 +173,96 @@ def test_lbvh_sizes_at_the_seams_of_the_builder(oracle, n):
                 os.environ[k] = v
 
 
+@pytest.mark.parametrize("case", ["uniform", "clusters", "dense_cloud", "identical", "stretch_128", "stretch_129"])
+def test_lbvh_sort_by_upper_bytes(oracle, capfd, case):
+    """Builds of more than 131 072 boxes sort by the upper four key bytes and finish the sort inside the stretches of keys
+    that share them (up to 128 keys); a longer stretch that is out of order makes the build sort by all eight bytes
+    after all (it says so with RTHIP_TUNE_LOG).  Every case against the oracle: uniform boxes (stretches are rare
+    pairs), clusters of 60 boxes within 1e-5 (every stretch needs work, many straddle the finishing kernel's tiles), a
+    cloud of 300 000 boxes inside 1e-4 of the scene (one long stretch, out of order: all eight passes), 300 000
+    identical boxes (one long stretch, in order: nothing to do), and stretches of exactly 128 and 129 keys in
+    descending order."""
+    n = 300_000
+    rng = np.random.default_rng(11)
+    cen = rng.random((n, 3)).astype(np.float32)
+    falls_back = False
+    if case == "clusters":
+        centres = rng.random((5000, 3)).astype(np.float32)
+        cen = centres[rng.integers(0, 5000, n)] + (rng.random((n, 3)).astype(np.float32) - 0.5) * 1e-5
+    elif case == "dense_cloud":
+        cen = 0.5 + (rng.random((n, 3)).astype(np.float32) - 0.5) * 1e-4
+        falls_back = True
+    elif case == "identical":
+        cen[:] = 0.375
+    elif case in ("stretch_128", "stretch_129"):
+        # y = z = 0.25: a key's upper 31 bits hold the upper 10 bits of x, so the keys of one 2^-10 wide cell of x form a
+        # stretch; the cells' keys are handed over with descending x, i.e. every stretch is in reverse order
+        length = 128 if case == "stretch_128" else 129
+        cells = 700
+        j = np.arange(length, dtype=np.float64)[::-1]
+        xs = (np.arange(cells, dtype=np.float64)[:, None] + 17) / 1024.0 + (j[None, :] + 1) * 2.0 ** -20
+        m = cells * length
+        cen[:m, 0] = xs.reshape(-1).astype(np.float32)
+        cen[:m, 1:] = 0.25
+        cen[m:, 0] = 0.9 + 0.1 * cen[m:, 0]  # the rest lies beyond the cells
+        falls_back = case == "stretch_129"
+    cen[-2], cen[-1] = (0.0, 0.0, 0.0), (1.0, 1.0, 1.0)  # fix the bounds
+    half = np.full((n, 3), 1e-6, dtype=np.float32)
+    boxes = np.concatenate([cen - half, cen + half], axis=1).astype(np.float32)
+    want = oracle.lbvh_build(boxes)[3]
+    saved = os.environ.get("RTHIP_TUNE_LOG")
+    os.environ["RTHIP_TUNE_LOG"] = "1"
+    t = T.rt_make_tracer(T.RT_TracerSettings(max_bounces=1, sky=True), device_id=0)
+    try:
+        capfd.readouterr()
+        assert_same_tree(T.lbvh_build(t, boxes)[3], want, case)
+        said = "all eight passes" in capfd.readouterr().err
+        assert said == falls_back, f"{case}: fell back {said}, expected {falls_back}"
+        assert_same_tree(T.lbvh_build(t, boxes)[3], want, case + ", second build")  # after a fallback: no second attempt
+        assert "all eight passes" not in capfd.readouterr().err
+    finally:
+        T.rt_tracer_cleanup(t)
+        if saved is None:
+            os.environ.pop("RTHIP_TUNE_LOG", None)
+        else:
+            os.environ["RTHIP_TUNE_LOG"] = saved
+
+
+def test_large_build_can_be_captured_in_a_hip_graph(gpu_tracer):
+    """A build of more than 131 072 boxes reads one word back from the device half way through its sort, which a stream
+    capture does not allow: on a stream that is being captured it sorts by all eight key bytes instead and only
+    enqueues.  The captured build, replayed on other boxes, gives the tree of the build outside the capture."""
+    import torch
+
+    lib, h = gpu_tracer.lib, gpu_tracer.h
+    n = 200_000
+    gpu_tracer.check(lib.rthip_lbvh_reserve(h, n), "rthip_lbvh_reserve")
+
+    def boxes(seed):
+        g = torch.Generator(device="cuda")
+        g.manual_seed(seed)
+        cen = torch.rand((n, 3), device="cuda", generator=g)
+        cen[: n // 2] = torch.floor(cen[: n // 2] * 300) / 300  # stretches of keys with equal upper bytes, equal keys among them
+        return torch.cat([cen - 0.001, cen + 0.001], dim=1).contiguous()
+
+    buf = boxes(1)
+    nodes = torch.zeros((2 * n - 1, 8), dtype=torch.int32, device="cuda")
+    s = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    torch.cuda.synchronize()
+    with torch.cuda.graph(graph, stream=s):
+        gpu_tracer.check(lib.rthip_lbvh_build_device(h, buf.data_ptr(), n, nodes.data_ptr(), s.cuda_stream), "build (capture)")
+    for seed in (1, 2):
+        buf.copy_(boxes(seed))
+        nodes.fill_(-1)
+        graph.replay()
+        torch.cuda.synchronize()
+        ref = torch.zeros((2 * n - 1, 8), dtype=torch.int32, device="cuda")
+        gpu_tracer.check(lib.rthip_lbvh_build_device(h, buf.data_ptr(), n, ref.data_ptr(), torch.cuda.current_stream().cuda_stream), "build")
+        torch.cuda.synchronize()
+        assert torch.equal(nodes, ref), f"replay with seed {seed}"
+
+
 def test_lbvh_tile_merge_with_lopsided_tiles(oracle, gpu_tracer):
     """The merge of the tile-sorted keys copies, for 64 neighbouring keys of one tile, the stretch of every other tile
     that lies between them; a stretch of 128 keys or more is searched in global memory instead.  Here the tiles of 1024
