@@ -1624,37 +1624,94 @@ __global__ __launch_bounds__(kBlock) void instance_aabb_kernel(const DevInstance
 }
 
 // ---- records of the ordered (fast) traversal -------------------------------------------------------------------
-// From the finished pre-order tree (the walk's record form): inner node i has its left child in record i + 1 and its
-// right child in record skip(i + 1).  Inner nodes are numbered in pre-order among themselves (rank = exclusive count
-// of inner records before i), so the root is record 0 and a left inner child is the next record.  One record = 4
-// float4: {min.x, max.x, min.y, max.y} {min.z, max.z, ref, 0} of the left child, then the same of the right child;
-// ref = rank of an inner child, or 0x80000000 | id for a leaf child.
-__global__ __launch_bounds__(kBlock) void wide_flags_kernel(const float4* __restrict__ nodes, uint32_t n_nodes,
-                                                            uint32_t* __restrict__ flags) {
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i < n_nodes) flags[i] = __float_as_uint(nodes[2 * (uint64_t)i + 1].w) == 0u ? 1u : 0u;
-}
-
-__global__ __launch_bounds__(kBlock) void wide_emit_kernel(const float4* __restrict__ nodes, uint32_t n_nodes,
-                                                           const uint32_t* __restrict__ rank, const uint32_t* __restrict__ tile_sums,
-                                                           float4* __restrict__ wide) {
+// The ordered walk reads a 4-wide tree collapsed from the finished pre-order binary tree (the walk's record form):
+// an inner node at EVEN depth becomes a record that holds the boxes of its grandchildren (of a child that is a leaf,
+// the child itself), 2 to 4 slots in pre-order; inner nodes at odd depth have no record.  Every box is a box of the
+// binary tree, bit for bit, and a grandchild's box lies inside its parent's, so the walk reaches exactly the primitives
+// the binary tree would lead it to.  Records are numbered in pre-order among themselves (root = 0).
+//
+// One record = 8 float4 = one 128-byte line: slot k's {min.x, max.x, min.y, max.y} in [k], the z bounds
+// {min.z0, max.z0, min.z1, max.z1} {min.z2, max.z2, min.z3, max.z3} in [4] [5], the references in [6] (record index,
+// 0x80000000 | id for a primitive, 0xffffffff for an empty slot, whose box is a point at +infinity), and in [7] each
+// slot's node index in the binary tree (read only by a walk that has run out of stack and goes through a slot's
+// subtree in the binary tree's own order).
+//
+// Depth without a top-down pass: in pre-order, depth(i) = (inner nodes before i) - (inner nodes whose subtree has
+// ended before or at i), so every inner node j adds 1 at j + 1 and takes 1 away at skip(j), and a prefix sum gives the depths.
+__global__ __launch_bounds__(kBlock) void wide_depth_marks_kernel(const float4* __restrict__ nodes, uint32_t n_nodes,
+                                                                  uint32_t* __restrict__ marks) {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n_nodes) return;
     const float4 mine = nodes[2 * (uint64_t)i + 1];
-    if (__float_as_uint(mine.w) != 0u) return;  // a leaf has no record of its own
-    auto rank_of = [&](uint32_t k) { return rank[k] + (tile_sums ? tile_sums[k / (uint32_t)kScanTile] : 0u); };
-    const uint32_t L = i + 1;
-    const float4 la = nodes[2 * (uint64_t)L], lb = nodes[2 * (uint64_t)L + 1];
-    const uint32_t R = __float_as_uint(lb.z);
-    const float4 ra = nodes[2 * (uint64_t)R], rb = nodes[2 * (uint64_t)R + 1];
-    const uint32_t lid = __float_as_uint(lb.w), rid = __float_as_uint(rb.w);
-    const uint32_t refl = lid ? (0x80000000u | lid) : rank_of(L);
-    const uint32_t refr = rid ? (0x80000000u | rid) : rank_of(R);
-    float4* out = wide + 4 * (uint64_t)rank_of(i);
-    out[0] = la;
-    out[1] = make_float4(lb.x, lb.y, __uint_as_float(refl), 0.f);
-    out[2] = ra;
-    out[3] = make_float4(rb.x, rb.y, __uint_as_float(refr), 0.f);
+    if (__float_as_uint(mine.w) != 0u) return;
+    atomicAdd(&marks[i + 1], 1u);
+    atomicSub(&marks[__float_as_uint(mine.z)], 1u);  // skip(i) <= n_nodes: marks has n_nodes + 1 words
+}
+
+// depth -> "has a record" (inner and at even depth), in place; the word behind the last node stays 0
+__global__ __launch_bounds__(kBlock) void wide_flags_kernel(const float4* __restrict__ nodes, uint32_t n_nodes,
+                                                            uint32_t* __restrict__ depth_to_flag) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i > n_nodes) return;
+    uint32_t f = 0u;
+    if (i < n_nodes) f = (__float_as_uint(nodes[2 * (uint64_t)i + 1].w) == 0u && (depth_to_flag[i] & 1u) == 0u) ? 1u : 0u;
+    depth_to_flag[i] = f;
+}
+
+__global__ __launch_bounds__(kBlock) void wide_emit_kernel(const float4* __restrict__ nodes, uint32_t n_nodes,
+                                                           const uint32_t* __restrict__ rank, float4* __restrict__ wide) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n_nodes) return;
+    const uint32_t my_rank = rank[i];
+    if (rank[i + 1] == my_rank) return;  // no record: a leaf, or an inner node at odd depth
+    const float inf = __uint_as_float(0x7f800000u);
+    float4 xy[4], zz[2];
+    uint32_t ref[4], bin[4];
+    for (int k = 0; k < 4; k++) {
+        xy[k] = make_float4(inf, inf, inf, inf);
+        ref[k] = 0xffffffffu;
+        bin[k] = 0u;
+    }
+    zz[0] = zz[1] = make_float4(inf, inf, inf, inf);
+    int slots = 0;
+    auto put = [&](const float4 a, const float4 b, uint32_t node) {
+        const uint32_t id = __float_as_uint(b.w);
+        xy[slots] = a;
+        if (slots & 1) {
+            zz[slots >> 1].z = b.x;
+            zz[slots >> 1].w = b.y;
+        } else {
+            zz[slots >> 1].x = b.x;
+            zz[slots >> 1].y = b.y;
+        }
+        ref[slots] = id ? (0x80000000u | id) : rank[node];
+        bin[slots] = node;
+        slots++;
+    };
+    uint32_t child = i + 1;
+    for (int c = 0; c < 2; c++) {
+        const float4 ca = nodes[2 * (uint64_t)child], cb = nodes[2 * (uint64_t)child + 1];
+        if (__float_as_uint(cb.w) != 0u) {
+            put(ca, cb, child);
+        } else {
+            const uint32_t gl = child + 1;
+            const float4 la = nodes[2 * (uint64_t)gl], lb = nodes[2 * (uint64_t)gl + 1];
+            const uint32_t gr = __float_as_uint(lb.z);
+            const float4 ra = nodes[2 * (uint64_t)gr], rb = nodes[2 * (uint64_t)gr + 1];
+            put(la, lb, gl);
+            put(ra, rb, gr);
+        }
+        child = __float_as_uint(cb.z);  // the right child starts where the left child's subtree ends
+    }
+    float4* out = wide + 8 * (uint64_t)my_rank;
+    out[0] = xy[0];
+    out[1] = xy[1];
+    out[2] = xy[2];
+    out[3] = xy[3];
+    out[4] = zz[0];
+    out[5] = zz[1];
+    out[6] = make_float4(__uint_as_float(ref[0]), __uint_as_float(ref[1]), __uint_as_float(ref[2]), __uint_as_float(ref[3]));
+    out[7] = make_float4(__uint_as_float(bin[0]), __uint_as_float(bin[1]), __uint_as_float(bin[2]), __uint_as_float(bin[3]));
 }
 
 inline uint32_t div_up(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
@@ -1738,15 +1795,19 @@ int radix_sort_workspace_device(rthip_ctx* ctx, uint64_t n, int n_bytes, hipStre
 }
 
 int wide_convert_device(rthip_ctx* ctx, const float4* d_nodes, uint32_t n_nodes, float4* d_wide, hipStream_t s) {
-    if (n_nodes < 3) return RTHIP_OK;  // a single leaf has no inner record
-    RT_TRY(rthip_reserve(ctx, ctx->wide_rank, (size_t)n_nodes * 4));
-    RT_TRY(rthip_reserve(ctx, ctx->ws.scan_aux, scan_tmp_elems(n_nodes) * 4));
+    if (n_nodes < 3) return RTHIP_OK;  // a single leaf has no record
+    RT_TRY(rthip_reserve(ctx, ctx->wide_rank, ((size_t)n_nodes + 1) * 4));
+    RT_TRY(rthip_reserve(ctx, ctx->ws.scan_aux, scan_tmp_elems((uint64_t)n_nodes + 1) * 4));
     uint32_t* rank = (uint32_t*)ctx->wide_rank.p;
-    const uint32_t blocks = div_up(n_nodes, kBlock);
+    const uint32_t blocks = div_up((uint64_t)n_nodes + 1, kBlock);
+    RT_HIP(ctx, hipMemsetAsync(rank, 0, ((size_t)n_nodes + 1) * 4, s));
+    wide_depth_marks_kernel<<<blocks, kBlock, 0, s>>>(d_nodes, n_nodes, rank);
+    RT_HIP(ctx, hipGetLastError());
+    RT_TRY((scan_u32<true>(ctx, rank, (uint64_t)n_nodes + 1, (uint32_t*)ctx->ws.scan_aux.p, s)));
     wide_flags_kernel<<<blocks, kBlock, 0, s>>>(d_nodes, n_nodes, rank);
     RT_HIP(ctx, hipGetLastError());
-    RT_TRY((scan_u32<false>(ctx, rank, n_nodes, (uint32_t*)ctx->ws.scan_aux.p, s)));
-    wide_emit_kernel<<<blocks, kBlock, 0, s>>>(d_nodes, n_nodes, rank, nullptr, d_wide);
+    RT_TRY((scan_u32<false>(ctx, rank, (uint64_t)n_nodes + 1, (uint32_t*)ctx->ws.scan_aux.p, s)));
+    wide_emit_kernel<<<blocks, kBlock, 0, s>>>(d_nodes, n_nodes, rank, d_wide);
     RT_HIP(ctx, hipGetLastError());
     return RTHIP_OK;
 }

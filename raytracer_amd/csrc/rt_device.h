@@ -325,24 +325,34 @@ __device__ __forceinline__ bool any_hit_query(const DevScene& S, V3 wo, V3 wd, f
 // The reference's query visits the two children of a node always left first (lbvh.c:157-158), whatever the ray, so a
 // ray that hits something close by still walks every subtree whose box it pierces in front of AND behind the hit until
 // the interval has shrunk.  The opt-in fast mode walks the same tree with the same box, triangle and sphere tests, but
-// (1) from records that hold BOTH children's boxes (64 bytes, one aligned fetch per inner node; leaves have no record
-// of their own, a child reference is either an inner record or a primitive id), (2) nearer child first, the farther one
-// pushed on a per-lane stack in LDS, so that a close hit shrinks the interval before the far subtrees are looked at.
+// (1) from 4-wide records collapsed from the binary tree (wide_emit_kernel, lbvh_build.hip: one 128-byte line holds
+// the boxes of a node's grandchildren, so a step is one aligned fetch and the chain of dependent fetches of a ray is
+// half as long; leaves have no record of their own, a reference is either a record or a primitive id), (2) nearest
+// box first, the others pushed on a per-lane stack in LDS together with the distance at which the ray enters them, so
+// that a close hit shrinks the interval before the far subtrees are looked at and a subtree that has fallen behind the
+// hit by the time it is popped costs one comparison instead of a fetch.
 // Same acceptance rule for every primitive (min <= t <= max, ties accepted), so the result is the closest hit too; it
 // can differ from the reference's only where the reference's own answer depends on its visiting order: among hits at
 // exactly equal t the last visited wins, and a primitive whose box test (no slack) fails against the already shrunk
 // interval is never tested although its triangle test (with slack) would have accepted it.
-constexpr uint32_t kLeafBit = 0x80000000u;  // child reference: kLeafBit | 1-based primitive id, else index of an inner record
-constexpr uint32_t kPop = 0xffffffffu;      // "take the next reference from the stack"
-// Stack entries per lane, in LDS (entry e of a lane at lds[e * kBlock]: no bank conflicts).  The stack holds the far
-// siblings along the current path, so it is as deep as the tree at most; 24 covers the trees of scenes up to tens of
-// millions of primitives.  A ray that would need more (a degenerate tree: thousands of primitives at one point) sets
-// `overflow` and is answered by the stackless fixed-order walk instead, which needs no stack at all.
-constexpr int kFastLds = 24;
+constexpr uint32_t kLeafBit = 0x80000000u;  // reference: kLeafBit | 1-based primitive id, else index of a record
+constexpr uint32_t kPop = 0xffffffffu;      // "take the next reference from the stack"; also the reference of an empty slot
+// Stack entries per lane, in LDS (entry e of a lane at lds[e * kBlock]: 8 bytes, no bank conflicts).  The stack holds
+// the boxes hit but not yet entered along the current path: up to three per level of the 4-wide tree, in practice one
+// or two for a few levels, and LDS per workgroup decides how many waves a CU holds (measured: 16 entries against 24
+// is +60 % on frames through 10 000 instances; 12 entries lose 7 % on rays through that TLAS).  When the boxes of a step do not fit, the farthest ones are gone
+// through at once in the binary tree's stackless order (inside a mesh; see trav_fast_step), so a short stack costs
+// some ordering, not the answer.  Only a ray that runs out of stack among the TLAS's own boxes sets `overflow` and
+// is answered by the stackless fixed-order walk instead, which needs no stack at all.
+#ifndef RT_FAST_STACK
+#define RT_FAST_STACK 16
+#endif
+constexpr int kFastLds = RT_FAST_STACK;
 
 struct FastStack {
-    uint32_t* lds;  // this lane's column
+    uint2* lds;  // this lane's column: (key, reference) per entry
 };
+__device__ __forceinline__ uint2* fast_stack_column(uint32_t* workgroup_base) { return (uint2*)workgroup_base + threadIdx.x; }
 
 // The slab test of `slab` that also reports where the ray enters the box (the lower end of the clipped interval).
 __device__ __forceinline__ bool slab_near(float4 xy, float zlo, float zhi, V3 o, V3 inv, float tmax, float& tnear) {
@@ -354,6 +364,22 @@ __device__ __forceinline__ bool slab_near(float4 xy, float zlo, float zhi, V3 o,
     return !(tmax < tmin);
 }
 
+// Sort key of a box the ray hits: the entry distance (>= EPSILON_F32 > 0, so its bits order like the number) with its
+// two lowest bits replaced by the slot, so that boxes entered at (nearly) the same distance go left first like the
+// reference and a key tells which slot it came from.  `key & ~3` as a float is <= the true entry distance: a subtree
+// is dropped at pop time only if even that lies behind the interval's end -- exactly when its box test would fail.
+__device__ __forceinline__ uint32_t fast_key(bool hit, float tnear, uint32_t slot) {
+    return hit ? ((__float_as_uint(tnear) & ~3u) | slot) : 0xffffffffu;
+}
+__device__ __forceinline__ void fast_order(uint32_t& ka, uint32_t& ra, uint32_t& kb, uint32_t& rb) {
+    const bool swap = kb < ka;
+    const uint32_t k0 = swap ? kb : ka, k1 = swap ? ka : kb, r0 = swap ? rb : ra, r1 = swap ? ra : rb;
+    ka = k0;
+    kb = k1;
+    ra = r0;
+    rb = r1;
+}
+
 struct TravFast {
     V3 wo, wd, winv;  // world-space ray and 1/d
     V3 o, d, inv;     // ray of the level being walked
@@ -363,7 +389,7 @@ struct TravFast {
     uint32_t cur_inst;  // TLAS id of the instance being walked (0: in the TLAS)
     uint32_t tri_base;
     uint32_t overflow;  // the stack was too short for this ray: T.h is not valid, ask the stackless walk
-    const float4* nodes;  // the records being walked: 4 x float4 per inner node
+    const float4* nodes;  // the records being walked: 8 x float4 each
     Hit h;
 };
 
@@ -389,12 +415,21 @@ __device__ __forceinline__ void trav_fast_begin(TravFast& T, const DevScene& S, 
     T.h.t = kMaxF;
 }
 
-// One step.  Returns true when the query has ended (T.h is final).  ANY: stop at the first accepted primitive.
+// One step.  Returns true when the query has ended (T.h is final).
 template <bool COUNT>
 __device__ __forceinline__ bool trav_fast_step(TravFast& T, const DevScene& S, Counters& cnt, FastStack& st) {
     uint32_t cur = T.cur;
     if (cur == kPop) {
-        if (T.sp == T.base) {
+        // the nearest waiting box that still reaches into the interval; the ones behind its end are dropped unseen
+        while (T.sp != T.base) {
+            T.sp--;
+            const uint2 e = st.lds[T.sp * kBlock];
+            if (!(__uint_as_float(e.x & ~3u) > T.tmax)) {
+                cur = e.y;
+                break;
+            }
+        }
+        if (cur == kPop) {
             if (T.cur_inst == 0) {
                 T.h.t = T.tmax;
                 return true;
@@ -408,8 +443,6 @@ __device__ __forceinline__ bool trav_fast_step(TravFast& T, const DevScene& S, C
             T.base = 0;
             return false;
         }
-        T.sp--;
-        cur = st.lds[T.sp * kBlock];
     }
     if (cur & kLeafBit) {
         const uint32_t id = cur & ~kLeafBit;
@@ -449,39 +482,90 @@ __device__ __forceinline__ bool trav_fast_step(TravFast& T, const DevScene& S, C
         T.inv = mk(1.f / T.d.x, 1.f / T.d.y, 1.f / T.d.z);
         T.cur_inst = id;
         T.tri_base = it->tri_base;
-        T.nodes = S.blas_wide + 4 * (size_t)it->wide_base;
+        T.nodes = S.blas_wide + 8 * (size_t)it->wide_base;
         T.base = T.sp;
-        T.cur = it->n_nodes == 1 ? (kLeafBit | 1u) : 0u;  // a one-triangle mesh has no inner record
+        T.cur = it->n_nodes == 1 ? (kLeafBit | 1u) : 0u;  // a one-triangle mesh has no record
         return false;
     }
-    const float4* rec = T.nodes + 4 * (size_t)cur;
-    const float4 l0 = rec[0], l1 = rec[1], r0 = rec[2], r1 = rec[3];
-    if (COUNT) cnt.nodes += 2;
-    float tl, tr_;
-    const bool hl = slab_near(l0, l1.x, l1.y, T.o, T.inv, T.tmax, tl);
-    const bool hr = slab_near(r0, r1.x, r1.y, T.o, T.inv, T.tmax, tr_);
-    const uint32_t refl = __float_as_uint(l1.z), refr = __float_as_uint(r1.z);
-    if (hl && hr) {
-        const bool right_first = tr_ < tl;  // equal entry distances: left first, like the reference
-        if (T.sp >= (uint32_t)kFastLds) {  // no room: give up on this walk (the caller falls back, see kFastLds)
-            T.overflow = 1;
-            T.h.t = T.tmax;
-            return true;
+    const float4* rec = T.nodes + 8 * (size_t)cur;
+    const float4 b0 = rec[0], b1 = rec[1], b2 = rec[2], b3 = rec[3], z01 = rec[4], z23 = rec[5];
+    const float4 refs = rec[6];
+    uint32_t r0 = __float_as_uint(refs.x), r1 = __float_as_uint(refs.y), r2 = __float_as_uint(refs.z), r3 = __float_as_uint(refs.w);
+    float t0, t1, t2, t3;
+    const bool h0 = slab_near(b0, z01.x, z01.y, T.o, T.inv, T.tmax, t0);
+    const bool h1 = slab_near(b1, z01.z, z01.w, T.o, T.inv, T.tmax, t1);
+    const bool h2 = slab_near(b2, z23.x, z23.y, T.o, T.inv, T.tmax, t2) && r2 != kPop;
+    const bool h3 = slab_near(b3, z23.z, z23.w, T.o, T.inv, T.tmax, t3) && r3 != kPop;
+    if (COUNT) cnt.nodes += 2u + (r2 != kPop ? 1u : 0u) + (r3 != kPop ? 1u : 0u);
+    uint32_t k0 = fast_key(h0, t0, 0u), k1 = fast_key(h1, t1, 1u), k2 = fast_key(h2, t2, 2u), k3 = fast_key(h3, t3, 3u);
+    // sorting network of four: (0,1) (2,3) (0,2) (1,3) (1,2); boxes that were missed carry the largest key and end up last
+    fast_order(k0, r0, k1, r1);
+    fast_order(k2, r2, k3, r3);
+    fast_order(k0, r0, k2, r2);
+    fast_order(k1, r1, k3, r3);
+    fast_order(k1, r1, k2, r2);
+    uint32_t hits = (h0 ? 1u : 0u) + (h1 ? 1u : 0u) + (h2 ? 1u : 0u) + (h3 ? 1u : 0u);
+    if (hits > 1u) {
+        if (T.sp + hits - 1u > (uint32_t)kFastLds) {
+            // No room for all of them.  Inside a mesh the farthest boxes that do not fit are gone through here and now,
+            // in the binary tree's own stackless order (trav_step's walk over that slot's subtree): the same tests, only
+            // not nearest first.  At the TLAS level the walk gives up and the caller asks the stackless walk.
+            if (T.cur_inst == 0) {
+                T.overflow = 1;
+                T.h.t = T.tmax;
+                return true;
+            }
+            const float4 bins = rec[7];
+            const float4* bn = S.blas + 2 * (size_t)S.inst[T.cur_inst - 1].node_base;
+            while (hits > 1u && T.sp + hits - 1u > (uint32_t)kFastLds) {
+                const uint32_t key = hits > 3u ? k3 : (hits > 2u ? k2 : k1);  // the farthest one left; its low bits name the slot
+                const uint32_t slot = key & 3u;
+                uint32_t idx = __float_as_uint(slot == 0u ? bins.x : (slot == 1u ? bins.y : (slot == 2u ? bins.z : bins.w)));
+                uint32_t end = 0xffffffffu;
+                while (idx < end) {
+                    const float4 ra = bn[2 * (size_t)idx], rb = bn[2 * (size_t)idx + 1];
+                    uint32_t skip = __float_as_uint(rb.z);
+                    const uint32_t id = __float_as_uint(rb.w);
+                    if (skip <= idx) skip = idx + 1u;  // never on a well-formed tree; bounds the walk on a corrupt one
+                    if (end == 0xffffffffu) end = skip;  // the first node is the slot's: its subtree ends at its skip
+                    if (COUNT) cnt.nodes++;
+                    if (!slab(make_float4(ra.x, ra.z, rb.x, 0.f), make_float4(ra.y, ra.w, rb.y, 0.f), T.o, T.inv, kEps, T.tmax)) {
+                        idx = skip;
+                        continue;
+                    }
+                    if (id == 0u) {
+                        idx++;
+                        continue;
+                    }
+                    const float4* tv = S.tri_v + 3 * (size_t)(T.tri_base + (id - 1));
+                    const float4 a = tv[0], b = tv[1], c = tv[2];
+                    if (COUNT) cnt.tris++;
+                    float u, v;
+                    if (tri_test(T.o, T.d, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), kEps, T.tmax, u, v)) {
+                        T.h.inst = T.cur_inst;
+                        T.h.tri = (id - 1) * 3;
+                        T.h.u = u;
+                        T.h.v = v;
+                    }
+                    idx = skip;
+                }
+                hits--;
+            }
         }
-        st.lds[T.sp * kBlock] = right_first ? refl : refr;
-        T.sp++;
-        T.cur = right_first ? refr : refl;
-    } else {
-        T.cur = hl ? refl : (hr ? refr : kPop);
+        // farthest first, so that the nearest of them is popped first
+        if (hits > 3u) st.lds[(T.sp++) * kBlock] = make_uint2(k3, r3);
+        if (hits > 2u) st.lds[(T.sp++) * kBlock] = make_uint2(k2, r2);
+        if (hits > 1u) st.lds[(T.sp++) * kBlock] = make_uint2(k1, r1);
     }
+    T.cur = hits ? r0 : kPop;
     return false;
 }
 
 template <bool COUNT>
-__device__ __forceinline__ Hit closest_hit_query_fast(const DevScene& S, V3 wo, V3 wd, Counters& cnt, uint32_t* lds_column) {
+__device__ __forceinline__ Hit closest_hit_query_fast(const DevScene& S, V3 wo, V3 wd, Counters& cnt, uint32_t* lds_base) {
     TravFast T;
     FastStack st;
-    st.lds = lds_column;
+    st.lds = fast_stack_column(lds_base);
     trav_fast_begin(T, S, wo, wd);
     for (;;) {
         if (COUNT) {
@@ -495,10 +579,10 @@ __device__ __forceinline__ Hit closest_hit_query_fast(const DevScene& S, V3 wo, 
 }
 
 template <bool COUNT>
-__device__ __forceinline__ bool any_hit_query_fast(const DevScene& S, V3 wo, V3 wd, float tmax, Counters& cnt, uint32_t* lds_column) {
+__device__ __forceinline__ bool any_hit_query_fast(const DevScene& S, V3 wo, V3 wd, float tmax, Counters& cnt, uint32_t* lds_base) {
     TravFast T;
     FastStack st;
-    st.lds = lds_column;
+    st.lds = fast_stack_column(lds_base);
     trav_fast_begin(T, S, wo, wd);
     T.tmax = tmax;
     for (;;) {

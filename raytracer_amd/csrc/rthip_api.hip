@@ -96,16 +96,16 @@ uint64_t* counters_or_null(rthip_ctx* ctx) { return ctx->counting ? (uint64_t*)c
 
 // RTHIP_TRAV_FAST: the records of the ordered walk for every committed mesh / for the TLAS (enqueued on ctx->stream)
 int convert_blas_wide(rthip_ctx* ctx) {
-    RT_TRY(rthip_reserve(ctx, ctx->blas_wide, (ctx->total_tris ? ctx->total_tris : 1) * 64));
+    RT_TRY(rthip_reserve(ctx, ctx->blas_wide, (ctx->total_tris ? ctx->total_tris : 1) * 128));
     for (HostMesh& m : ctx->meshes)
         RT_TRY(wide_convert_device(ctx, (const float4*)ctx->blas_nodes.p + 2 * (size_t)m.dev.node_base, m.dev.n_nodes,
-                                   (float4*)ctx->blas_wide.p + 4 * (size_t)m.dev.wide_base, ctx->stream));
+                                   (float4*)ctx->blas_wide.p + 8 * (size_t)m.dev.wide_base, ctx->stream));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->blas_wide_ready = true;
     return RTHIP_OK;
 }
 int convert_tlas_wide(rthip_ctx* ctx) {
-    RT_TRY(rthip_reserve(ctx, ctx->tlas_wide, (ctx->n_inst ? (size_t)ctx->n_inst : 1) * 64));
+    RT_TRY(rthip_reserve(ctx, ctx->tlas_wide, (ctx->n_inst ? (size_t)ctx->n_inst : 1) * 128));
     if (ctx->n_inst)
         RT_TRY(wide_convert_device(ctx, (const float4*)ctx->tlas_nodes.p, 2 * ctx->n_inst - 1, (float4*)ctx->tlas_wide.p, ctx->stream));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -379,7 +379,7 @@ int rthip_blas_commit(rthip_ctx* ctx) {
         HostMesh& m = ctx->meshes[k];
         if (!m.present) return rthip_fail(ctx, RTHIP_E_INVALID, "mesh %zu was never added", k);
         m.dev.node_base = (uint32_t)nodes;
-        m.dev.wide_base = (uint32_t)(tris - k);  // a mesh of T triangles has T - 1 inner nodes
+        m.dev.wide_base = (uint32_t)(tris - k);  // room for T - 1 records per mesh of T triangles (it has T - 1 inner nodes; about half of them get a record)
         m.dev.n_nodes = 2 * m.n_tris - 1;
         m.dev.tri_base = (uint32_t)tris;
         m.dev.n_tris = m.n_tris;

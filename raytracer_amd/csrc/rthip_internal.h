@@ -48,7 +48,7 @@ struct DevTree {
 
 // Per-mesh data the traversal kernels read.
 struct DevMesh {
-    uint32_t wide_base;  // first inner record of this mesh in the fast mode's record array
+    uint32_t wide_base;  // first record of this mesh in the fast mode's record array (records of 8 float4)
     uint32_t node_base;  // first node of this BLAS in the shared node array (in nodes, not float4s)
     uint32_t n_nodes;
     uint32_t tri_base;   // first triangle of this mesh in the shared triangle arrays
@@ -65,7 +65,7 @@ struct DevInstance {
     uint32_t tri_base;
     uint32_t has_normals;
     float sphere_radius;
-    uint32_t wide_base;  // first inner record of this mesh in the fast mode's record array (records, not float4s)
+    uint32_t wide_base;  // first record of this mesh in the fast mode's record array (records of 8 float4)
     float sphere_center[4];
     float translation[4];
     float rotation[4];
@@ -78,7 +78,7 @@ struct DevScene {
     const float4* blas;       // all BLAS nodes, mesh after mesh
     const float4* tri_v;      // 3 x float4 per triangle: v0, v1, v2 (w unused), mesh after mesh
     const float4* tri_n;      // 3 x float4 per triangle: n0, n1, n2 (meshes without normals: unused)
-    const float4* tlas_wide;  // RTHIP_TRAV_FAST: 4 x float4 per inner TLAS node (both children's boxes and references)
+    const float4* tlas_wide;  // RTHIP_TRAV_FAST: the TLAS collapsed to 4-wide records of 8 x float4 (wide_emit_kernel)
     const float4* blas_wide;  // the same for every mesh, mesh after mesh
     const DevInstance* inst;  // by TLAS id - 1
     const rthip_material* mats;
@@ -151,9 +151,9 @@ struct rthip_ctx {
     uint64_t total_blas_nodes = 0, total_tris = 0;
 
     int traversal = 0;        // RTHIP_TRAV_EXACT / RTHIP_TRAV_FAST
-    DevBuf blas_wide;         // float4[4 * (total tris - meshes)]: the fast mode's records of every BLAS
-    DevBuf tlas_wide;         // float4[4 * (n_inst - 1)]
-    DevBuf wide_rank;         // uint32[nodes]: scratch of the conversion
+    DevBuf blas_wide;         // float4[8 * (total tris - meshes)]: room for the fast mode's records of every BLAS
+    DevBuf tlas_wide;         // float4[8 * (n_inst - 1)]
+    DevBuf wide_rank;         // uint32[nodes + 1]: scratch of the conversion
     bool blas_wide_ready = false, tlas_wide_ready = false;
     DevBuf tlas_nodes;  // float4[2 * (2 n_inst - 1)]
     DevBuf inst;        // DevInstance[n_inst]

@@ -58,7 +58,7 @@ template <>
 struct Walk<true> {
     TravFast T;
     FastStack st;
-    __device__ __forceinline__ void init(uint32_t* lds_column) { st.lds = lds_column; }
+    __device__ __forceinline__ void init(uint32_t* lds_base) { st.lds = fast_stack_column(lds_base); }
     __device__ __forceinline__ void begin(const DevScene& S, V3 o, V3 d) { trav_fast_begin(T, S, o, d); }
     template <bool COUNT, bool DEFER>
     __device__ __forceinline__ bool step(const DevScene& S, Counters& cnt) {
@@ -68,9 +68,9 @@ struct Walk<true> {
     }
 };
 
-// This lane's column of the ordered walk's stack: it lies behind the bounce stack in the dynamic LDS block.
+// The workgroup's block of the ordered walk's stacks: it lies behind the bounce stack in the dynamic LDS block.
 __device__ __forceinline__ uint32_t* fast_column(uint32_t* bounce_stack_base, uint32_t max_bounces) {
-    return bounce_stack_base + (size_t)(max_bounces ? max_bounces : 1u) * kBlock + threadIdx.x;
+    return bounce_stack_base + (size_t)(max_bounces ? max_bounces : 1u) * kBlock;
 }
 
 // One closest-hit query in the chosen mode.
@@ -94,7 +94,7 @@ __device__ __forceinline__ void work_slot_release(uint32_t* work) {
 }
 
 template <bool COUNT, bool DEFER, bool FAST = false>
-__global__ __launch_bounds__(kBlock, 5) void cast_kernel(DevScene S, rthip_cast_settings c, uint64_t seed,
+__global__ __launch_bounds__(kBlock, FAST ? 4 : 5) void cast_kernel(DevScene S, rthip_cast_settings c, uint64_t seed,
                                                       float* __restrict__ out, int width, int height,
                                                       rthip_shard shard, uint32_t* work_counters, uint32_t refill, uint32_t inst_batch,
                                                       uint32_t accumulate, uint64_t* counters) {
@@ -288,7 +288,7 @@ __device__ __forceinline__ bool pixel_of_thread(int width, int height, int& x, i
 #define RT_STATIC_WAVES 5
 #endif
 template <bool COUNT, bool BATCH = false, bool FAST = false>
-__global__ __launch_bounds__(kBlock, RT_STATIC_WAVES) void cast_static_kernel(DevScene S, rthip_cast_settings c, uint64_t seed,
+__global__ __launch_bounds__(kBlock, FAST ? 4 : RT_STATIC_WAVES) void cast_static_kernel(DevScene S, rthip_cast_settings c, uint64_t seed,
                                                              float* __restrict__ out, int width, int height,
                                                              rthip_shard shard, uint32_t accumulate, uint64_t* counters,
                                                              uint32_t inst_batch = 0) {
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(kBlock, RT_STATIC_WAVES) void cast_static_kernel(De
 // start, the slowest 1.5 times the median).  The samples of a pixel are added in the order of the sample loop
 // (raytracer_cpu.c:196-236) by the pixel's first lane, so the sum has the same bits.
 template <bool COUNT, bool BATCH, bool FAST = false>
-__global__ __launch_bounds__(kBlock, RT_STATIC_WAVES) void cast_samples_kernel(DevScene S, rthip_cast_settings c, uint64_t seed,
+__global__ __launch_bounds__(kBlock, FAST ? 4 : RT_STATIC_WAVES) void cast_samples_kernel(DevScene S, rthip_cast_settings c, uint64_t seed,
                                                               float* __restrict__ out, int width, int height,
                                                               rthip_shard shard, uint32_t log2_group, uint32_t accumulate,
                                                               uint64_t* counters, uint32_t inst_batch) {
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(kBlock) void primary_hits_kernel(DevScene S, rthip_
         V3 o, d;
         camera_ray(c1, width, height, x, y, 0, 0, false, g, o, d);
         rays = 1;
-        const Hit h = query<COUNT, FAST>(S, o, d, cnt, fast_lds + threadIdx.x);
+        const Hit h = query<COUNT, FAST>(S, o, d, cnt, fast_lds);
         uint32_t* r = hits4 + 4 * ((size_t)y * width + x);
         r[0] = h.inst;
         r[1] = h.inst ? h.tri : 0u;
@@ -547,7 +547,7 @@ __global__ __launch_bounds__(kBlock) void trace_rays_kernel(DevScene S, const fl
         const V3 o = mk(ro[3 * i], ro[3 * i + 1], ro[3 * i + 2]);
         const V3 d = mk(rd[3 * i], rd[3 * i + 1], rd[3 * i + 2]);
         rays = 1;
-        const Hit h = query<COUNT, FAST>(S, o, d, cnt, fast_lds + threadIdx.x);
+        const Hit h = query<COUNT, FAST>(S, o, d, cnt, fast_lds);
         write_ray_result(S, i, h, o, d, hits4, uv, normal);
     }
     if (COUNT) flush_counters(counters, cnt, rays);
@@ -576,7 +576,7 @@ __global__ __launch_bounds__(kBlock) void trace_rays_persistent_kernel(DevScene 
     bool active = false;
     uint64_t ray = 0;
     Walk<FAST> Wk;
-    Wk.init(fast_lds + threadIdx.x);
+    Wk.init(fast_lds);
     Wk.begin(S, mk(0.f, 0.f, 0.f), mk(0.f, 0.f, 1.f));
 
     for (;;) {
@@ -638,7 +638,7 @@ __global__ __launch_bounds__(kBlock) void occlusion_kernel(DevScene S, const flo
         const V3 d = mk(rd[3 * i], rd[3 * i + 1], rd[3 * i + 2]);
         rays = 1;
         bool hit;
-        if constexpr (FAST) hit = any_hit_query_fast<COUNT>(S, o, d, tmax, cnt, fast_lds + threadIdx.x);
+        if constexpr (FAST) hit = any_hit_query_fast<COUNT>(S, o, d, tmax, cnt, fast_lds);
         else hit = any_hit_query<COUNT>(S, o, d, tmax, cnt);
         out[i] = hit ? 1 : 0;
     }
@@ -647,7 +647,15 @@ __global__ __launch_bounds__(kBlock) void occlusion_kernel(DevScene S, const flo
 
 inline uint32_t div_up(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
 
-constexpr size_t kFastLdsBytes = (size_t)kFastLds * kBlock * sizeof(uint32_t);  // the ordered walk's LDS stack per workgroup
+constexpr size_t kFastLdsBytes = (size_t)kFastLds * kBlock * sizeof(uint2);  // the ordered walk's LDS stack per workgroup
+
+// A launch that asks for more than 64 KB of dynamic LDS (the ordered walk's stacks behind a bounce stack of more than
+// 32 bounces) has to say so first.
+template <class K>
+int allow_lds(rthip_ctx* ctx, K kernel, size_t bytes) {
+    if (bytes > (64u << 10)) RT_HIP(ctx, hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return RTHIP_OK;
+}
 
 }  // namespace
 
@@ -769,6 +777,7 @@ int cast_records_launch(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_
     const uint64_t n_paths = (uint64_t)width * height * cast.samples * cast.samples;
     const size_t lds = (size_t)(scene.max_bounces ? scene.max_bounces : 1) * kBlock * sizeof(uint32_t);
     const uint32_t blocks = div_up(n_paths, kBlock);
+    if (ctx->traversal == RTHIP_TRAV_FAST) RT_TRY(allow_lds(ctx, cast_records_kernel<true>, lds + kFastLdsBytes));
     if (ctx->traversal == RTHIP_TRAV_FAST)
         cast_records_kernel<true><<<blocks, kBlock, lds + kFastLdsBytes, stream>>>(scene, cast, seed, width, height, d_slots, d_counts);
     else
@@ -793,6 +802,8 @@ int launch_static(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_settin
     const size_t lds = (size_t)(scene.max_bounces ? scene.max_bounces : 1) * kBlock * sizeof(uint32_t);
     const uint32_t blocks = div_up(width, 16) * div_up(height, 16);
     if (ctx->traversal == RTHIP_TRAV_FAST) {
+        if (d_counters) RT_TRY(allow_lds(ctx, cast_static_kernel<true, false, true>, lds + kFastLdsBytes));
+        else RT_TRY(allow_lds(ctx, cast_static_kernel<false, false, true>, lds + kFastLdsBytes));
         if (d_counters)
             cast_static_kernel<true, false, true><<<blocks, kBlock, lds + kFastLdsBytes, stream>>>(scene, cast, seed, d_rgb, width, height, shard, ctx->cast_accumulate, d_counters);
         else
@@ -826,6 +837,8 @@ int launch_samples(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_setti
     cast_samples_kernel<COUNT, BATCH><<<blocks, kBlock, lds, stream>>>(scene, cast, seed, d_rgb, width, height, shard, log2_group, \
                                                                        ctx->cast_accumulate, CNT, ib)
     if (ctx->traversal == RTHIP_TRAV_FAST) {
+        if (d_counters) RT_TRY(allow_lds(ctx, cast_samples_kernel<true, false, true>, lds + kFastLdsBytes));
+        else RT_TRY(allow_lds(ctx, cast_samples_kernel<false, false, true>, lds + kFastLdsBytes));
         if (d_counters)
             cast_samples_kernel<true, false, true><<<blocks, kBlock, lds + kFastLdsBytes, stream>>>(scene, cast, seed, d_rgb, width, height, shard, log2_group, ctx->cast_accumulate, d_counters, 0u);
         else
@@ -861,6 +874,8 @@ int launch_persistent(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_se
     cast_kernel<COUNT, DEFER><<<blocks, kBlock, lds, stream>>>(scene, cast, seed, d_rgb, width, height, shard, work, \
                                                                refill, inst_batch, ctx->cast_accumulate, CNT)
     if (ctx->traversal == RTHIP_TRAV_FAST) {
+        if (d_counters) RT_TRY(allow_lds(ctx, cast_kernel<true, false, true>, lds + kFastLdsBytes));
+        else RT_TRY(allow_lds(ctx, cast_kernel<false, false, true>, lds + kFastLdsBytes));
         if (d_counters)
             cast_kernel<true, false, true><<<blocks, kBlock, lds + kFastLdsBytes, stream>>>(scene, cast, seed, d_rgb, width, height, shard, work, refill, 0u, ctx->cast_accumulate, d_counters);
         else

@@ -1061,11 +1061,9 @@ def test_fast_traversal_against_the_exact_walk(oracle, gpu_tracer):
         gpu_tracer.check(gpu_tracer.lib.rthip_set_traversal(gpu_tracer.h, 7), "rthip_set_traversal")
 
 
-def test_fast_traversal_on_a_tree_deeper_than_its_stack(gpu_tracer):
-    """Sixty large triangles, each with a centroid coordinate half the previous one's, make a radix tree about sixty
-    levels deep whose boxes a ray pierces all at once: it wants more stack than the ordered walk keeps (24 entries), and
-    such a ray is answered by the stackless walk.  Most of the triangles lie in one plane, so which of them is reported
-    is a tie; the distance is not."""
+def deep_tree_triangles():
+    """Sixty large triangles, each with a centroid coordinate half the previous one's: their radix tree is about sixty
+    levels deep, and a ray along z pierces all of its boxes at once."""
     tris = []
     for j in range(1, 21):
         dlt = 0.5 ** j
@@ -1074,24 +1072,40 @@ def test_fast_traversal_on_a_tree_deeper_than_its_stack(gpu_tracer):
             ymax = 3 + 2 * dlt if axis == 1 else 3.0
             z = dlt if axis == 2 else 0.0
             tris.append([[-3, -3, z], [xmax, -3, z], [-3, ymax, z]])
-    v = np.zeros((180, 4), dtype=np.float32)
-    v[:, :3] = np.array(tris, dtype=np.float32).reshape(180, 3)
-    w = world.rt_make_world()
-    m = world.rt_world_add_mesh(w)
-    scenes._set_mesh(m, v, None, scenes.GEO_P)
-    mat = world.rt_world_add_material(w)
-    mat.type, mat.albedo = abi.MAT_LAMBERTIAN, scenes.v3(0.5, 0.5, 0.5)
-    it = world.rt_world_add_instance(w)
-    it.type, it.material, it.mesh = abi.INST_MESH, mat, m
-    it.translation, it.rotation, it.scale = scenes.v3(0, 0, 0), scenes.IDENTITY_QUAT, scenes.v3(1, 1, 1)
-    build(gpu_tracer, w, 2, True)
-    nodes = T.get_tree(gpu_tracer, 0)
+    return np.array(tris, dtype=np.float32)
+
+
+def tree_depth(nodes):
     depth, open_until = 0, []
     for i in range(nodes.shape[0]):
         while open_until and open_until[-1] <= i:
             open_until.pop()
         depth = max(depth, len(open_until))
         open_until.append(int(nodes["skip"][i]))
+    return depth
+
+
+@pytest.mark.parametrize("level", ["mesh", "tlas"])
+def test_fast_traversal_on_a_tree_deeper_than_its_stack(gpu_tracer, level):
+    """A tree about sixty levels deep whose boxes a ray pierces all at once wants more stack than the ordered walk keeps
+    (16 entries).  As one mesh: the boxes that do not fit are gone through in the binary tree's stackless order inside
+    the step.  As sixty one-triangle instances (the same tree as the TLAS): such a ray is answered by the stackless walk.
+    Most of the triangles lie in one plane, so which of them is reported is a tie; the distance is not."""
+    tris = deep_tree_triangles()
+    w = world.rt_make_world()
+    mat = world.rt_world_add_material(w)
+    mat.type, mat.albedo = abi.MAT_LAMBERTIAN, scenes.v3(0.5, 0.5, 0.5)
+    groups = [tris.reshape(180, 3)] if level == "mesh" else [t for t in tris]
+    for g in groups:
+        v = np.zeros((g.shape[0], 4), dtype=np.float32)
+        v[:, :3] = g
+        m = world.rt_world_add_mesh(w)
+        scenes._set_mesh(m, v, None, scenes.GEO_P)
+        it = world.rt_world_add_instance(w)
+        it.type, it.material, it.mesh = abi.INST_MESH, mat, m
+        it.translation, it.rotation, it.scale = scenes.v3(0, 0, 0), scenes.IDENTITY_QUAT, scenes.v3(1, 1, 1)
+    build(gpu_tracer, w, 2, True)
+    depth = tree_depth(T.get_tree(gpu_tracer, 0 if level == "mesh" else -1))
     assert depth >= 40, depth
     rng = np.random.default_rng(1)
     n = 4096
@@ -1102,6 +1116,12 @@ def test_fast_traversal_on_a_tree_deeper_than_its_stack(gpu_tracer):
     t_diff, prim_diff, hit_miss, a, b = fast_vs_exact_rays(gpu_tracer, o, d)
     assert (t_diff, hit_miss) == (0, 0) and int((a[0] != 0).sum()) == n
     assert np.allclose(a[2][: n // 2], 2.5, rtol=1e-6) and np.allclose(a[2][n // 2:], 3.0, rtol=1e-6)
+    occ = T.occluded(gpu_tracer, o, d, 2.75)
+    T.set_traversal(gpu_tracer, "fast")
+    try:
+        assert (T.occluded(gpu_tracer, o, d, 2.75) == occ).all() and int(occ.sum()) == n // 2
+    finally:
+        T.set_traversal(gpu_tracer, "exact")
 
 
 def test_occlusion_rays(oracle, gpu_tracer):
