@@ -130,7 +130,12 @@ typedef struct rthip_node {
  * row-major; this context renders tiles with (tile % world) == rank and leaves
  * other pixels at 0, so the shares sum to the frame.  mode 2 (samples): this
  * context renders sample indices s with (s % world) == rank of every pixel and
- * writes the plain sum of their radiance (no 1/spp factor). */
+ * writes the plain sum of their radiance (no 1/spp factor).  mode 3 (bands): the
+ * frame is cut into `world` bands of whole rows, ceil(height / world) rounded up to
+ * a multiple of 64 rows each (the last bands may be short or empty); this context
+ * renders band `rank` and does NOT touch the other rows, so several launches can
+ * fill one framebuffer (rthip_cast does, to send finished rows to the host while the
+ * rest still renders) and a band is one contiguous block of memory to ship. */
 typedef struct rthip_shard {
     uint32_t mode;
     uint32_t rank;
@@ -211,7 +216,9 @@ int rthip_cast(rthip_ctx* ctx, const rthip_cast_settings* cast, uint64_t seed, f
 
 /* Optional: page-locked host memory for the framebuffer (hipHostMalloc).  rthip_cast copies the frame into ordinary
  * (pageable) memory through the runtime's staging copies; into a buffer from rthip_host_alloc it goes by DMA at the
- * link's rate (1920x1080 floats: 1.4 ms -> 0.45 ms for the copy).  Free with rthip_host_free, or implicitly by
+ * link's rate (1920x1080 floats: 1.4 ms -> 0.45 ms for the copy), and frames of 2^19 pixels or more are rendered in
+ * four bands of rows (rthip_shard mode 3; RTHIP_CAST_BANDS=1..8), each on a stream of its own with its copy behind it,
+ * so that finished rows travel while the rest renders (the whole call 0.83 -> 0.71 ms).  Free with rthip_host_free, or implicitly by
  * rthip_destroy.  No counterpart in the reference (its framebuffer is arena memory and never leaves the CPU,
  * src/demos/cornell/main.c:214, raytracer_cpu.c:190-192); page-locking the caller's own allocation (hipHostRegister)
  * is not offered because not every host allows it. */

@@ -62,6 +62,19 @@ __device__ __forceinline__ V3 refract(V3 i, V3 n, float eta) {  // common_math.c
     return sub(scale(i, eta), scale(n, eta * ndoti + sqrtf(k)));
 }
 
+// Whether a pixel belongs to this context's share of the frame (rthip_shard): mode 1 = 64x64 tiles dealt round-robin,
+// mode 3 = bands of whole rows, `band_rows` each (shard_band_rows).  Modes 0 and 2 own every pixel.
+__device__ __forceinline__ uint32_t shard_band_rows(const rthip_shard& shard, int height) {
+    if (shard.mode != 3) return 1u;
+    const uint32_t rows = ((uint32_t)height + shard.world - 1u) / shard.world;
+    return (rows + 63u) & ~63u;
+}
+__device__ __forceinline__ bool shard_owns(const rthip_shard& shard, uint32_t px, uint32_t py, int width, uint32_t band_rows) {
+    if (shard.mode == 1) return (((py / 64u) * (((uint32_t)width + 63u) / 64u) + (px / 64u)) % shard.world) == shard.rank;
+    if (shard.mode == 3) return py / band_rows == shard.rank;
+    return true;
+}
+
 struct Hit {
     uint32_t inst;  // 1-based TLAS id, 0 = miss
     uint32_t tri;   // index-buffer offset of the triangle ((id-1)*3), meshes only

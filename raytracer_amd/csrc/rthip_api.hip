@@ -149,6 +149,8 @@ int rthip_create(rthip_ctx** out_ctx, int device_id) {
     if (mode && strcmp(mode, "persistent") == 0) ctx->cast_mode = 0;
     if (mode && strcmp(mode, "auto") == 0) ctx->cast_mode = 3;
     ctx->persistent_blocks = (uint32_t)prop.multiProcessorCount * 5u;
+    const char* cast_bands = getenv("RTHIP_CAST_BANDS");
+    if (cast_bands && atoi(cast_bands) >= 1 && atoi(cast_bands) <= rthip_ctx::kMaxBands) ctx->cast_bands = atoi(cast_bands);
     const char* ib = getenv("RTHIP_INST_BATCH");
     if (ib && atoi(ib) >= 0 && atoi(ib) <= 64) ctx->inst_batch = (uint32_t)atoi(ib);
     const char* refill = getenv("RTHIP_REFILL");
@@ -189,6 +191,12 @@ void rthip_destroy(rthip_ctx* ctx) {
     for (DevBuf* b : all) rthip_release(*b);
     for (DevBuf& b : ctx->wf) rthip_release(b);
     for (hipEvent_t e : ctx->slot_done)
+        if (e) (void)hipEventDestroy(e);
+    for (hipStream_t b : ctx->band_stream)
+        if (b) (void)hipStreamDestroy(b);
+    for (hipStream_t b : ctx->band_copy_stream)
+        if (b) (void)hipStreamDestroy(b);
+    for (hipEvent_t e : ctx->band_done)
         if (e) (void)hipEventDestroy(e);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -522,7 +530,7 @@ int rthip_cast_device(rthip_ctx* ctx, const rthip_cast_settings* cast, uint64_t 
     rthip_shard sh = {0, 0, 1};
     if (shard) {
         sh = *shard;
-        if (sh.mode > 2 || (sh.mode != 0 && (sh.world == 0 || sh.rank >= sh.world)))
+        if (sh.mode > 3 || (sh.mode != 0 && (sh.world == 0 || sh.rank >= sh.world)))
             return rthip_fail(ctx, RTHIP_E_INVALID, "bad shard {mode %u, rank %u, world %u}", sh.mode, sh.rank, sh.world);
     }
     RT_HIP(ctx, hipSetDevice(ctx->device));
@@ -565,6 +573,16 @@ int rthip_host_free(rthip_ctx* ctx, void* ptr) {
     return rthip_fail(ctx, RTHIP_E_INVALID, "rthip_host_free: %p does not come from rthip_host_alloc of this context", ptr);
 }
 
+// Whether a host pointer is page-locked memory the device can copy into without staging (rthip_host_alloc, hipHostMalloc).
+static bool host_pointer_is_pinned(const void* p) {
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+        (void)hipGetLastError();  // an ordinary malloc'ed pointer is reported as an error by some runtimes
+        return false;
+    }
+    return attr.type == hipMemoryTypeHost;
+}
+
 int rthip_cast(rthip_ctx* ctx, const rthip_cast_settings* cast, uint64_t seed, float* out_rgb, int width, int height) {
     RT_TRY(check_ready(ctx, "rthip_cast"));
     RT_TRY(check_cast(ctx, cast, width, height));
@@ -573,11 +591,47 @@ int rthip_cast(rthip_ctx* ctx, const rthip_cast_settings* cast, uint64_t seed, f
     const size_t bytes = (size_t)width * height * 3 * sizeof(float);
     ctx->frame_w = ctx->frame_h = 0;
     RT_TRY(rthip_reserve(ctx, ctx->frame, bytes));
+    // Into page-locked memory a large frame goes in bands of rows (rthip_shard mode 3): every band is rendered on a
+    // stream of its own with its copy to the host right behind it, so the rows that are finished early (sky) are on
+    // their way while the bands that hold the scene still render, and the bands overlap like frames on several streams.
+    // A copy into pageable memory is staged by the runtime and holds the calling thread, so it stays one launch + one copy.
+    uint32_t bands = (uint32_t)ctx->cast_bands;
+    // (the staged renderer keeps its path state in one set of arrays per context: one launch at a time)
+    if ((uint64_t)width * height < (1ull << 19) || ctx->counting || ctx->cast_mode == 2 || (uint32_t)height < 64u * bands || !host_pointer_is_pinned(out_rgb)) bands = 1;
     RT_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-    RT_TRY(rthip_cast_device(ctx, cast, seed, (float*)ctx->frame.p, width, height, nullptr, ctx->stream));
-    RT_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-    RT_HIP(ctx, hipMemcpyAsync(out_rgb, ctx->frame.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (bands <= 1) {
+        RT_TRY(rthip_cast_device(ctx, cast, seed, (float*)ctx->frame.p, width, height, nullptr, ctx->stream));
+        RT_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+        RT_HIP(ctx, hipMemcpyAsync(out_rgb, ctx->frame.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    } else {
+        const uint32_t rows = (((uint32_t)height + bands - 1u) / bands + 63u) & ~63u;  // shard_band_rows
+        for (uint32_t k = 0; k < bands; k++) {
+            if (!ctx->band_stream[k]) RT_HIP(ctx, hipStreamCreateWithFlags(&ctx->band_stream[k], hipStreamNonBlocking));
+            if (!ctx->band_copy_stream[k]) RT_HIP(ctx, hipStreamCreateWithFlags(&ctx->band_copy_stream[k], hipStreamNonBlocking));
+            if (!ctx->band_done[k]) RT_HIP(ctx, hipEventCreateWithFlags(&ctx->band_done[k], hipEventDisableTiming));
+        }
+        // all the launches first, then the copies on streams of their own: a copy waits for its band only, and no launch
+        // queues up behind a copy
+        uint32_t used = 0;
+        for (uint32_t k = 0; k < bands && k * rows < (uint32_t)height; k++, used++) {
+            const rthip_shard band = {3u, k, bands};
+            hipStream_t bs = ctx->band_stream[k];
+            RT_HIP(ctx, hipStreamWaitEvent(bs, ctx->ev0, 0));  // behind whatever the context's stream held before this call
+            RT_TRY(rthip_cast_device(ctx, cast, seed, (float*)ctx->frame.p, width, height, &band, bs));
+            RT_HIP(ctx, hipEventRecord(ctx->band_done[k], bs));
+            RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->band_done[k], 0));
+        }
+        for (uint32_t k = 0; k < used; k++) {
+            const uint32_t y0 = k * rows, y1 = (k + 1u) * rows < (uint32_t)height ? (k + 1u) * rows : (uint32_t)height;
+            const size_t off = (size_t)y0 * width * 3, count = (size_t)(y1 - y0) * width * 3;
+            RT_HIP(ctx, hipStreamWaitEvent(ctx->band_copy_stream[k], ctx->band_done[k], 0));
+            RT_HIP(ctx, hipMemcpyAsync(out_rgb + off, (const float*)ctx->frame.p + off, count * sizeof(float), hipMemcpyDeviceToHost, ctx->band_copy_stream[k]));
+        }
+        RT_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));  // every band rendered: the frame is whole in device memory
+        for (uint32_t k = 0; k < used; k++) RT_HIP(ctx, hipStreamSynchronize(ctx->band_copy_stream[k]));
+        RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
     RT_HIP(ctx, hipEventElapsedTime(&ctx->last_cast_ms, ctx->ev0, ctx->ev1));
     ctx->frame_w = width;  // the image stays in device memory for rthip_hdr_encode(rgb = NULL)
     ctx->frame_h = height;

@@ -138,6 +138,12 @@ struct rthip_ctx {
     std::vector<Pinned> pinned;    // page-locked host memory handed out by rthip_host_alloc
     hipStream_t stream = nullptr;  // the context's own stream for host-blocking entry points
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // rthip_cast into page-locked memory: the frame in bands of rows, each on a stream of its own, its copy behind it
+    static constexpr int kMaxBands = 8;
+    hipStream_t band_stream[kMaxBands] = {};
+    hipStream_t band_copy_stream[kMaxBands] = {};
+    hipEvent_t band_done[kMaxBands] = {};
+    int cast_bands = 4;  // RTHIP_CAST_BANDS; 1 = one launch, one copy
 
     LbvhWorkspace ws;
     LbvhWorkspace ws_static;  // the same arrays carved out of the device's static scratch array (lbvh_static_workspace_init)

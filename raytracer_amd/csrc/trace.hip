@@ -111,7 +111,7 @@ __global__ __launch_bounds__(kBlock, FAST ? 4 : 5) void cast_kernel(DevScene S, 
     uint64_t tile_id = 0;
     uint32_t tile_pos = 64;  // positions of tile_id already handed out (64: none left)
     uint32_t qslot = wave_id & 7u, qtried = 0;  // which of the 8 dynamic counters, and how many ran dry
-    const uint32_t shard_tiles_x = (uint32_t)(width + 63) / 64;
+    const uint32_t band_rows = shard_band_rows(shard, height);
 
     Counters cnt = {0, 0, 0, 0};
     uint32_t rays = 0;
@@ -179,15 +179,14 @@ __global__ __launch_bounds__(kBlock, FAST ? 4 : 5) void cast_kernel(DevScene S, 
                 py = (tile / tiles_x) * 8u + (in >> 3);
                 if (px < (uint32_t)width && py < (uint32_t)height) {
                     pixel = py * (uint32_t)width + px;
-                    bool mine = true;
-                    if (shard.mode == 1) mine = (((py / 64u) * shard_tiles_x + (px / 64u)) % shard.world) == shard.rank;
+                    const bool mine = shard_owns(shard, px, py, width, band_rows);
                     if (mine) {
                         acc = mk(0.f, 0.f, 0.f);
                         sidx = 0;
                         if (shard.mode == 2)
                             while (sidx < spp && (sidx % shard.world) != shard.rank) sidx++;
                         state = ST_NEED_SAMPLE;
-                    } else if (!accumulate) {  // another rank's tile: this rank's share of the pixel is 0
+                    } else if (!accumulate && shard.mode != 3) {  // another rank's tile: this rank's share of the pixel is 0 (rows of another band are left alone)
                         put_pixel(out, pixel, mk(0.f, 0.f, 0.f), 0u);
                     }
                 }
@@ -304,11 +303,7 @@ __global__ __launch_bounds__(kBlock, FAST ? 4 : RT_STATIC_WAVES) void cast_stati
     if (inside) {
         const int samples = (int)c.samples;
         const uint32_t pixel = (uint32_t)(y * width + x);
-        bool mine = true;
-        if (shard.mode == 1) {
-            const uint32_t tile = (uint32_t)((y / 64) * ((width + 63) / 64) + (x / 64));
-            mine = (tile % shard.world) == shard.rank;
-        }
+        const bool mine = shard_owns(shard, (uint32_t)x, (uint32_t)y, width, shard_band_rows(shard, height));
         V3 acc = mk(0.f, 0.f, 0.f);
         if (mine) {
             for (int ys = 0; ys < samples; ys++)
@@ -336,7 +331,7 @@ __global__ __launch_bounds__(kBlock, FAST ? 4 : RT_STATIC_WAVES) void cast_stati
                 }
             if (shard.mode != 2) acc = scale(acc, 1.f / ((float)samples * (float)samples));
         }
-        if (mine || !accumulate) put_pixel(out, pixel, acc, accumulate);
+        if (mine || (!accumulate && shard.mode != 3)) put_pixel(out, pixel, acc, accumulate);
     }
 #ifdef RT_STAMP
     {
@@ -385,11 +380,7 @@ __global__ __launch_bounds__(kBlock, FAST ? 4 : RT_STATIC_WAVES) void cast_sampl
     const uint32_t pixel = inside ? (uint32_t)(y * width + x) : 0u;
     Counters cnt = {0, 0, 0, 0};
     uint32_t rays = 0;
-    bool mine = inside;
-    if (inside && shard.mode == 1) {
-        const uint32_t tile = (uint32_t)((y / 64) * ((width + 63) / 64) + (x / 64));
-        mine = (tile % shard.world) == shard.rank;
-    }
+    const bool mine = inside && shard_owns(shard, (uint32_t)x, (uint32_t)y, width, shard_band_rows(shard, height));
     const bool have = mine && !(shard.mode == 2 && (sidx % shard.world) != shard.rank);
     V3 L = mk(0.f, 0.f, 0.f);
     if (have) {
@@ -420,7 +411,7 @@ __global__ __launch_bounds__(kBlock, FAST ? 4 : RT_STATIC_WAVES) void cast_sampl
     }
     if (inside && sidx == 0) {
         if (mine && shard.mode != 2) acc = scale(acc, 1.f / ((float)samples * (float)samples));
-        if (mine || !accumulate) put_pixel(out, pixel, acc, accumulate);
+        if (mine || (!accumulate && shard.mode != 3)) put_pixel(out, pixel, acc, accumulate);
     }
     if (COUNT) flush_counters(counters, cnt, rays);
 }

@@ -53,10 +53,8 @@ __device__ __forceinline__ void position_to_pixel(uint32_t pos, uint32_t tiles_x
     py = (tile / tiles_x) * 8u + (in >> 3);
 }
 
-__device__ __forceinline__ bool pixel_is_mine(const rthip_shard& shard, uint32_t px, uint32_t py, int width) {
-    if (shard.mode != 1) return true;
-    const uint32_t shard_tiles_x = (uint32_t)(width + 63) / 64;
-    return (((py / 64u) * shard_tiles_x + (px / 64u)) % shard.world) == shard.rank;
+__device__ __forceinline__ bool pixel_is_mine(const rthip_shard& shard, uint32_t px, uint32_t py, int width, int height) {
+    return shard_owns(shard, px, py, width, shard_band_rows(shard, height));
 }
 
 __global__ __launch_bounds__(kBlock) void wf_raygen_kernel(DevScene S, rthip_cast_settings c, uint64_t seed, int width,
@@ -66,7 +64,7 @@ __global__ __launch_bounds__(kBlock) void wf_raygen_kernel(DevScene S, rthip_cas
     const uint32_t pos = B.first + p / B.spp, sidx = p % B.spp;
     uint32_t px, py;
     position_to_pixel(pos, B.tiles_x, px, py);
-    bool live = px < (uint32_t)width && py < (uint32_t)height && pixel_is_mine(shard, px, py, width);
+    bool live = px < (uint32_t)width && py < (uint32_t)height && pixel_is_mine(shard, px, py, width, height);
     if (shard.mode == 2 && (sidx % shard.world) != shard.rank) live = false;
     if (S.max_bounces == 0) live = false;  // rt_cpu_trace_ray with depth 0 is black (:247-249)
     A.radiance[p] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -224,7 +222,9 @@ __global__ __launch_bounds__(kBlock) void wf_resolve_kernel(rthip_cast_settings 
     position_to_pixel(B.first + k, B.tiles_x, px, py);
     if (px >= (uint32_t)width || py >= (uint32_t)height) return;
     V3 acc = mk(0.f, 0.f, 0.f);
-    if (pixel_is_mine(shard, px, py, width)) {
+    const bool mine = pixel_is_mine(shard, px, py, width, height);
+    if (!mine && shard.mode == 3) return;  // rows of another band are left alone
+    if (mine) {
         for (uint32_t s = 0; s < B.spp; s++) {
             if (shard.mode == 2 && (s % shard.world) != shard.rank) continue;
             const float4 L = A.radiance[(size_t)k * B.spp + s];

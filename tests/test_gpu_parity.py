@@ -1163,6 +1163,27 @@ def test_cast_into_page_locked_host_memory(gpu_tracer):
     T.host_free(gpu_tracer, big)
     with pytest.raises(T.RTHipError):
         gpu_tracer.check(gpu_tracer.lib.rthip_host_free(gpu_tracer.h, plain.ctypes.data), "rthip_host_free")
+    # Frames of 2^19 pixels and more travel in bands of rows (rthip_shard mode 3), every band rendered on a stream of
+    # its own with its copy behind it: every kernel, a ragged last band, and a height that leaves the last band empty.
+    verts, indices = scenes.bunny_class_mesh(3)
+    w, cam, sky = scenes.bunny(verts, indices)
+    build(gpu_tracer, w, 2, sky)
+    try:
+        for wd, ht, samples in ((1024, 600, 1), (2100, 260, 1), (1024, 520, 2)):
+            c = cam(wd, ht, samples)
+            plain = np.zeros((ht, wd, 3), dtype=np.float32)
+            T.set_cast_kernel(gpu_tracer, "auto")
+            T.rt_tracer_cast(gpu_tracer, c, plain, wd, ht, seed=5)
+            assert float(plain.max()) > 0.0
+            pinned = T.host_alloc(gpu_tracer, (ht, wd, 3))
+            for kernel in ("auto", "static", "persistent", "wavefront") + (("static-samples",) if samples == 2 else ()):
+                T.set_cast_kernel(gpu_tracer, kernel)
+                pinned[:] = -1.0
+                T.rt_tracer_cast(gpu_tracer, c, pinned, wd, ht, seed=5)
+                assert (bits(pinned) == bits(plain)).all(), (wd, ht, kernel)
+            T.host_free(gpu_tracer, pinned)
+    finally:
+        T.set_cast_kernel(gpu_tracer, "auto")
 
 
 def test_group_of_contexts_renders_the_single_context_frame(gpu_tracer):
