@@ -357,19 +357,21 @@ int rthip_occluded_device(rthip_ctx* ctx, const float* d_origins, const float* d
  * lbvh.c:151-161).
  *   RTHIP_TRAV_EXACT (default)  the reference's walk: depth first, always the left child before the right one,
  *                               whatever the ray.  Results are the reference's bit for bit.
- *   RTHIP_TRAV_FAST             opt-in: the same trees, the same box / triangle / sphere arithmetic and the same
- *                               acceptance rule (min <= t <= max), but the nearer child is visited first (the farther
- *                               one waits on a per-lane stack in LDS) and an inner node's record holds both children's
- *                               boxes.  Rays test several times fewer boxes.  The result is the closest hit as well;
+ *   RTHIP_TRAV_FAST             opt-in: the same trees (collapsed two levels at a time into 4-wide records, every box
+ *                               a box of the binary tree), the same box / triangle / sphere arithmetic and the same
+ *                               acceptance rule (min <= t <= max), but the nearest box is entered first; the others
+ *                               wait on a per-lane stack in LDS with their entry distance and are dropped unseen
+ *                               once a closer hit has been found.  A ray's chain of dependent fetches is half as
+ *                               long and it tests fewer boxes.  The result is the closest hit as well;
  *                               it differs from the reference's only where the reference's answer is an artefact of
  *                               its visiting order: which of several primitives at exactly the same distance is
  *                               reported, and seam rays where the reference skips a triangle because its box (tested
  *                               without slack) lies behind the interval already shrunk to a neighbour's hit while
  *                               the triangle test (with slack) would have accepted it, or the other way round.
- *                               DESIGN.md holds the measured mismatch counts.  The wavefront kernel has no fast
- *                               walk: RTHIP_KERNEL_WAVEFRONT renders with RTHIP_KERNEL_PERSISTENT in this mode.
- * Switching to FAST builds the extra records for the trees that exist (and for every tree built afterwards: +64 bytes
- * per inner node); it waits for the GPU. */
+ *                               The measured mismatch counts are in the design notes.  The wavefront kernel has no
+ *                               fast walk: RTHIP_KERNEL_WAVEFRONT renders with RTHIP_KERNEL_PERSISTENT in this mode.
+ * Switching to FAST builds the extra records for the trees that exist (and for every tree built afterwards: room for
+ * 128 bytes per inner node, about half of it used); it waits for the GPU. */
 enum { RTHIP_TRAV_EXACT = 0, RTHIP_TRAV_FAST = 1 };
 int rthip_set_traversal(rthip_ctx* ctx, int mode);
 

@@ -149,6 +149,12 @@ int rthip_create(rthip_ctx** out_ctx, int device_id) {
     if (mode && strcmp(mode, "persistent") == 0) ctx->cast_mode = 0;
     if (mode && strcmp(mode, "auto") == 0) ctx->cast_mode = 3;
     ctx->persistent_blocks = (uint32_t)prop.multiProcessorCount * 5u;
+    ctx->cus = (uint32_t)prop.multiProcessorCount;
+    const char* per_cu = getenv("RTHIP_PERSISTENT_PER_CU");  // resident workgroups per CU the persistent kernels are launched for
+    if (per_cu && atoi(per_cu) >= 1 && atoi(per_cu) <= 8) {
+        ctx->persistent_blocks = (uint32_t)prop.multiProcessorCount * (uint32_t)atoi(per_cu);
+        ctx->persistent_blocks_forced = true;
+    }
     const char* cast_bands = getenv("RTHIP_CAST_BANDS");
     if (cast_bands && atoi(cast_bands) >= 1 && atoi(cast_bands) <= rthip_ctx::kMaxBands) ctx->cast_bands = atoi(cast_bands);
     const char* ib = getenv("RTHIP_INST_BATCH");

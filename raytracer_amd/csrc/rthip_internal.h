@@ -175,7 +175,11 @@ struct rthip_ctx {
     bool slot_used[kEagerSlots] = {};
     uint32_t capture_next = 0;               // capture slots handed out since the last scene build
     int cast_mode = 3;           // 0: persistent kernel, 1: fixed pixel per thread, 2: wavefront, 3: 0 or 1 by scene size (RTHIP_CAST=...)
-    uint32_t persistent_blocks = 256u * 5u;  // resident workgroups of the persistent kernel (CUs x 5)
+    uint32_t persistent_blocks = 256u * 5u;  // resident workgroups of the persistent kernel (CUs x 5) where the runtime cannot tell
+    uint32_t cus = 256u;
+    bool persistent_blocks_forced = false;   // RTHIP_PERSISTENT_PER_CU
+    struct Resident { const void* kernel; size_t lds; uint32_t blocks; };
+    std::vector<Resident> resident;          // workgroups of a persistent kernel the GPU holds at once, per kernel and LDS size
     DevBuf wf[11];               // path-state arrays of the wavefront renderer
     uint64_t wf_capacity = 1ull << 23;  // paths per wavefront batch
     uint32_t inst_batch = 0;     // persistent kernel chosen by name: 0 = enter instances at once, k = park and enter k lanes at a time (RTHIP_INST_BATCH)

@@ -93,8 +93,11 @@ __device__ __forceinline__ void work_slot_release(uint32_t* work) {
     }
 }
 
+#ifndef RT_PERSIST_WAVES
+#define RT_PERSIST_WAVES 5
+#endif
 template <bool COUNT, bool DEFER, bool FAST = false>
-__global__ __launch_bounds__(kBlock, FAST ? 4 : 5) void cast_kernel(DevScene S, rthip_cast_settings c, uint64_t seed,
+__global__ __launch_bounds__(kBlock, FAST ? 4 : RT_PERSIST_WAVES) void cast_kernel(DevScene S, rthip_cast_settings c, uint64_t seed,
                                                       float* __restrict__ out, int width, int height,
                                                       rthip_shard shard, uint32_t* work_counters, uint32_t refill, uint32_t inst_batch,
                                                       uint32_t accumulate, uint64_t* counters) {
@@ -650,6 +653,21 @@ int allow_lds(rthip_ctx* ctx, K kernel, size_t bytes) {
 
 }  // namespace
 
+// How many workgroups of a persistent kernel the GPU holds at once (registers and LDS decide; asked of the runtime once
+// per kernel and LDS size): a persistent launch is that many workgroups, never more than the work.
+template <class K>
+uint32_t resident_blocks(rthip_ctx* ctx, K kernel, size_t lds) {
+    if (ctx->persistent_blocks_forced) return ctx->persistent_blocks;
+    for (const rthip_ctx::Resident& r : ctx->resident)
+        if (r.kernel == (const void*)kernel && r.lds == lds) return r.blocks;
+    int per_cu = 0;
+    uint32_t blocks = ctx->persistent_blocks;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, lds) == hipSuccess && per_cu >= 1) blocks = ctx->cus * (uint32_t)per_cu;
+    else (void)hipGetLastError();
+    ctx->resident.push_back({(const void*)kernel, lds, blocks});
+    return blocks;
+}
+
 int work_slot_take(rthip_ctx* ctx, hipStream_t stream, uint32_t** out_work, int* out_slot) {
     hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
     if (stream) (void)hipStreamIsCapturing(stream, &capturing);
@@ -695,7 +713,11 @@ int trace_rays_launch(rthip_ctx* ctx, const DevScene& scene, const float* d_o, c
     const bool resident = ctx->cast_mode == 0 || (ctx->cast_mode != 1 && ctx->cast_mode != 4 && scene_bytes <= (256ull << 20));
     if (n >= (1ull << 18) && n < (1ull << 32) * kRayGrab && resident) {
         uint32_t blocks = div_up(n, kBlock);
-        if (blocks > ctx->persistent_blocks) blocks = ctx->persistent_blocks;
+        const uint32_t held = fast ? (d_counters ? resident_blocks(ctx, trace_rays_persistent_kernel<true, true>, kFastLdsBytes)
+                                                 : resident_blocks(ctx, trace_rays_persistent_kernel<false, true>, kFastLdsBytes))
+                                   : (d_counters ? resident_blocks(ctx, trace_rays_persistent_kernel<true, false>, 0)
+                                                 : resident_blocks(ctx, trace_rays_persistent_kernel<false, false>, 0));
+        if (blocks > held) blocks = held;
         uint32_t* work = nullptr;  // a slot of zeroed counters: see work_slot_release
         int slot = -1;
         RT_TRY(work_slot_take(ctx, stream, &work, &slot));
@@ -849,11 +871,16 @@ int launch_samples(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_setti
 int launch_persistent(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_settings& cast, uint64_t seed, float* d_rgb,
                       int width, int height, rthip_shard shard, uint32_t refill, uint32_t inst_batch, uint64_t* d_counters,
                       hipStream_t stream) {
-    // persistent grid: as many workgroups as are resident at once (CUs x 5 at 96 VGPRs), never more than the work
+    // persistent grid: as many workgroups as are resident at once (resident_blocks), never more than the work
     const uint64_t total = (uint64_t)div_up(width, 8) * div_up(height, 8) * 64ull;
     uint32_t blocks = div_up(total, kBlock);
-    if (blocks > ctx->persistent_blocks) blocks = ctx->persistent_blocks;
     const size_t lds = (size_t)(scene.max_bounces ? scene.max_bounces : 1) * kBlock * sizeof(uint32_t);
+    const bool fast_walk = ctx->traversal == RTHIP_TRAV_FAST, batched = inst_batch != 0;
+    uint32_t held;
+    if (fast_walk) held = d_counters ? resident_blocks(ctx, cast_kernel<true, false, true>, lds + kFastLdsBytes) : resident_blocks(ctx, cast_kernel<false, false, true>, lds + kFastLdsBytes);
+    else if (batched) held = d_counters ? resident_blocks(ctx, cast_kernel<true, true>, lds) : resident_blocks(ctx, cast_kernel<false, true>, lds);
+    else held = d_counters ? resident_blocks(ctx, cast_kernel<true, false>, lds) : resident_blocks(ctx, cast_kernel<false, false>, lds);
+    if (blocks > held) blocks = held;
     // every launch gets its own set of 8 work counters (one 128-byte line each), so that casts enqueued back to back or
     // on several streams do not share them; a slot is taken only once its previous launch has finished, and is zero
     // when a launch starts (the ring is zeroed once, and every launch leaves its slot zeroed: work_slot_release)

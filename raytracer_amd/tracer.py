@@ -287,8 +287,8 @@ TRAVERSALS = {"exact": 0, "fast": 1}
 
 
 def set_traversal(tracer: RT_Tracer, mode: str) -> None:
-    """"exact": the reference's fixed left-before-right walk (default, bit-identical results); "fast": nearer child
-    first with a per-lane stack (see include/rthip.h at rthip_set_traversal)."""
+    """"exact": the reference's fixed left-before-right walk (default, bit-identical results); "fast": 4-wide records,
+    nearest box first, a per-lane stack (see include/rthip.h at rthip_set_traversal)."""
     tracer.check(tracer.lib.rthip_set_traversal(tracer.h, TRAVERSALS[mode]), "rthip_set_traversal")
 
 
