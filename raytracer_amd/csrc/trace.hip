@@ -1049,10 +1049,18 @@ int cast_launch(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_settings
     const uint64_t pixel_waves = (uint64_t)div_up(width, 8) * div_up(height, 8);
     if (choice.kernel == 4 && !by_samples_possible) choice.kernel = 1;
     if (ctx->cast_mode == 3 && fast) {
-        // The ordered walk's paths are shorter and more alike, and its step is longer: measured at 1920x1080, the
-        // pixel- / sample-per-lane kernels beat the persistent one on every workload (10 M-triangle soup 554 vs 415,
-        // 10 000 instances 805 vs 726, bunny-class 7508 vs 4758 Mrays/s), so no probe is needed.
-        choice.kernel = by_samples_possible ? 4 : 1;
+        // No probe for the ordered walk.  Measured at 1920x1080 (Mrays/s, four streams; persistent with refill 16 against
+        // the pixel- / sample-per-lane kernels): 10 000 instances 1329 vs 1031, 10 M-triangle soup 1509 vs 1374, height
+        // field 1340 vs 1249 -- deep scenes keep their long-tailed walks in this mode too -- but bunny-class 6308 vs 7498
+        // (one stream): short paths that are alike want the least bookkeeping per ray.
+        const uint64_t paths = (uint64_t)width * (uint64_t)height * cast.samples * cast.samples;
+        if (deep && paths >= (1ull << 20)) {
+            choice.kernel = 0;
+            choice.refill = 16;
+            choice.inst_batch = 0;
+        } else {
+            choice.kernel = by_samples_possible ? 4 : 1;
+        }
     } else if (ctx->cast_mode == 3 && by_samples_possible && pixel_waves < (deep ? 20480ull : 40000ull)) {
         choice.kernel = 4;
     } else if (ctx->cast_mode == 3) {

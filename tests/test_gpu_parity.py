@@ -452,6 +452,27 @@ def test_every_cast_kernel_gives_the_same_bits(oracle, gpu_tracer, kernel):
                 torch.cuda.synchronize()
                 want, _ = sc.cast(c, seed, wd, ht, rng_mode=oracle.RNG_COUNTER, shard=shard, threads=8)
                 assert (bits(buf.cpu().numpy()) == bits(want)).all(), f"{kernel}: shard {shard} differs"
+        # shard mode 3, bands of whole rows (150 rows in 2 bands of 128): a band's launch leaves the other rows alone, so
+        # the bands of one frame can be rendered into one buffer in any order
+        w, cam, sky = scenes.cornell()
+        build(gpu_tracer, w, 8, sky)
+        wd, ht = 70, 150
+        c = cam(wd, ht, 2)
+        want, _ = oracle.Scene(world.flatten_world(w), 8, sky).cast(c, 9, wd, ht, rng_mode=oracle.RNG_COUNTER, threads=8)
+        buf = torch.full((ht, wd, 3), 7.0, dtype=torch.float32, device="cuda:0")
+        for rank in (1, 0):
+            sh = np.zeros(1, dtype=abi.SHARD)
+            sh[0] = (3, rank, 2)
+            rc = gpu_tracer.lib.rthip_cast_device(gpu_tracer.h, abi.ptr(c), 9, buf.data_ptr(), wd, ht, abi.ptr(sh),
+                                                  torch.cuda.current_stream().cuda_stream)
+            gpu_tracer.check(rc, "rthip_cast_device")
+            torch.cuda.synchronize()
+            got = buf.cpu().numpy()
+            assert (bits(got[128:]) == bits(want[128:])).all(), f"{kernel}: band 1 differs"
+            if rank == 1:
+                assert (got[:128] == 7.0).all(), f"{kernel}: band 1 wrote into band 0's rows"
+            else:
+                assert (bits(got) == bits(want)).all(), f"{kernel}: band 0 differs"
         # max_bounces 0: black frame (raytracer_cpu.c:247-249)
         w, cam, sky = scenes.cornell()
         build(gpu_tracer, w, 0, sky)

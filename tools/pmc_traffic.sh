@@ -5,6 +5,9 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/pmc_traffic
 mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
+# rthip_cast into page-locked memory (the bench's host_cast figure) renders a frame as four launches of a quarter each:
+# one launch per frame here, so that the per-launch averages of the cast kernels are whole frames
+export RTHIP_CAST_BANDS=1
 # a workload named <name>+fast runs with --traversal fast
 for W in ${@:-bunny instanced soup cornell soup-rays instanced-rays cornell-mesh heightfield bunny+fast instanced+fast soup+fast soup-rays+fast instanced-rays+fast heightfield+fast}; do
   SIZES=""

@@ -110,6 +110,9 @@ def main():
         elif name == "heightfield":
             w, cam, sky = scenes.heightfield_world(2236, seed=1)
             bounces = 4
+        elif name == "heightfield3163":  # the same surface with twice the triangles (not in the default list)
+            w, cam, sky = scenes.heightfield_world(3163, seed=1)
+            bounces = 4
         tr = T.rt_make_tracer(T.RT_TracerSettings(max_bounces=bounces, sky=sky))
         T.rt_tracer_build_blas(tr, w)
         T.rt_tracer_build_tlas(tr, w)
@@ -135,6 +138,9 @@ def main():
             o, d = scenes.incoherent_rays_device(torch, 1 << 22, 2, (0.0, 0.0, 0.0), (1.0, 0.6, 1.0))
             rays_case(tr, o, d, "10M height field, 2^22 incoherent rays", out)
             frame_case(tr, cam, 1920, 1080, 1, "10M height field 1080p 1 spp 4 bounces", out, ("auto", "static", "persistent"))
+        elif name == "heightfield3163":
+            o, d = scenes.incoherent_rays_device(torch, 1 << 22, 2, (0.0, 0.0, 0.0), (1.0, 0.6, 1.0))
+            rays_case(tr, o, d, "20M height field (3163^2 cells), 2^22 incoherent rays", out)
         T.rt_tracer_cleanup(tr)
     with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "probe_fast.json"), "w") as f:
         json.dump(out, f, indent=1)
