@@ -146,7 +146,20 @@ def check_random_world(oracle, gpu_tracer, seed, kernels=("auto", "static", "per
         assert (inst == oi).all() and (tri == ot).all() and (bits(t) == bits(ott)).all(), f"closest hits differ ({int((inst != oi).sum())} ids)"
         assert (bits(uv) == bits(ouv)).all(), "uv differ"
         assert same_or_both_nan(nrm, onrm).all(), "normals differ"
-        assert (T.occluded(gpu_tracer, o, d, 4.0) == sc.occluded(o, d, 4.0)).all(), "occlusion differs"
+        occ = T.occluded(gpu_tracer, o, d, 4.0)
+        assert (occ == sc.occluded(o, d, 4.0)).all(), "occlusion differs"
+        # the ordered walk on the same rays (they are aimed at vertices and edges, so seams are common): never hit
+        # against miss, the same occlusion answers, the distance equal up to a seam's 1-2 ulp
+        T.set_traversal(gpu_tracer, "fast")
+        try:
+            finst, _, ft, _, _ = T.trace_rays(gpu_tracer, o, d)
+            focc = T.occluded(gpu_tracer, o, d, 4.0)
+        finally:
+            T.set_traversal(gpu_tracer, "exact")
+        assert ((finst != 0) == (inst != 0)).all(), "ordered walk: hit against miss"
+        assert (focc == occ).all(), "ordered walk: occlusion differs"
+        hit = inst != 0
+        assert np.allclose(ft[hit], t[hit], rtol=1e-6, atol=0.0), "ordered walk: another distance"
         rng = np.random.default_rng(seed)
         wd, ht, smp = int(rng.integers(8, 70)), int(rng.integers(8, 50)), int(rng.choice([1, 2, 2, 3, 4]))
         c = cam(wd, ht, smp)
