@@ -1664,54 +1664,52 @@ __global__ __launch_bounds__(kBlock) void wide_emit_kernel(const float4* __restr
     if (i >= n_nodes) return;
     const uint32_t my_rank = rank[i];
     if (rank[i + 1] == my_rank) return;  // no record: a leaf, or an inner node at odd depth
+    // The slots' nodes, left to right: a child that is a leaf stands for itself, an inner child for its two children.
+    // (Written with selects and fixed slots: an array filled at a running position would live in scratch memory.)
+    constexpr uint32_t kNone = 0xffffffffu;
+    const uint32_t c0 = i + 1;
+    const float4 c0b = nodes[2 * (uint64_t)c0 + 1];
+    const uint32_t c1 = __float_as_uint(c0b.z);  // the right child starts where the left child's subtree ends
+    const float4 c1b = nodes[2 * (uint64_t)c1 + 1];
+    const bool in0 = __float_as_uint(c0b.w) == 0u, in1 = __float_as_uint(c1b.w) == 0u;
+    const uint32_t l0 = c0 + 1, l1 = c1 + 1;  // left grandchildren (read only under an inner child)
+    const uint32_t r0 = in0 ? __float_as_uint(nodes[2 * (uint64_t)l0 + 1].z) : kNone;
+    const uint32_t r1 = in1 ? __float_as_uint(nodes[2 * (uint64_t)l1 + 1].z) : kNone;
+    const uint32_t first1 = in1 ? l1 : c1;  // the first slot of the right child
+    uint32_t node[4];
+    node[0] = in0 ? l0 : c0;
+    node[1] = in0 ? r0 : first1;
+    node[2] = in0 ? first1 : (in1 ? r1 : kNone);
+    node[3] = (in0 && in1) ? r1 : kNone;
     const float inf = __uint_as_float(0x7f800000u);
-    float4 xy[4], zz[2];
-    uint32_t ref[4], bin[4];
+    float4 xy[4];
+    float zlo[4], zhi[4];
+    uint32_t ref[4];
+#pragma unroll
     for (int k = 0; k < 4; k++) {
         xy[k] = make_float4(inf, inf, inf, inf);
-        ref[k] = 0xffffffffu;
-        bin[k] = 0u;
-    }
-    zz[0] = zz[1] = make_float4(inf, inf, inf, inf);
-    int slots = 0;
-    auto put = [&](const float4 a, const float4 b, uint32_t node) {
-        const uint32_t id = __float_as_uint(b.w);
-        xy[slots] = a;
-        if (slots & 1) {
-            zz[slots >> 1].z = b.x;
-            zz[slots >> 1].w = b.y;
+        zlo[k] = zhi[k] = inf;
+        ref[k] = kNone;
+        if (node[k] != kNone) {
+            const float4 a = nodes[2 * (uint64_t)node[k]], b = nodes[2 * (uint64_t)node[k] + 1];
+            const uint32_t id = __float_as_uint(b.w);
+            xy[k] = a;
+            zlo[k] = b.x;
+            zhi[k] = b.y;
+            ref[k] = id ? (0x80000000u | id) : rank[node[k]];
         } else {
-            zz[slots >> 1].x = b.x;
-            zz[slots >> 1].y = b.y;
+            node[k] = 0u;
         }
-        ref[slots] = id ? (0x80000000u | id) : rank[node];
-        bin[slots] = node;
-        slots++;
-    };
-    uint32_t child = i + 1;
-    for (int c = 0; c < 2; c++) {
-        const float4 ca = nodes[2 * (uint64_t)child], cb = nodes[2 * (uint64_t)child + 1];
-        if (__float_as_uint(cb.w) != 0u) {
-            put(ca, cb, child);
-        } else {
-            const uint32_t gl = child + 1;
-            const float4 la = nodes[2 * (uint64_t)gl], lb = nodes[2 * (uint64_t)gl + 1];
-            const uint32_t gr = __float_as_uint(lb.z);
-            const float4 ra = nodes[2 * (uint64_t)gr], rb = nodes[2 * (uint64_t)gr + 1];
-            put(la, lb, gl);
-            put(ra, rb, gr);
-        }
-        child = __float_as_uint(cb.z);  // the right child starts where the left child's subtree ends
     }
     float4* out = wide + 8 * (uint64_t)my_rank;
     out[0] = xy[0];
     out[1] = xy[1];
     out[2] = xy[2];
     out[3] = xy[3];
-    out[4] = zz[0];
-    out[5] = zz[1];
+    out[4] = make_float4(zlo[0], zhi[0], zlo[1], zhi[1]);
+    out[5] = make_float4(zlo[2], zhi[2], zlo[3], zhi[3]);
     out[6] = make_float4(__uint_as_float(ref[0]), __uint_as_float(ref[1]), __uint_as_float(ref[2]), __uint_as_float(ref[3]));
-    out[7] = make_float4(__uint_as_float(bin[0]), __uint_as_float(bin[1]), __uint_as_float(bin[2]), __uint_as_float(bin[3]));
+    out[7] = make_float4(__uint_as_float(node[0]), __uint_as_float(node[1]), __uint_as_float(node[2]), __uint_as_float(node[3]));
 }
 
 inline uint32_t div_up(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
