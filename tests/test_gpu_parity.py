@@ -1145,6 +1145,25 @@ def test_fast_traversal_on_a_tree_deeper_than_its_stack(gpu_tracer, level):
         T.set_traversal(gpu_tracer, "exact")
 
 
+def test_fast_traversal_with_a_long_bounce_stack(oracle, gpu_tracer):
+    """40 bounces: the bounce stack (40 KB) and the ordered walk's stacks (32 KB) together pass the 64 KB of dynamic LDS
+    a launch gets without asking; every kernel must still start, and the Cornell frame is the exact walk's."""
+    w, cam, sky = scenes.cornell()
+    build(gpu_tracer, w, 40, sky)
+    c = cam(48, 40, 2)
+    want, _ = oracle.Scene(world.flatten_world(w), 40, sky).cast(c, 6, 48, 40, rng_mode=oracle.RNG_COUNTER, threads=8)
+    T.set_traversal(gpu_tracer, "fast")
+    try:
+        for kernel in ("static", "static-samples", "persistent"):
+            T.set_cast_kernel(gpu_tracer, kernel)
+            img = np.zeros((40, 48, 3), dtype=np.float32)
+            T.rt_tracer_cast(gpu_tracer, c, img, 48, 40, seed=6)
+            assert (bits(img) == bits(want)).all(), kernel
+    finally:
+        T.set_cast_kernel(gpu_tracer, "auto")
+        T.set_traversal(gpu_tracer, "exact")
+
+
 def test_occlusion_rays(oracle, gpu_tracer):
     """Shadow rays (any-hit walk) against the reference's interval-limited query, and against the
     oracle on an instanced scene with random rays and several tmax."""
