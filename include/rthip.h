@@ -214,11 +214,12 @@ int rthip_tlas_build(rthip_ctx* ctx, const rthip_instance* instances, uint32_t n
  * sample, draw index), so the image does not depend on scheduling or GPU count. */
 int rthip_cast(rthip_ctx* ctx, const rthip_cast_settings* cast, uint64_t seed, float* out_rgb, int width, int height);
 
-/* Optional: page-locked host memory for the framebuffer (hipHostMalloc).  rthip_cast copies the frame into ordinary
- * (pageable) memory through the runtime's staging copies; into a buffer from rthip_host_alloc it goes by DMA at the
- * link's rate (1920x1080 floats: 1.4 ms -> 0.45 ms for the copy), and frames of 2^19 pixels or more are rendered in
- * four bands of rows (rthip_shard mode 3; RTHIP_CAST_BANDS=1..8), each on a stream of its own with its copy behind it,
- * so that finished rows travel while the rest renders (the whole call 0.83 -> 0.71 ms).  Free with rthip_host_free, or implicitly by
+/* Optional: page-locked host memory for the framebuffer (hipHostMalloc).  rthip_cast renders frames of 2^19 pixels or
+ * more in four bands of rows (rthip_shard mode 3; RTHIP_CAST_BANDS=1..8), each on a stream of its own with its copy
+ * behind it, so that finished rows travel while the rest renders.  Into a buffer from rthip_host_alloc the bands go by
+ * DMA at the link's rate (a 1920x1080 call: 0.72 ms); into ordinary (pageable) memory they go by DMA into page-locked
+ * staging of the context and from there by host threads, two per band (0.95 ms; the runtime's own staged copy of the
+ * whole frame, which RTHIP_CAST_BANDS=1 keeps, makes it 1.85 ms).  Free with rthip_host_free, or implicitly by
  * rthip_destroy.  No counterpart in the reference (its framebuffer is arena memory and never leaves the CPU,
  * src/demos/cornell/main.c:214, raytracer_cpu.c:190-192); page-locking the caller's own allocation (hipHostRegister)
  * is not offered because not every host allows it. */

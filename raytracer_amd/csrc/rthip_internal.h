@@ -144,6 +144,8 @@ struct rthip_ctx {
     hipStream_t band_copy_stream[kMaxBands] = {};
     hipEvent_t band_done[kMaxBands] = {};
     int cast_bands = 4;  // RTHIP_CAST_BANDS; 1 = one launch, one copy
+    void* host_stage = nullptr;  // page-locked staging for rthip_cast into pageable memory (grown on demand)
+    size_t host_stage_bytes = 0;
 
     LbvhWorkspace ws;
     LbvhWorkspace ws_static;  // the same arrays carved out of the device's static scratch array (lbvh_static_workspace_init)

@@ -1,5 +1,6 @@
 """rthip_cast (the call behind rt_tracer_cast: a frame into the caller's host buffer) on the default 1080p frame: into
-pageable memory, and into page-locked memory from rthip_host_alloc in 1, 2, 4 and 8 bands of rows (RTHIP_CAST_BANDS).
+pageable memory and into page-locked memory from rthip_host_alloc, each in 1, 2, 4 and 8 bands of rows (RTHIP_CAST_BANDS;
+1 band = one launch and one copy, into pageable memory the runtime's own staged copy).
 Run on the GPU box: python3 tools/probe_host_cast.py"""
 import os
 import sys
@@ -37,8 +38,8 @@ def run(bands, pinned, traversal="exact", reps=30):
 
 
 for traversal in ("exact", "fast"):
-    ms, k, chk = run(1, False, traversal)
-    print(f"{traversal}: pageable            {ms:.3f} ms per call (render {k:.3f} ms)  checksum {chk:.6f}", flush=True)
-    for bands in (1, 2, 4, 8):
-        ms, k, chk = run(bands, True, traversal)
-        print(f"{traversal}: page-locked, {bands} band(s) {ms:.3f} ms per call (render {k:.3f} ms)  checksum {chk:.6f}", flush=True)
+    for pinned in (False, True):
+        for bands in (1, 2, 4, 8):
+            ms, k, chk = run(bands, pinned, traversal)
+            kind = "page-locked" if pinned else "pageable   "
+            print(f"{traversal}: {kind}, {bands} band(s) {ms:.3f} ms per call (render {k:.3f} ms)  checksum {chk:.6f}", flush=True)
