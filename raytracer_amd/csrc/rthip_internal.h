@@ -143,6 +143,8 @@ struct rthip_ctx {
     hipStream_t band_stream[kMaxBands] = {};
     hipStream_t band_copy_stream[kMaxBands] = {};
     hipEvent_t band_done[kMaxBands] = {};
+    static constexpr int kBandChunks = 4;    // a band's copy into staging goes in this many pieces, each with an event
+    hipEvent_t chunk_done[kMaxBands * kBandChunks] = {};
     int cast_bands = 4;  // RTHIP_CAST_BANDS; 1 = one launch, one copy
     void* host_stage = nullptr;  // page-locked staging for rthip_cast into pageable memory (grown on demand)
     size_t host_stage_bytes = 0;
