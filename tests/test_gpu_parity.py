@@ -729,6 +729,27 @@ def test_cornell_with_mesh_scene(oracle, gpu_tracer):
     want, _ = sc.cast(c, 11, wd, ht, rng_mode=oracle.RNG_COUNTER, threads=8)
     assert (bits(img) == bits(want)).all()
     assert float(img.mean()) > 0.01  # the light is seen
+    # the configuration's 1024 samples per pixel (samples = 32) on a handful of pixels, whole and as a sample shard
+    wd, ht, smp = 8, 6, 32
+    c = cam(wd, ht, smp)
+    want, _ = sc.cast(c, 12, wd, ht, rng_mode=oracle.RNG_COUNTER, threads=8)
+    try:
+        for kernel in ("auto", "static", "persistent"):
+            T.set_cast_kernel(gpu_tracer, kernel)
+            img = np.zeros((ht, wd, 3), dtype=np.float32)
+            T.rt_tracer_cast(gpu_tracer, c, img, wd, ht, seed=12)
+            assert (bits(img) == bits(want)).all(), kernel
+    finally:
+        T.set_cast_kernel(gpu_tracer, "auto")
+    import torch
+    part, _ = sc.cast(c, 12, wd, ht, rng_mode=oracle.RNG_COUNTER, shard=(2, 5, 8), threads=8)
+    buf = torch.zeros((ht, wd, 3), dtype=torch.float32, device="cuda:0")
+    sh = np.zeros(1, dtype=abi.SHARD)
+    sh[0] = (2, 5, 8)
+    gpu_tracer.check(gpu_tracer.lib.rthip_cast_device(gpu_tracer.h, abi.ptr(c), 12, buf.data_ptr(), wd, ht, abi.ptr(sh),
+                                                      torch.cuda.current_stream().cuda_stream), "rthip_cast_device")
+    torch.cuda.synchronize()
+    assert (bits(buf.cpu().numpy()) == bits(part)).all(), "sample shard 5 of 8 at 1024 spp"
 
 
 def test_auto_kernel_choice_changes_no_bit(gpu_tracer):
