@@ -218,7 +218,7 @@ int rthip_cast(rthip_ctx* ctx, const rthip_cast_settings* cast, uint64_t seed, f
  * more in four bands of rows (rthip_shard mode 3; RTHIP_CAST_BANDS=1..8), each on a stream of its own with its copy
  * behind it, so that finished rows travel while the rest renders.  Into a buffer from rthip_host_alloc the bands go by
  * DMA at the link's rate (a 1920x1080 call: 0.72 ms); into ordinary (pageable) memory they go by DMA into page-locked
- * staging of the context, a quarter of a band at a time, and from there by host threads, two per band (0.83 ms; the runtime's own staged copy of the
+ * staging of the context, a quarter of a band at a time, and from there by host threads, two per band (0.82 ms; the runtime's own staged copy of the
  * whole frame, which RTHIP_CAST_BANDS=1 keeps, makes it 1.85 ms).  Free with rthip_host_free, or implicitly by
  * rthip_destroy.  No counterpart in the reference (its framebuffer is arena memory and never leaves the CPU,
  * src/demos/cornell/main.c:214, raytracer_cpu.c:190-192); page-locking the caller's own allocation (hipHostRegister)

@@ -7,8 +7,6 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include <thread>
-
 #include "rthip_internal.h"
 
 int rthip_fail(rthip_ctx* ctx, int code, const char* fmt, ...) {
@@ -117,6 +115,47 @@ int convert_tlas_wide(rthip_ctx* ctx) {
 
 }  // namespace
 
+void HostPool::start(uint32_t n, int device) {
+    for (uint32_t i = 0; i < n; i++)
+        threads.emplace_back([this, device] {
+            (void)hipSetDevice(device);
+            uint64_t seen = 0;
+            for (;;) {
+                std::unique_lock<std::mutex> lock(m);
+                wake.wait(lock, [&] { return stop || generation != seen; });
+                if (stop) return;
+                seen = generation;
+                while (next < pieces) {
+                    const uint32_t mine = next++;
+                    lock.unlock();
+                    job(mine);
+                    lock.lock();
+                    if (++finished == pieces) done.notify_all();
+                }
+            }
+        });
+}
+
+void HostPool::run(uint32_t n_pieces, std::function<void(uint32_t)> fn) {
+    std::unique_lock<std::mutex> lock(m);
+    job = std::move(fn);
+    pieces = n_pieces;
+    next = 0;
+    finished = 0;
+    generation++;
+    wake.notify_all();
+    done.wait(lock, [&] { return finished == pieces; });
+}
+
+HostPool::~HostPool() {
+    {
+        std::lock_guard<std::mutex> lock(m);
+        stop = true;
+    }
+    wake.notify_all();
+    for (std::thread& t : threads) t.join();
+}
+
 extern "C" {
 
 int rthip_abi_version(void) { return RTHIP_ABI_VERSION; }
@@ -200,6 +239,8 @@ void rthip_destroy(rthip_ctx* ctx) {
     for (DevBuf& b : ctx->wf) rthip_release(b);
     for (hipEvent_t e : ctx->slot_done)
         if (e) (void)hipEventDestroy(e);
+    delete ctx->movers;
+    ctx->movers = nullptr;
     if (ctx->host_stage) (void)hipHostFree(ctx->host_stage);
     for (hipStream_t b : ctx->band_stream)
         if (b) (void)hipStreamDestroy(b);
@@ -677,22 +718,21 @@ int rthip_cast(rthip_ctx* ctx, const rthip_cast_settings* cast, uint64_t seed, f
             // buffer (measured at 1920x1080 with four bands, whole bands per thread: 1.02 ms per call with one thread per
             // band, 0.95 with two, 0.93 with four)
             constexpr uint32_t per_band = 2u;
-            hipError_t status[rthip_ctx::kMaxBands * per_band];
-            std::thread movers[rthip_ctx::kMaxBands * per_band];
-            for (uint32_t t = 0; t < used * per_band; t++) {
-                status[t] = hipSuccess;
-                movers[t] = std::thread([&, t] {
-                    const uint32_t k = t / per_band;
-                    status[t] = hipSetDevice(ctx->device);
-                    for (uint32_t c = t % per_band; c < kChunks && status[t] == hipSuccess; c += per_band) {
-                        const size_t first = (size_t)c * piece[k];
-                        const size_t n = first >= count[k] ? 0 : (count[k] - first < piece[k] ? count[k] - first : piece[k]);
-                        status[t] = hipEventSynchronize(ctx->chunk_done[k * kChunks + c]);
-                        if (status[t] == hipSuccess && n) memcpy(out_rgb + off[k] + first, landing + off[k] + first, n * sizeof(float));
-                    }
-                });
+            if (!ctx->movers) {
+                ctx->movers = new HostPool;
+                ctx->movers->start((uint32_t)ctx->cast_bands * per_band, ctx->device);
             }
-            for (uint32_t t = 0; t < used * per_band; t++) movers[t].join();
+            hipError_t status[rthip_ctx::kMaxBands * per_band];
+            for (uint32_t t = 0; t < used * per_band; t++) status[t] = hipSuccess;
+            ctx->movers->run(used * per_band, [&](uint32_t t) {
+                const uint32_t k = t / per_band;
+                for (uint32_t c = t % per_band; c < kChunks && status[t] == hipSuccess; c += per_band) {
+                    const size_t first = (size_t)c * piece[k];
+                    const size_t n = first >= count[k] ? 0 : (count[k] - first < piece[k] ? count[k] - first : piece[k]);
+                    status[t] = hipEventSynchronize(ctx->chunk_done[k * kChunks + c]);
+                    if (status[t] == hipSuccess && n) memcpy(out_rgb + off[k] + first, landing + off[k] + first, n * sizeof(float));
+                }
+            });
             for (uint32_t t = 0; t < used * per_band; t++) RT_HIP(ctx, status[t]);
         }
         RT_HIP(ctx, hipStreamSynchronize(ctx->stream));

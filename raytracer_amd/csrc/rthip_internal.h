@@ -6,6 +6,10 @@
 #include <stdint.h>
 
 #include <string>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "rthip.h"
@@ -121,6 +125,21 @@ constexpr uint32_t kEagerSlots = 64;
 constexpr uint32_t kCaptureSlots = 192;
 constexpr uint32_t kWorkSlots = kEagerSlots + kCaptureSlots;
 
+// Host threads that stay with a context and run the pieces of a job handed to them (rthip_cast's movers: started once,
+// so that a call pays a wake-up instead of eight thread starts).
+struct HostPool {
+    std::vector<std::thread> threads;
+    std::mutex m;
+    std::condition_variable wake, done;
+    std::function<void(uint32_t)> job;
+    uint64_t generation = 0;
+    uint32_t pieces = 0, next = 0, finished = 0;
+    bool stop = false;
+    void start(uint32_t n, int device);
+    void run(uint32_t n_pieces, std::function<void(uint32_t)> fn);  // returns when every piece has run
+    ~HostPool();
+};
+
 struct rthip_ctx {
     int device = 0;
     std::string err;
@@ -147,6 +166,7 @@ struct rthip_ctx {
     hipEvent_t chunk_done[kMaxBands * kBandChunks] = {};
     int cast_bands = 4;  // RTHIP_CAST_BANDS; 1 = one launch, one copy
     void* host_stage = nullptr;  // page-locked staging for rthip_cast into pageable memory (grown on demand)
+    HostPool* movers = nullptr;  // the threads that move staged bands into the caller's buffer (started at first use)
     size_t host_stage_bytes = 0;
 
     LbvhWorkspace ws;
