@@ -1247,6 +1247,39 @@ def test_cast_into_page_locked_host_memory(gpu_tracer):
         T.set_cast_kernel(gpu_tracer, "auto")
 
 
+def test_host_buffer_casts_of_changing_sizes_and_contexts(gpu_tracer):
+    """rthip_cast into pageable memory goes through page-locked staging and a pool of host threads that the context
+    keeps: frames that grow and shrink (the staging is regrown), small frames in between (one launch, one copy), pageable
+    and page-locked buffers in turn, and contexts that are destroyed with their pool; every frame against the same
+    frame rendered into device memory."""
+    import torch
+
+    verts, indices = scenes.bunny_class_mesh(3)
+    w, cam, sky = scenes.bunny(verts, indices)
+    for _ in range(2):  # two contexts, one after the other: the first one's threads and staging go with it
+        tr = T.rt_make_tracer(T.RT_TracerSettings(max_bounces=2, sky=sky))
+        try:
+            T.rt_tracer_build_blas(tr, w)
+            T.rt_tracer_build_tlas(tr, w)
+            for wd, ht in ((1024, 512), (300, 200), (1920, 1080), (1024, 600), (64, 64), (2048, 1100)):
+                c = cam(wd, ht, 1)
+                dev = torch.zeros((ht, wd, 3), dtype=torch.float32, device="cuda:0")
+                tr.check(tr.lib.rthip_cast_device(tr.h, abi.ptr(c), 21, dev.data_ptr(), wd, ht, None,
+                                                  torch.cuda.current_stream().cuda_stream), "rthip_cast_device")
+                torch.cuda.synchronize()
+                want = dev.cpu().numpy()
+                img = np.full((ht, wd, 3), -1.0, dtype=np.float32)
+                T.rt_tracer_cast(tr, c, img, wd, ht, seed=21)
+                assert (bits(img) == bits(want)).all(), ("pageable", wd, ht)
+                pinned = T.host_alloc(tr, (ht, wd, 3))
+                pinned[:] = -1.0
+                T.rt_tracer_cast(tr, c, pinned, wd, ht, seed=21)
+                assert (bits(pinned) == bits(want)).all(), ("page-locked", wd, ht)
+                T.host_free(tr, pinned)
+        finally:
+            T.rt_tracer_cleanup(tr)
+
+
 def test_group_of_contexts_renders_the_single_context_frame(gpu_tracer):
     """rthip_group_*: several contexts (here on one GPU) behind one handle.  Tiles: each context renders and ships only its
     own 64x64 tiles and the frame is the single context's bit for bit, into host memory and into device memory; samples:
