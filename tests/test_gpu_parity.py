@@ -986,7 +986,7 @@ def test_ten_million_triangle_soup_incoherent_rays(oracle, gpu_tracer):
         head, st = run(m, counting=True)
         assert torch.equal(head, plain[:m])
         # the opt-in ordered walk on the same stream: the same distance bit for bit on every ray; another primitive only
-        # where two lie at exactly that distance (the reference reports the last one it visits); a third fewer box tests
+        # where two lie at exactly that distance (the reference reports the last one it visits); fewer box tests
         T.set_traversal(gpu_tracer, "fast")
         fast, fst = run(n, counting=True)
         assert torch.equal(fast[:, 2], plain[:, 2]), f"{int((fast[:, 2] != plain[:, 2]).sum())} rays at another distance"
@@ -1034,7 +1034,7 @@ def fast_vs_exact_rays(gpu_tracer, o, d):
 
 
 def test_fast_traversal_against_the_exact_walk(oracle, gpu_tracer):
-    """RTHIP_TRAV_FAST (nearer child first, stack in LDS) against the reference's walk.  Pinned: on the reference's own
+    """RTHIP_TRAV_FAST (4-wide records, nearest box first, stack in LDS) against the reference's walk.  Pinned: on the reference's own
     scenes every primary ray gets the same primitive at the same distance; on incoherent rays through deep scenes the
     distance is equal bit for bit and at most a handful of rays report another primitive at that same distance."""
     g = golden("demo_cornell")
