@@ -1166,6 +1166,14 @@ struct ClimbArgs {
     uint32_t* starters;        // gaps of the nodes that span chunks and got both children from the local kernel
     uint32_t* start_count;
     float4* nodes;             // the pre-order records
+    // the climb above the chunks by leaf ranges (range_upper_kernel; builds of up to kOneGroupUpper leaves): no child
+    // records, counters or start list, their buffers hold these instead
+    float* pre_box;            // float[6n]: per leaf, the box of the leaves from its chunk's first leaf up to it
+    float* suf_box;            // float[6n]: per leaf, the box of the leaves from it to its chunk's last leaf
+    uint16_t* tab;             // per chunk 256 entries: [q] the rightmost window entry in 0 .. kChunk-1 with a priority below q,
+                               // [128 + q] the leftmost window entry in 1 .. kChunk with a priority below q (0xffff: none)
+    uint8_t* cmin;             // per chunk 2 bytes: the smallest priority among window entries 0 .. kChunk-1, and among 1 .. kChunk
+    uint32_t ranges;           // 1: this form
 };
 
 #ifdef RT_CLIMB_STAMP
@@ -1222,7 +1230,7 @@ __device__ __forceinline__ void leaf_box(uint32_t c0, const ClimbArgs& A, const 
 }
 
 // Which gaps of the chunk are local.  Ends with a barrier.
-__device__ __forceinline__ void chunk_window(ClimbLds& L, const LeafIn& in) {
+__device__ __forceinline__ void chunk_window(ClimbLds& L, const LeafIn& in, uint32_t* min_before = nullptr, uint32_t* min_after = nullptr) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     if (tid == 0) {
         L.qn[0] = L.qn[1] = L.qn[2] = 0;
@@ -1252,6 +1260,8 @@ __device__ __forceinline__ void chunk_window(ClimbLds& L, const LeafIn& in) {
     if (lane > 0) before = pl < before ? pl : before;
     if (lane < 63) after = sr < after ? sr : after;
     const bool loc = tid >= 1 && e > before && e > after;
+    if (min_before) *min_before = before;  // over the window's entries 0 .. tid-1 (0xff: none)
+    if (min_after) *min_after = after;     // over the entries tid+1 .. kChunk
     L.win[tid] = (uint8_t)(e | (loc ? 0x80u : 0u));
     __syncthreads();
 }
@@ -1301,13 +1311,13 @@ __device__ __forceinline__ void arrive(ClimbLds& L, uint32_t c0, const ClimbArgs
             mine.lefts = lefts | ((parent_right ? pr_l : pr_r) << 16);
             L.lrec[2 * where + side] = mine;
             queued = atomicAdd(&L.lflag[where], 1u) == 1u;  // the records are read after the next barrier
-        } else {
+        } else if (!A.ranges) {
             const uint32_t far_prio = (parent_right ? pr_l : pr_r) & 0x7fu;  // of the gap beyond the far end
             mine.lefts = lefts | (far_prio << 16);
             A.child[2 * (uint64_t)parent + side] = mine;
             where = parent + 1u - c0;
             noted = true;
-        }
+        }  // (with ranges the nodes above the chunks take their boxes from the leaves' prefix / suffix boxes)
     }
     wave_push(queued, where, &L.qn[next_q], L.queue[next_q]);
     wave_push(noted, where, &L.n_pend, L.pend);
@@ -1368,6 +1378,7 @@ __device__ __forceinline__ void chunk_climb(ClimbLds& L, uint32_t c0, const Clim
         clr = t;
     }
     CLIMB_STAMP(3);
+    if (A.ranges) return;
     // The parents that span chunks: count this chunk's records there (all at once: a counter in HBM takes microseconds
     // to answer); where it was the second to arrive the parent is complete and goes on the upper kernel's list, with
     // one device-wide atomic per chunk.
@@ -1391,13 +1402,150 @@ __device__ __forceinline__ void chunk_climb(ClimbLds& L, uint32_t c0, const Clim
     }
 }
 
-template <bool PAIRED>
+// What the range form of the climb above the chunks needs from a chunk (see range_upper_kernel): every leaf's prefix
+// and suffix box inside the chunk, the chunk's two tables of "nearest gap with a priority below q", and the list of
+// the chunk's gaps whose nodes reach beyond it.  Window entry k is gap c0 - 1 + k (chunk_window); a gap beyond the
+// array's ends has priority 0, below every real one, and so ends every search.  Call after chunk_window, by all threads.
+__device__ __forceinline__ void merge_after(float* acc, const float* later) { merge_sibling(acc, later, true); }
+__device__ __forceinline__ void chunk_ranges(ClimbLds& L, uint32_t c0, const ClimbArgs& A, const float* box, uint32_t min_before,
+                                             uint32_t min_after) {
+    const uint32_t n = A.n, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t chunk = c0 / (uint32_t)kChunk;
+    const float inf = __uint_as_float(0x7f800000u);
+    __shared__ float wtot[2][kChunk / 64][6];  // per wave: box of its leaves, for the prefix and for the suffix scan
+    __shared__ uint16_t tab[256];
+    __shared__ uint32_t bestA[128], bestB[128], cmins[2];
+    // ---- boxes: inclusive scans in leaf order, the earlier leaf always the first operand
+    float mine[6], pre[6], suf[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) mine[k] = (c0 + tid < n) ? box[k] : (k < 3 ? inf : -inf);
+#pragma unroll
+    for (int k = 0; k < 6; k++) pre[k] = suf[k] = mine[k];
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        float up[6], down[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            up[k] = __shfl_up(pre[k], o);
+            down[k] = __shfl_down(suf[k], o);
+        }
+        if (lane >= (uint32_t)o) {  // pre = (leaves before) then (pre)
+            merge_after(up, pre);
+#pragma unroll
+            for (int k = 0; k < 6; k++) pre[k] = up[k];
+        }
+        if (lane + (uint32_t)o < 64u) merge_after(suf, down);
+    }
+    if (lane == 63u)
+#pragma unroll
+        for (int k = 0; k < 6; k++) wtot[0][wave][k] = pre[k];
+    if (lane == 0u)
+#pragma unroll
+        for (int k = 0; k < 6; k++) wtot[1][wave][k] = suf[k];
+    if (tid < 128u) {
+        bestA[tid] = 0u;
+        bestB[tid] = 0xffffu;
+    }
+    if (tid < 2u) cmins[tid] = 0xffu;
+    __syncthreads();
+    {
+        float acc[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) acc[k] = k < 3 ? inf : -inf;
+        for (uint32_t w = 0; w < wave; w++) merge_after(acc, wtot[0][w]);
+        merge_after(acc, pre);
+#pragma unroll
+        for (int k = 0; k < 6; k++) pre[k] = acc[k];
+        for (uint32_t w = wave + 1; w < (uint32_t)kChunk / 64u; w++) merge_after(suf, wtot[1][w]);
+    }
+    if (c0 + tid < n) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            A.pre_box[6 * (uint64_t)(c0 + tid) + k] = pre[k];
+            A.suf_box[6 * (uint64_t)(c0 + tid) + k] = suf[k];
+        }
+    }
+    // ---- tables.  Thread t looks at window entry t (0 .. kChunk-1); entry kChunk has no thread, thread 0 sees to it.
+    // rightmost entry below q = the largest position among the entries with priority + 1 <= q: every entry marks
+    // best[priority + 1] with its position, a prefix maximum over the 128 slots does the rest (leftmost: minimum).
+    const uint32_t e = (uint32_t)L.win[tid] & 0x7fu;          // entry tid
+    const uint32_t e_end = (uint32_t)L.win[kChunk] & 0x7fu;  // entry kChunk
+    if (e < 127u) {
+        atomicMax(&bestA[e + 1u], tid + 1u);                       // among entries 0 .. kChunk-1; 0 = none
+        if (tid >= 1u) atomicMin(&bestB[e + 1u], tid);             // among entries 1 .. kChunk; 0xffff = none
+    }
+    if (tid == 0u && e_end < 127u) atomicMin(&bestB[e_end + 1u], (uint32_t)kChunk);
+    __syncthreads();
+    if (wave < 2u) {  // wave 0: prefix maximum of bestA, wave 1: prefix minimum of bestB, two slots per lane
+        uint32_t* best = wave == 0u ? bestA : bestB;
+        uint32_t a = best[2u * lane], b = best[2u * lane + 1u];
+        b = wave == 0u ? (a > b ? a : b) : (a < b ? a : b);
+        uint32_t run = b;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t u = __shfl_up(run, o);
+            if (lane >= (uint32_t)o) run = wave == 0u ? (u > run ? u : run) : (u < run ? u : run);
+        }
+        const uint32_t prev = __shfl_up(run, 1);
+        if (lane > 0u) a = wave == 0u ? (prev > a ? prev : a) : (prev < a ? prev : a);
+        if (wave == 0u) {
+            tab[2u * lane] = a ? (uint16_t)(a - 1u) : (uint16_t)0xffffu;
+            tab[2u * lane + 1u] = run ? (uint16_t)(run - 1u) : (uint16_t)0xffffu;
+        } else {
+            tab[128u + 2u * lane] = (uint16_t)a;
+            tab[128u + 2u * lane + 1u] = (uint16_t)run;
+        }
+    }
+    // the smallest priorities: among the entries 0 .. kChunk-1, and among 1 .. kChunk
+    uint32_t mA = e, mB = tid == 0u ? e_end : e;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t x = __shfl_xor(mA, o), y = __shfl_xor(mB, o);
+        mA = x < mA ? x : mA;
+        mB = y < mB ? y : mB;
+    }
+    if (lane == 0u) {
+        atomicMin(&cmins[0], mA);
+        atomicMin(&cmins[1], mB);
+    }
+    __syncthreads();
+    if (tid < 256u) A.tab[256u * chunk + tid] = tab[tid];
+    if (tid < 2u) A.cmin[2u * chunk + tid] = (uint8_t)cmins[tid];
+    // ---- the gaps whose nodes reach beyond the chunk: entries 1 .. kChunk-1 that are not local, and entry kChunk.
+    // List word: the gap, its priority in bits 17-23, bit 30: a smaller priority among the entries before it in the
+    // window, bit 31: among those after it.
+    {
+        const uint64_t gap = (uint64_t)c0 - 1u + tid;
+        const bool exists = tid >= 1u && gap + 1u < n;
+        const bool upper = exists && (L.win[tid] & 0x80u) == 0u;
+        wave_push(upper, tid | (min_before < e ? 0x4000u : 0u) | (min_after < e ? 0x8000u : 0u), &L.n_start, L.stage);
+    }
+    lds_barrier();
+    const uint32_t total = L.n_start;
+    const uint64_t end_gap = (uint64_t)c0 - 1u + kChunk;
+    const bool end_exists = end_gap + 1u < n;
+    if (tid < 64u) {
+        uint32_t base = 0;
+        if (lane == 0u) base = atomicAdd(A.start_count, total + (end_exists ? 1u : 0u));
+        base = __shfl(base, 0);
+        for (uint32_t k = lane; k < total; k += 64u) {
+            const uint32_t v = L.stage[k], entry = v & 0x3fffu;
+            A.starters[base + k] = (c0 - 1u + entry) | (((uint32_t)L.win[entry] & 0x7fu) << 17) | ((v & 0xc000u) << 16);
+        }
+        if (lane == 0u && end_exists) A.starters[base + total] = (uint32_t)end_gap | (e_end << 17) | (cmins[0] < e_end ? 0x40000000u : 0u);
+    }
+    lds_barrier();
+    if (tid == 0u) L.n_start = 0;
+}
+
+template <bool PAIRED, bool RANGES = false>
 __global__ __launch_bounds__(kChunk) void climb_local_kernel(ClimbArgs A) {
     __shared__ ClimbLds L;
     const uint32_t c0 = blockIdx.x * (uint32_t)kChunk;
     CLIMB_STAMP(0);
     const LeafIn in = leaf_in(c0, A);
-    chunk_window(L, in);
+    uint32_t min_before = 0xffu, min_after = 0xffu;
+    chunk_window(L, in, &min_before, &min_after);
     CLIMB_STAMP(1);
     float box[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     leaf_box(c0, A, in, box);
@@ -1405,6 +1553,7 @@ __global__ __launch_bounds__(kChunk) void climb_local_kernel(ClimbArgs A) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     CLIMB_STAMP(2);
 #endif
+    if constexpr (RANGES) chunk_ranges(L, c0, A, box, min_before, min_after);  // its LDS exists in this instance only
     chunk_climb<PAIRED>(L, c0, A, in, box);
     CLIMB_STAMP(4);
 #ifdef RT_CLIMB_STAMP
@@ -1478,6 +1627,108 @@ __global__ __launch_bounds__(MODE == 3 ? kOneGroupThreads : kBlock) void climb_u
                 pl = s_lefts >> 16;
             }
         }
+    }
+}
+
+// The climb above the chunks WITHOUT a chain of hand-offs, for builds of up to kOneGroupUpper leaves (one workgroup).
+// A node's box is the box of its leaf range, and the reference's Min / Max (common_core.h:113-114: the right operand
+// on ties) return the rightmost of the equal extremes of a range however the reduction is bracketed, so any reduction
+// that keeps the leaves in order gives the bits of the reference's nested merges (lbvh.c:58).  The node that splits at
+// gap g reaches from the nearest gap of smaller priority on its left to the nearest one on its right: found through a
+// sparse table of the chunks' minimum priorities and the chunks' own tables (chunk_ranges); its box is (suffix box of
+// its first leaf) + (whole chunks between, from a sparse table of chunk boxes) + (prefix box of its last leaf); its place
+// is 2 l + S(r), S(r) = how many ancestors hold leaf r in their left subtree (the node's own ancestors of that kind are
+// exactly those: the running-minimum records seen from gap r).  One thread per node, nothing waits for anything.
+constexpr int kRangeLevels = 9;  // 2^8 = 256 chunks of 512 leaves = kOneGroupUpper
+template <bool PAIRED>
+__global__ __launch_bounds__(kOneGroupThreads) void range_upper_kernel(ClimbArgs A) {
+    __shared__ uint8_t minA[kRangeLevels][256], minB[kRangeLevels][256];
+    __shared__ float cbox[kRangeLevels - 1][256][6];
+    const uint32_t n = A.n, tid = threadIdx.x;
+    const uint32_t chunks = (n + (uint32_t)kChunk - 1u) / (uint32_t)kChunk;  // <= 256
+    const uint32_t count = *A.start_count;
+    const uint32_t first = blockIdx.x * (uint32_t)kOneGroupThreads + tid;
+    uint32_t word = first < count ? A.starters[first] : 0u;  // asked for before the tables are made
+    if (tid < chunks) {
+        minA[0][tid] = A.cmin[2u * tid];
+        minB[0][tid] = A.cmin[2u * tid + 1u];
+        const uint32_t last = ((tid + 1u) * (uint32_t)kChunk < n ? (tid + 1u) * (uint32_t)kChunk : n) - 1u;
+#pragma unroll
+        for (int k = 0; k < 6; k++) cbox[0][tid][k] = A.pre_box[6 * (uint64_t)last + k];
+    }
+    __syncthreads();
+    for (int lv = 1; lv < kRangeLevels && (1u << lv) <= chunks; lv++) {
+        const uint32_t half = 1u << (lv - 1);
+        if (tid < chunks && tid + 2u * half <= chunks) {
+            const uint8_t a = minA[lv - 1][tid], b = minA[lv - 1][tid + half], c = minB[lv - 1][tid], d = minB[lv - 1][tid + half];
+            minA[lv][tid] = a < b ? a : b;
+            minB[lv][tid] = c < d ? c : d;
+            if (lv < kRangeLevels - 1) {
+                float box[6];
+#pragma unroll
+                for (int k = 0; k < 6; k++) box[k] = cbox[lv - 1][tid][k];
+                merge_sibling(box, cbox[lv - 1][tid + half], true);
+#pragma unroll
+                for (int k = 0; k < 6; k++) cbox[lv][tid][k] = box[k];
+            }
+        }
+        __syncthreads();
+    }
+    for (uint32_t t = first; t < count; t += gridDim.x * (uint32_t)kOneGroupThreads) {
+        if (t != first) word = A.starters[t];
+        const uint32_t g = word & 0x1ffffu;
+        const bool left_in = (word & 0x40000000u) != 0u, right_in = (word & 0x80000000u) != 0u;
+        if (g + 1u >= n) continue;
+        const uint32_t q = (word >> 17) & 0x7fu;
+        const uint32_t c = g / (uint32_t)kChunk;  // the chunk in whose window g is one of the entries 1 .. kChunk
+        // left end: the nearest gap before g with a priority below q (gap -1 counts, with priority 0)
+        uint32_t cl = c;
+        if (!left_in) {  // none in this chunk's window: the nearest chunk before it whose entries 0 .. kChunk-1 hold one
+            uint32_t pos = c;
+            for (int lv = kRangeLevels - 1; lv >= 0; lv--) {
+                const uint32_t step = 1u << lv;
+                if (step <= chunks && pos >= step && minA[lv][pos - step] >= q) pos -= step;
+            }
+            if (pos == 0u) continue;  // cannot happen: chunk 0 holds gap -1
+            cl = pos - 1u;
+        }
+        const uint32_t le = A.tab[256u * cl + q];
+        // right end: the nearest gap behind g with a priority below q (gap n-1 counts, with priority 0)
+        uint32_t cr = c;
+        if (!right_in) {
+            uint32_t pos = c + 1u;
+            for (int lv = kRangeLevels - 1; lv >= 0; lv--) {
+                const uint32_t step = 1u << lv;
+                if (pos + step <= chunks && minB[lv][pos] >= q) pos += step;
+            }
+            if (pos >= chunks) continue;  // cannot happen: the last chunk holds gap n-1
+            cr = pos;
+        }
+        const uint32_t re = A.tab[256u * cr + 128u + q];
+        if (le == 0xffffu || re == 0xffffu) continue;  // cannot happen
+        const uint32_t l = cl * (uint32_t)kChunk + le;               // gap cl*kChunk - 1 + le, plus one
+        uint32_t r = cr * (uint32_t)kChunk - 1u + re;                // the gap itself: the node's last leaf
+        if (r > n - 1u) r = n - 1u;
+        if (!(l <= g && g < r)) continue;  // cannot happen
+        const uint32_t first_chunk = l / (uint32_t)kChunk, last_chunk = r / (uint32_t)kChunk;
+        if (last_chunk <= first_chunk) continue;  // cannot happen: such a node lies inside a chunk
+        float box[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) box[k] = A.suf_box[6 * (uint64_t)l + k];
+        if (last_chunk > first_chunk + 1u) {  // whole chunks between: two overlapping power-of-two stretches
+            const uint32_t a = first_chunk + 1u, b = last_chunk - 1u;
+            const int lv = 31 - __clz((int)(b - a + 1u));
+            merge_sibling(box, cbox[lv][a], true);
+            merge_sibling(box, cbox[lv][b + 1u - (1u << lv)], true);
+        }
+        if (last_chunk > first_chunk) {
+            float tail[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) tail[k] = A.pre_box[6 * (uint64_t)r + k];
+            merge_sibling(box, tail, true);
+        }
+        const uint32_t lefts = r + 1u < n ? (uint32_t)A.lefts[r] : 0u;
+        put_inner<PAIRED>(A.nodes, box, l, r, lefts);
     }
 }
 
@@ -1866,7 +2117,7 @@ int lbvh_reserve_workspace(rthip_ctx* ctx, uint64_t n, LbvhWorkspace* ws) {
     RT_TRY(rthip_reserve(ctx, w.child, 2 * n * sizeof(ChildRec)));
     RT_TRY(rthip_reserve(ctx, w.vis, (size_t)div_up(n, kVisTile) * (sizeof(ulonglong2) + sizeof(VisF))));
     RT_TRY(rthip_reserve(ctx, w.flags, n * 4));
-    RT_TRY(rthip_reserve(ctx, w.starters, (n / 2 + 1) * 4));  // a leaf delivers to at most one such node, a node takes two
+    RT_TRY(rthip_reserve(ctx, w.starters, (n + 1) * 4));  // the start list of the upper kernel (at most n / 2 nodes), or every gap above the chunks (range form)
     RT_TRY(rthip_reserve(ctx, w.lefts, n + 32));
     RT_TRY(rthip_reserve(ctx, w.bounds, kBoundBytes));
     return RTHIP_OK;
@@ -1898,6 +2149,14 @@ int lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, float4* 
     A.starters = (uint32_t*)w.starters.p;
     A.start_count = (uint32_t*)w.flags.p + (n - 1);
     A.nodes = d_nodes;
+    // up to kOneGroupUpper leaves the nodes above the chunks can come from leaf ranges instead of a chain of hand-offs
+    // (range_upper_kernel); the child records' and the counters' buffers then hold the range form's tables
+    const uint32_t n_chunks = div_up(n, kChunk);
+    A.ranges = (n > (uint64_t)kChunk && n <= kOneGroupUpper && ctx->upper_ranges && !ctx->upper_device_wide) ? 1u : 0u;
+    A.pre_box = (float*)w.child.p;
+    A.suf_box = A.pre_box + 6 * n;
+    A.tab = (uint16_t*)w.flags.p;
+    A.cmin = (uint8_t*)w.flags.p + 512ull * n_chunks;
 
     if (n <= (uint64_t)kChunk) {  // one workgroup does everything
         ctx->bounds_of = nullptr;
@@ -1969,9 +2228,19 @@ int lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, float4* 
     vis_leaf_kernel<<<vtiles, kBlock, 0, s>>>(prio, (uint32_t)n, tile_f, vtiles, vtiles > kVisFusedTiles ? tile_in : nullptr, lefts);
     RT_HIP(ctx, hipGetLastError());
     // boxes: every node's record goes to its pre-order place
-    if (paired) climb_local_kernel<true><<<chunks, kChunk, 0, s>>>(A);
+    if (A.ranges) {
+        if (paired) climb_local_kernel<true, true><<<chunks, kChunk, 0, s>>>(A);
+        else climb_local_kernel<false, true><<<chunks, kChunk, 0, s>>>(A);
+    } else if (paired) climb_local_kernel<true><<<chunks, kChunk, 0, s>>>(A);
     else climb_local_kernel<false><<<chunks, kChunk, 0, s>>>(A);
     RT_HIP(ctx, hipGetLastError());
+    if (A.ranges) {
+        const uint32_t groups = n_chunks >= 64u ? 8u : 2u;  // every workgroup builds the tables for itself (a microsecond)
+        if (paired) range_upper_kernel<true><<<groups, kOneGroupThreads, 0, s>>>(A);
+        else range_upper_kernel<false><<<groups, kOneGroupThreads, 0, s>>>(A);
+        RT_HIP(ctx, hipGetLastError());
+        return RTHIP_OK;
+    }
     const int mode = (n <= kOneGroupUpper && !ctx->upper_device_wide) ? 3 : (int)ctx->refit_fence;
 #define RT_UPPER(MODE, GRID, BLOCK)                                               \
     if (paired) climb_upper_kernel<MODE, true><<<GRID, BLOCK, 0, s>>>(A);         \
@@ -2034,7 +2303,7 @@ int lbvh_static_workspace_init(rthip_ctx* ctx) {
               carve(w.block_hist, base, off, hist_bytes) &&
               carve(w.prio, base, off, n + 8) && carve(w.child, base, off, 2 * n * sizeof(ChildRec)) &&
               carve(w.vis, base, off, (size_t)div_up(n, kVisTile) * (sizeof(ulonglong2) + sizeof(VisF))) && carve(w.flags, base, off, n * 4) &&
-              carve(w.starters, base, off, (n / 2 + 1) * 4) && carve(w.lefts, base, off, n + 32) && carve(w.bounds, base, off, kBoundBytes);
+              carve(w.starters, base, off, (n + 1) * 4) && carve(w.lefts, base, off, n + 32) && carve(w.bounds, base, off, kBoundBytes);
     if (!ok) return rthip_fail(ctx, RTHIP_E_LIMIT, "the static workspace of %zu bytes is too small for %llu boxes", kStaticBytes, (unsigned long long)n);
     ctx->ws_static_ready = true;
     return RTHIP_OK;

@@ -181,6 +181,8 @@ int rthip_create(rthip_ctx** out_ctx, int device_id) {
     if (top_bytes && (top_bytes[0] == '4' || top_bytes[0] == '8')) ctx->sort_top_bytes = top_bytes[0] - '0';
     const char* small_tile = getenv("RTHIP_SORT_SMALL_TILE_MAX");
     if (small_tile && small_tile[0]) ctx->sort_small_tile_max = strtoull(small_tile, nullptr, 10);
+    const char* ranges = getenv("RTHIP_UPPER_RANGES");
+    if (ranges && (ranges[0] == '0' || ranges[0] == '1')) ctx->upper_ranges = ranges[0] - '0';
     const char* wide = getenv("RTHIP_UPPER_DEVICE_WIDE");
     ctx->upper_device_wide = (wide && wide[0] == '1') ? 1 : 0;
     const char* mode = getenv("RTHIP_CAST");

@@ -150,6 +150,7 @@ struct rthip_ctx {
     uint64_t sort_top_gave_up_n = 0;  // a build of this many boxes needed all eight passes after all: not tried again
     int sort_by_passes = 0;     // RTHIP_SORT_BY_PASSES=1: small sorts also go pass by pass through HBM (diagnostic)
     uint64_t sort_small_tile_max = 1ull << 18;  // sorts of up to this many keys use 1024-key tiles (RTHIP_SORT_SMALL_TILE_MAX)
+    int upper_ranges = 1;       // builds of up to 2^17 leaves take the nodes above the chunks from leaf ranges (RTHIP_UPPER_RANGES=0: the chain of hand-offs in one workgroup)
     int upper_device_wide = 0;  // RTHIP_UPPER_DEVICE_WIDE=1: never run the upper climbs in one workgroup (diagnostic)
     int refit_fence = 2;  // hand-offs of the upper hierarchy kernels: 0 release / acquire through the counter, 1 __threadfence(), 2 relaxed + s_waitcnt (default)
 

@@ -146,7 +146,8 @@ def test_lbvh_sizes_at_the_seams_of_the_builder(oracle, n):
     tile sort (1024), tile sort + merge against radix passes (131 072), small against large radix tiles (262 144), the
     upper box climb in one workgroup (131 072).  Half of the boxes sit on a lattice (runs of equal codes, pairs among
     them, as the two triangles of a quad give).  Every size against the oracle, and the same tree when the sort goes
-    pass by pass and when the upper climb runs device-wide."""
+    pass by pass, when the upper climb runs device-wide, and when builds of up to 131 072 leaves climb by hand-offs in one
+    workgroup instead of taking the nodes above the chunks from leaf ranges."""
     rng = np.random.default_rng(n)
     cen = rng.random((n, 3)).astype(np.float32)
     cen[: n // 2] = np.floor(cen[: n // 2] * 40) / 40
@@ -154,9 +155,10 @@ def test_lbvh_sizes_at_the_seams_of_the_builder(oracle, n):
     half = np.full((n, 3), 0.001, dtype=np.float32)
     boxes = np.concatenate([cen - half, cen + half], axis=1)
     want = oracle.lbvh_build(boxes)[3]
-    saved = {k: os.environ.get(k) for k in ("RTHIP_SORT_BY_PASSES", "RTHIP_UPPER_DEVICE_WIDE", "RTHIP_SORT_SMALL_TILE_MAX")}
+    saved = {k: os.environ.get(k) for k in ("RTHIP_SORT_BY_PASSES", "RTHIP_UPPER_DEVICE_WIDE", "RTHIP_SORT_SMALL_TILE_MAX", "RTHIP_UPPER_RANGES")}
     try:
-        for env in ({}, {"RTHIP_SORT_BY_PASSES": "1", "RTHIP_UPPER_DEVICE_WIDE": "1"}, {"RTHIP_SORT_BY_PASSES": "1", "RTHIP_SORT_SMALL_TILE_MAX": "0"}):
+        for env in ({}, {"RTHIP_SORT_BY_PASSES": "1", "RTHIP_UPPER_DEVICE_WIDE": "1"}, {"RTHIP_SORT_BY_PASSES": "1", "RTHIP_SORT_SMALL_TILE_MAX": "0"},
+                    {"RTHIP_UPPER_RANGES": "0"}):
             for k in saved:
                 os.environ.pop(k, None)
             os.environ.update(env)
