@@ -225,6 +225,18 @@ __device__ __forceinline__ uint32_t morton_axis(float c, float mn, float ext) {
     return (uint32_t)scaled;
 }
 
+// the code of box i: centroid (lbvh.c:114) normalised by the centroid bounds, 21 bits per axis, x lowest
+__device__ __forceinline__ uint64_t morton_of_box(const float* __restrict__ aabb6, uint64_t i, const float* mn, const float* ext) {
+    const float* b = aabb6 + 6 * i;
+    uint64_t code = 0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        float c = (b[k] + b[k + 3]) * 0.5f;  // lbvh.c:114
+        code |= spread21(morton_axis(c, mn[k], ext[k])) << k;
+    }
+    return code;
+}
+
 __global__ __launch_bounds__(kBlock) void morton_kernel(const float* __restrict__ aabb6, uint64_t n,
                                                         const uint32_t* __restrict__ bounds,
                                                         uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
@@ -239,14 +251,7 @@ __global__ __launch_bounds__(kBlock) void morton_kernel(const float* __restrict_
     }
     for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
         if (zero) zero[i] = 0u;  // the climb's arrival counters, cleared on the way (one launch fewer)
-        const float* b = aabb6 + 6 * i;
-        uint64_t code = 0;
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            float c = (b[k] + b[k + 3]) * 0.5f;  // lbvh.c:114
-            code |= spread21(morton_axis(c, mn[k], ext[k])) << k;
-        }
-        keys[i] = code;
+        keys[i] = morton_of_box(aabb6, i, mn, ext);
         if (vals) vals[i] = (uint32_t)i;  // the sort's first pass takes positions as values by itself
     }
 }
@@ -441,7 +446,7 @@ __global__ __launch_bounds__(BLOCK) void radix_scatter_kernel(const uint64_t* __
     }
 }
 
-// ---- sorts of at most kMergeTiles tiles: every tile sorted completely in LDS, then merged by rank ---------
+// ---- sorts of at most 128 tiles: every tile sorted completely in LDS, then merged by rank ----------------
 // Up to 2^17 keys the pass-by-pass sort is a chain of 24 small launches (its keys fit the L2 many times over), so
 // these sizes take two.  tile_sort_kernel sorts each tile of 1024 keys through all n_bytes digits without leaving LDS
 // (the same wave-ballot ranking as the scatter kernel, the tile ping-ponging between registers and LDS; small tiles,
@@ -450,98 +455,186 @@ __global__ __launch_bounds__(BLOCK) void radix_scatter_kernel(const uint64_t* __
 // come before it (keys <= in earlier tiles, < in later ones, which keeps equal keys in their original order).
 constexpr int kSmallSortBlock = 256;
 constexpr int kSmallTile = kSmallSortBlock * kSortItems;  // 1024 keys
-constexpr uint32_t kMergeTiles = 128;
 constexpr int kMergeBatch = 4;   // tiles a wave ranks against side by side
 constexpr int kMergeSeg = 128;   // keys of a tile's matching stretch held in LDS
+constexpr uint32_t kTileFixLong = 32;  // tile_sort_kernel finishes stretches of equal upper bytes up to this long by ranking
 
-__global__ __launch_bounds__(kSmallSortBlock) void tile_sort_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
-                                                                    uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
-                                                                    uint64_t n, int n_bytes) {
-    constexpr int kWaves = kSmallSortBlock / 64;
+// A tile of BLOCK * ITEMS keys, sorted stably through the digits top_first .. n_bytes - 1 in LDS.  With top_first > 0
+// (Morton codes: the upper four bytes decide the order of all but a few neighbours) the keys that share those digits
+// then lie in short stretches in their original order, and each is finished by ranking inside its stretch (smaller
+// lower digits first, equal ones by position); a stretch longer than kTileFixLong makes the workgroup start again
+// with all n_bytes digits.  MORTON: the keys are the Morton codes of the boxes aabb6 (keys_in is not read: what
+// morton_kernel would have written there is made here, one launch fewer; the values are the positions), and *zero_word
+// is cleared for the kernels that follow.
+template <int BLOCK, int ITEMS, bool MORTON = false>
+__global__ __launch_bounds__(BLOCK) void tile_sort_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                                                          uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+                                                          uint64_t n, int n_bytes, int top_first, const float* __restrict__ aabb6 = nullptr,
+                                                          const uint32_t* __restrict__ bounds = nullptr, uint32_t* __restrict__ zero_word = nullptr) {
+    constexpr int kWaves = BLOCK / 64, kTile = BLOCK * ITEMS;
+    static_assert(BLOCK >= 256, "one thread per digit");
     __shared__ uint32_t wave_cnt[kWaves][256];
     __shared__ uint32_t bin_start[256];
-    __shared__ uint32_t wave_tot[kWaves];
-    __shared__ uint64_t skeys[kSmallTile];
-    __shared__ uint32_t svals[kSmallTile];
+    __shared__ uint32_t wave_tot[4];
+    __shared__ uint64_t skeys[kTile];
+    __shared__ uint32_t svals[kTile];
+    __shared__ uint32_t long_stretch;
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const uint64_t base = (uint64_t)blockIdx.x * kSmallTile;
-    const uint32_t wpos = (uint32_t)wave * (64 * kSortItems);  // this wave's first position in the tile
+    const uint64_t base = (uint64_t)blockIdx.x * kTile;
+    const uint32_t wpos = (uint32_t)wave * (64 * ITEMS);  // this wave's first position in the tile
     const uint64_t lt_mask = (1ull << lane) - 1ull;
+    const uint32_t valid = n - base < (uint64_t)kTile ? (uint32_t)(n - base) : (uint32_t)kTile;
+    const bool owner = tid < 256;  // thread d < 256 scans digit d
 
-    uint64_t key[kSortItems];
-    uint32_t val[kSortItems];
+    if (tid == 0) long_stretch = 0;  // set only behind the barriers of the passes, read behind one more
+    uint64_t code[MORTON ? ITEMS : 1];
+    if constexpr (MORTON) {
+        __shared__ uint32_t sb[6];
+        float cen[ITEMS][3];  // asked for before the bounds: the two round trips to memory overlap
 #pragma unroll
-    for (int j = 0; j < kSortItems; j++) {
-        const uint64_t i = base + wpos + (uint64_t)j * 64 + lane;
-        key[j] = (i < n) ? keys_in[i] : ~0ull;  // padding sorts behind every real key and keeps its place there
-        val[j] = (i < n) ? (vals_in ? vals_in[i] : (uint32_t)i) : 0u;
-    }
-    for (int pass = 0; pass < n_bytes; pass++) {
-        const int shift = pass * 8;
-        // a wave's counters are its own until the barrier below (the previous pass's readers of them are behind that
-        // pass's later barriers), so clearing them needs no barrier
+        for (int j = 0; j < ITEMS; j++) {
+            const uint64_t i = base + wpos + (uint64_t)j * 64 + lane;
+            const float* b = aabb6 + 6 * (i < n ? i : 0);
 #pragma unroll
-        for (int q = 0; q < 4; q++) wave_cnt[wave][q * 64 + lane] = 0;
-        uint32_t rank[kSortItems];
-#pragma unroll
-        for (int j = 0; j < kSortItems; j++) {
-            const uint32_t d = (uint32_t)(key[j] >> shift) & 255u;
-            uint64_t same = ~0ull;
-#pragma unroll
-            for (int b = 0; b < 8; b++) {
-                const bool bit = (d >> b) & 1u;
-                const uint64_t bal = __ballot(bit);
-                same &= bit ? bal : ~bal;
-            }
-            const uint32_t below = __popcll(same & lt_mask);
-            uint32_t old = 0;
-            if (below == 0) {
-                old = wave_cnt[wave][d];
-                wave_cnt[wave][d] = old + __popcll(same);
-            }
-            old = __shfl(old, __ffsll((long long)same) - 1);
-            rank[j] = old + below;
+            for (int k = 0; k < 3; k++) cen[j][k] = (b[k] + b[k + 3]) * 0.5f;  // lbvh.c:114
         }
-        __syncthreads();
-        {   // thread d: offsets of each wave inside digit d, then the exclusive scan over the digits
-            uint32_t run = 0;
+        bounds_fold(bounds, sb);
 #pragma unroll
-            for (int w = 0; w < kWaves; w++) {
-                const uint32_t c = wave_cnt[w][tid];
-                wave_cnt[w][tid] = run;
-                run += c;
-            }
-            uint32_t incl = run;
+        for (int j = 0; j < ITEMS; j++) {
+            code[j] = 0;
 #pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const uint32_t up = __shfl_up(incl, o);
-                if (lane >= o) incl += up;
+            for (int k = 0; k < 3; k++) {
+                const float mn = ord2f(sb[k]), ext = ord2f(sb[k + 3]) - mn;  // extents = max - min, lbvh.c:106
+                code[j] |= spread21(morton_axis(cen[j][k], mn, ext)) << k;
             }
-            if (lane == 63) wave_tot[wave] = incl;
+        }
+        if (blockIdx.x == 0 && tid == 0) *zero_word = 0u;
+    }
+    uint64_t key[ITEMS];
+    uint32_t val[ITEMS];
+    for (int first = top_first;; first = 0) {
+#pragma unroll
+        for (int j = 0; j < ITEMS; j++) {
+            const uint64_t i = base + wpos + (uint64_t)j * 64 + lane;
+            if constexpr (MORTON) {
+                key[j] = (i < n) ? code[j] : ~0ull;
+                val[j] = (i < n) ? (uint32_t)i : 0u;
+            } else {
+                key[j] = (i < n) ? keys_in[i] : ~0ull;  // padding sorts behind every real key and keeps its place there
+                val[j] = (i < n) ? (vals_in ? vals_in[i] : (uint32_t)i) : 0u;
+            }
+        }
+        for (int pass = first; pass < n_bytes; pass++) {
+            const int shift = pass * 8;
+            // a wave's counters are its own until the barrier below (the previous pass's readers of them are behind that
+            // pass's later barriers), so clearing them needs no barrier
+#pragma unroll
+            for (int q = 0; q < 4; q++) wave_cnt[wave][q * 64 + lane] = 0;
+            uint32_t rank[ITEMS];
+#pragma unroll
+            for (int j = 0; j < ITEMS; j++) {
+                const uint32_t d = (uint32_t)(key[j] >> shift) & 255u;
+                uint64_t same = ~0ull;
+#pragma unroll
+                for (int b = 0; b < 8; b++) {
+                    const bool bit = (d >> b) & 1u;
+                    const uint64_t bal = __ballot(bit);
+                    same &= bit ? bal : ~bal;
+                }
+                const uint32_t below = __popcll(same & lt_mask);
+                uint32_t old = 0;
+                if (below == 0) {
+                    old = wave_cnt[wave][d];
+                    wave_cnt[wave][d] = old + __popcll(same);
+                }
+                old = __shfl(old, __ffsll((long long)same) - 1);
+                rank[j] = old + below;
+            }
             __syncthreads();
-            uint32_t wsum = 0;
-            for (int w = 0; w < wave; w++) wsum += wave_tot[w];
-            bin_start[tid] = wsum + incl - run;
-        }
-        __syncthreads();
+            {   // thread d: offsets of each wave inside digit d, then the exclusive scan over the digits
+                uint32_t run = 0;
+                if (owner) {
 #pragma unroll
-        for (int j = 0; j < kSortItems; j++) {
-            const uint32_t d = (uint32_t)(key[j] >> shift) & 255u;
-            const uint32_t pos = bin_start[d] + wave_cnt[wave][d] + rank[j];
-            skeys[pos] = key[j];
-            svals[pos] = val[j];
-        }
-        __syncthreads();
+                    for (int w = 0; w < kWaves; w++) {
+                        const uint32_t c = wave_cnt[w][tid];
+                        wave_cnt[w][tid] = run;
+                        run += c;
+                    }
+                }
+                uint32_t incl = run;
 #pragma unroll
-        for (int j = 0; j < kSortItems; j++) {
-            key[j] = skeys[wpos + j * 64 + lane];
-            val[j] = svals[wpos + j * 64 + lane];
+                for (int o = 1; o < 64; o <<= 1) {
+                    const uint32_t up = __shfl_up(incl, o);
+                    if (lane >= o) incl += up;
+                }
+                if (owner && lane == 63) wave_tot[wave] = incl;
+                __syncthreads();
+                if (owner) {
+                    uint32_t wsum = 0;
+                    for (int w = 0; w < wave; w++) wsum += wave_tot[w];
+                    bin_start[tid] = wsum + incl - run;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < ITEMS; j++) {
+                const uint32_t d = (uint32_t)(key[j] >> shift) & 255u;
+                const uint32_t pos = bin_start[d] + wave_cnt[wave][d] + rank[j];
+                skeys[pos] = key[j];
+                svals[pos] = val[j];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < ITEMS; j++) {
+                key[j] = skeys[wpos + j * 64 + lane];
+                val[j] = svals[wpos + j * 64 + lane];
+            }
+            // no barrier: the next pass writes the tile only after its own three barriers
         }
-        // no barrier: the next pass writes the tile only after its own three barriers
+        if (first == 0) break;
+
+        // the tile is in order by its upper digits and nobody writes it before the barrier below
+        const uint32_t* words = (const uint32_t*)skeys;  // key q: low word 2q, high word 2q + 1
+        uint32_t dst[ITEMS];
+        bool gave_up = false;
+#pragma unroll
+        for (int j = 0; j < ITEMS; j++) {
+            const uint32_t p = wpos + (uint32_t)j * 64 + (uint32_t)lane;
+            dst[j] = p;
+            if (p < valid) {
+                const uint32_t top = (uint32_t)(key[j] >> 32), low = (uint32_t)key[j];
+                uint32_t a = p, b = p + 1;
+                while (a > 0 && p - a < kTileFixLong && words[2 * (a - 1) + 1] == top) a--;
+                while (b < valid && b - p < kTileFixLong && words[2 * b + 1] == top) b++;
+                if (p - a >= kTileFixLong || b - p >= kTileFixLong) {
+                    gave_up = true;
+                } else if (b - a > 1) {
+                    uint32_t r = a;
+                    for (uint32_t q = a; q < b; q++) {
+                        const uint32_t lq = words[2 * q];
+                        r += (lq < low || (lq == low && q < p)) ? 1u : 0u;
+                    }
+                    dst[j] = r;
+                }
+            }
+        }
+        if (gave_up) long_stretch = 1;
+        __syncthreads();
+        if (!long_stretch) {
+#pragma unroll
+            for (int j = 0; j < ITEMS; j++) {
+                const uint32_t p = wpos + (uint32_t)j * 64 + (uint32_t)lane;
+                if (p < valid) {
+                    keys_out[base + dst[j]] = key[j];
+                    vals_out[base + dst[j]] = val[j];
+                }
+            }
+            return;
+        }
     }
 #pragma unroll
-    for (int j = 0; j < kSortItems; j++) {
+    for (int j = 0; j < ITEMS; j++) {
         const uint64_t i = base + wpos + (uint64_t)j * 64 + lane;
         if (i < n) {
             keys_out[i] = key[j];
@@ -572,7 +665,7 @@ __device__ __forceinline__ uint32_t rank_in_global(const uint64_t* __restrict__ 
 // searched in global memory.
 __global__ __launch_bounds__(256) void tile_merge_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals,
                                                          uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
-                                                         uint32_t n, uint32_t tiles, uint64_t mask) {
+                                                         uint32_t n, uint32_t tiles, uint32_t tile_keys, uint64_t mask) {
     __shared__ uint32_t ends[4][2][32];
     __shared__ uint64_t seg[4][kMergeBatch][kMergeSeg];
     __shared__ uint32_t partial[4][64];
@@ -582,15 +675,15 @@ __global__ __launch_bounds__(256) void tile_merge_kernel(const uint64_t* __restr
     const uint32_t last_lane = (n - i0 < 64u ? n - i0 : 64u) - 1u;
     const uint64_t full = keys[live ? i : i0], k = full & mask;
     const uint64_t k_first = __shfl(k, 0), k_last = __shfl(k, (int)last_lane);
-    const uint32_t mine = i0 / (uint32_t)kSmallTile;
+    const uint32_t mine = i0 / tile_keys;
     const uint32_t per_wave = (tiles + 3u) / 4u, t0 = wave * per_wave;  // this wave's tiles: t0 .. t0 + per_wave - 1
 
     {   // where the first (lanes 0-31) and the last key (lanes 32-63) fall in tile t0 + (lane & 31)
         const uint32_t tt = lane & 31u, t = t0 + tt, e = lane >> 5;
         uint32_t r = 0;
         if (tt < per_wave && t < tiles && t != mine) {
-            const uint32_t first = t * (uint32_t)kSmallTile;
-            const uint32_t count = n - first < (uint32_t)kSmallTile ? n - first : (uint32_t)kSmallTile;
+            const uint32_t first = t * tile_keys;
+            const uint32_t count = n - first < tile_keys ? n - first : tile_keys;
             r = rank_in_global(keys + first, count, e ? k_last : k_first, t < mine, mask);
         }
         ends[wave][e][tt] = r;
@@ -616,7 +709,7 @@ __global__ __launch_bounds__(256) void tile_merge_kernel(const uint64_t* __restr
             const bool or_equal = t < mine;
             kk[u] = k + (or_equal ? 1ull : 0ull);
             every[u] = or_equal && k == ~0ull;  // k + 1 wrapped: every key of an earlier tile comes first
-            const uint64_t* src = keys + (uint64_t)t * kSmallTile + lo[u];
+            const uint64_t* src = keys + (uint64_t)t * tile_keys + lo[u];
             a[u] = b[u] = ~0ull;
             if (len[u] < (uint32_t)kMergeSeg) {
                 if (lane < len[u]) a[u] = src[lane] & mask;
@@ -646,7 +739,7 @@ __global__ __launch_bounds__(256) void tile_merge_kernel(const uint64_t* __restr
         for (int u = 0; u < kMergeBatch; u++) {
             if (len[u] >= (uint32_t)kMergeSeg) {  // uniform over the wave
                 const uint32_t t = t0 + tb + u;
-                pos[u] = rank_in_global(keys + (uint64_t)t * kSmallTile + lo[u], len[u], k, t < mine, mask);
+                pos[u] = rank_in_global(keys + (uint64_t)t * tile_keys + lo[u], len[u], k, t < mine, mask);
             } else if (every[u]) {
                 pos[u] = len[u];
             }
@@ -657,7 +750,7 @@ __global__ __launch_bounds__(256) void tile_merge_kernel(const uint64_t* __restr
     partial[wave][lane] = before;
     __syncthreads();
     if (wave == 0 && live) {
-        const uint32_t rank = (i - mine * (uint32_t)kSmallTile) + partial[0][lane] + partial[1][lane] + partial[2][lane] + partial[3][lane];
+        const uint32_t rank = (i - mine * tile_keys) + partial[0][lane] + partial[1][lane] + partial[2][lane] + partial[3][lane];
         keys_out[rank] = full;
         vals_out[rank] = vals[i];
     }
@@ -975,9 +1068,11 @@ constexpr int kVisItems = 8;
 constexpr int kVisTile = kBlock * kVisItems;  // 2048 gaps per workgroup
 constexpr uint32_t kVisFusedTiles = kBlock;   // up to this many tiles, pass 3 finds the mask behind its tile by itself
 
-// Pass 1: priorities of a tile's gaps (written for the box climb) and the tile's stretch.
+// Pass 1: priorities of a tile's gaps (written for the box climb) and the tile's stretch; a tile is kBlock * ITEMS gaps.
+template <int ITEMS>
 __global__ __launch_bounds__(kBlock) void vis_tile_kernel(const uint64_t* __restrict__ keys, uint32_t n, uint8_t* __restrict__ prio,
                                                           VisF* __restrict__ tile_f) {
+    constexpr int kVisItems = ITEMS, kVisTile = kBlock * ITEMS;  // inside this kernel: its own tile
     __shared__ uint8_t sp[kVisTile];
     const uint32_t base = blockIdx.x * (uint32_t)kVisTile;
 #pragma unroll
@@ -1163,6 +1258,8 @@ struct ClimbArgs {
                                // priority of the gap beyond the child's far end (which the parent needs to find ITS parent)
     uint32_t* flags;           // arrival counters, zero before the climb
     const uint8_t* lefts;      // of every sorted leaf: how many of its ancestors hold it in their left subtree
+    uint8_t* lefts_w;          // the same array for the range form's chunk kernel, which fills it in itself ...
+    const VisF* chunk_f;       // ... from the stretch of every chunk's gaps (vis_tile_kernel with chunk-sized tiles)
     uint32_t* starters;        // gaps of the nodes that span chunks and got both children from the local kernel
     uint32_t* start_count;
     float4* nodes;             // the pre-order records
@@ -1205,7 +1302,7 @@ struct LeafIn {
     uint32_t prio_end;  // thread 0: of gap c0 - 1 + kChunk
 };
 
-__device__ __forceinline__ LeafIn leaf_in(uint32_t c0, const ClimbArgs& A) {
+__device__ __forceinline__ LeafIn leaf_in(uint32_t c0, const ClimbArgs& A, bool shape_known = true) {
     LeafIn in = {0u, 0u, 0u, 0u};
     const uint32_t n = A.n, i = c0 + threadIdx.x;
     const int64_t g = (int64_t)c0 - 1 + threadIdx.x;
@@ -1216,7 +1313,7 @@ __device__ __forceinline__ LeafIn leaf_in(uint32_t c0, const ClimbArgs& A) {
     }
     if (i < n) {
         in.prim = A.sorted_idx[i];
-        in.lefts = A.lefts[i];
+        if (shape_known) in.lefts = A.lefts[i];
     }
     return in;
 }
@@ -1543,12 +1640,53 @@ __global__ __launch_bounds__(kChunk) void climb_local_kernel(ClimbArgs A) {
     __shared__ ClimbLds L;
     const uint32_t c0 = blockIdx.x * (uint32_t)kChunk;
     CLIMB_STAMP(0);
-    const LeafIn in = leaf_in(c0, A);
+    LeafIn in = leaf_in(c0, A, !RANGES);
+    float box[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if constexpr (RANGES) {
+        leaf_box(c0, A, in, box);  // asked for before the scan's barriers, used after them
+        // The last step of the shape scan for this chunk's leaves (vis_leaf_kernel's, with chunks for tiles): the mask
+        // seen from behind the chunk is the join of the stretches of all later chunks, at most kChunk - 1 of them.
+        const uint32_t i = c0 + threadIdx.x, n = A.n;
+        const bool has_gap = i + 1u < n;
+        const uint32_t p = has_gap ? (uint32_t)A.prio[i] : 0u;
+        // Two scans share their barriers: over the later chunks' stretches (only their join is needed; waves whose
+        // chunks do not exist skip it) and over this chunk's gaps.
+        __shared__ VisF wave_own[kChunk / 64], wave_later[kChunk / 64];
+        const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+        const uint32_t t = blockIdx.x + 1u + threadIdx.x;
+        VisF own = has_gap ? vis_push(p, vis_identity()) : vis_identity();  // lanes [lane, 63] of this wave
+        VisF later = vis_identity();
+        const bool any_later = blockIdx.x + 1u + 64u * wave < gridDim.x;    // uniform over the wave
+        if (any_later && t < gridDim.x) later = A.chunk_f[t];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const VisF other = vis_shfl_down(own, o);
+            if (lane + (uint32_t)o < 64u) own = vis_join(own, other);
+            if (any_later) {
+                const VisF other_later = vis_shfl_down(later, o);
+                if (lane + (uint32_t)o < 64u) later = vis_join(later, other_later);
+            }
+        }
+        VisF right = vis_shfl_down(own, 1);
+        if (lane == 63u) right = vis_identity();
+        if (lane == 0u) {
+            wave_own[wave] = own;
+            wave_later[wave] = later;
+        }
+        __syncthreads();
+        VisF behind = vis_identity();  // everything behind this wave's gaps: the later waves, then the later chunks
+        for (int w = kChunk / 64 - 1; w >= 0; w--) behind = vis_join(wave_later[w], behind);
+        behind = VisF{0u, behind.lo, behind.hi};  // applied to the empty mask
+        for (int w = kChunk / 64 - 1; w > (int)wave; w--) behind = vis_join(wave_own[w], behind);
+        right = vis_join(right, behind);
+        if (has_gap) right = vis_push(p, right);
+        in.lefts = has_gap ? vis_count(right) : 0u;
+        if (i < n) A.lefts_w[i] = (uint8_t)in.lefts;
+    }
     uint32_t min_before = 0xffu, min_after = 0xffu;
     chunk_window(L, in, &min_before, &min_after);
     CLIMB_STAMP(1);
-    float box[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    leaf_box(c0, A, in, box);
+    if constexpr (!RANGES) leaf_box(c0, A, in, box);
 #ifdef RT_CLIMB_STAMP
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     CLIMB_STAMP(2);
@@ -1982,6 +2120,12 @@ int scan_u32(rthip_ctx* ctx, uint32_t* d, uint64_t n, uint32_t* tmp, hipStream_t
     return RTHIP_OK;
 }
 
+// the shape scan's records: a mask and a stretch per tile of kVisTile gaps, or a stretch per chunk (range form)
+size_t vis_bytes(uint64_t n) {
+    const size_t tiles = (size_t)div_up(n, kVisTile) * (sizeof(ulonglong2) + sizeof(VisF)), chunks = (size_t)div_up(n, kChunk) * sizeof(VisF);
+    return tiles > chunks ? tiles : chunks;
+}
+
 size_t scan_tmp_elems(uint64_t n) {
     size_t total = 0;
     while (n > (uint64_t)kScanTile) {
@@ -1994,8 +2138,20 @@ size_t scan_tmp_elems(uint64_t n) {
 
 }  // namespace
 
+// Keys per tile of the sort in tiles.  Measured, whole build of random boxes, tiles of 1024 / 2048 / 4096 keys: 3 000 boxes
+// 55 / 60 / 60 us, 10 000 59 / 61 / 71, 30 000 77 / 66 / 76, 81 920 82 / 77 / 83, 131 072 114 / 93 / 92: small tiles
+// spread the tile sort over more CUs, large ones leave the merge fewer tiles to rank against.
+static uint32_t merge_tile_keys(const rthip_ctx* ctx, uint64_t n) {
+    return ctx->sort_merge_tile ? ctx->sort_merge_tile : (n <= 16384 ? 1024u : 2048u);
+}
+
+// whether a sort of n eight-byte keys can make its keys itself, as the Morton codes of boxes (radix_sort_workspace_device's codes_of)
+static bool sort_makes_codes(const rthip_ctx* ctx, uint64_t n) {
+    return n <= ctx->sort_merge_max && !ctx->sort_by_passes && merge_tile_keys(ctx, n) <= 2048;
+}
+
 int radix_sort_workspace_device(rthip_ctx* ctx, uint64_t n, int n_bytes, hipStream_t s, int* cur_io, LbvhWorkspace* ws,
-                                bool identity_vals, int first_byte) {
+                                bool identity_vals, int first_byte, const MortonSource* codes_of) {
     LbvhWorkspace& w = ws ? *ws : ctx->ws;
     // Sizes just above the merge path sort in tiles of 1024 keys, which spreads a pass over more CUs.  Measured (whole
     // build, 1024- against 4096-key tiles): 200 000 keys 0.224 / 0.241 ms, 500 000 0.274 / 0.276, 10^6 0.369 / 0.334,
@@ -2006,20 +2162,35 @@ int radix_sort_workspace_device(rthip_ctx* ctx, uint64_t n, int n_bytes, hipStre
     uint64_t* keys[2] = {(uint64_t*)w.keys[0].p, (uint64_t*)w.keys[1].p};
     uint32_t* vals[2] = {(uint32_t*)w.vals[0].p, (uint32_t*)w.vals[1].p};
     int cur = *cur_io;
-    const uint32_t small_tiles = div_up(n, kSmallTile);
-    if (small_tiles <= kMergeTiles && !ctx->sort_by_passes && first_byte == 0) {
-        tile_sort_kernel<<<small_tiles, kSmallSortBlock, 0, s>>>(keys[cur], identity_vals ? nullptr : vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, n_bytes);
+    if (n <= ctx->sort_merge_max && !ctx->sort_by_passes && first_byte == 0) {
+        // tiles sorted in LDS, then merged by rank; eight-byte keys by their upper four bytes first (tile_sort_kernel)
+        const uint32_t tile_keys = merge_tile_keys(ctx, n);
+        const uint32_t merge_tiles = div_up(n, tile_keys);
+        const int top_first = (n_bytes == 8 && ctx->sort_top_bytes == 4) ? 4 : 0;
+        const uint32_t* v_in = identity_vals ? nullptr : vals[cur];
+        if (codes_of) {
+            if (!(sort_makes_codes(ctx, n) && n_bytes == 8 && identity_vals)) return rthip_fail(ctx, RTHIP_E_INVALID, "sort: codes of boxes asked for where the sort cannot make them");
+            if (tile_keys == 1024)
+                tile_sort_kernel<256, 4, true><<<merge_tiles, 256, 0, s>>>(nullptr, nullptr, keys[cur ^ 1], vals[cur ^ 1], n, n_bytes, top_first,
+                                                                           codes_of->aabb6, codes_of->bounds, codes_of->zero_word);
+            else
+                tile_sort_kernel<512, 4, true><<<merge_tiles, 512, 0, s>>>(nullptr, nullptr, keys[cur ^ 1], vals[cur ^ 1], n, n_bytes, top_first,
+                                                                           codes_of->aabb6, codes_of->bounds, codes_of->zero_word);
+        } else if (tile_keys == 1024) tile_sort_kernel<256, 4><<<merge_tiles, 256, 0, s>>>(keys[cur], v_in, keys[cur ^ 1], vals[cur ^ 1], n, n_bytes, top_first);
+        else if (tile_keys == 2048) tile_sort_kernel<512, 4><<<merge_tiles, 512, 0, s>>>(keys[cur], v_in, keys[cur ^ 1], vals[cur ^ 1], n, n_bytes, top_first);
+        else tile_sort_kernel<512, 8><<<merge_tiles, 512, 0, s>>>(keys[cur], v_in, keys[cur ^ 1], vals[cur ^ 1], n, n_bytes, top_first);
         RT_HIP(ctx, hipGetLastError());
         cur ^= 1;
-        if (small_tiles > 1) {
+        if (merge_tiles > 1) {
             const uint64_t mask = n_bytes >= 8 ? ~0ull : ((1ull << (8 * n_bytes)) - 1ull);
-            tile_merge_kernel<<<div_up(n, 64), 256, 0, s>>>(keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], (uint32_t)n, small_tiles, mask);
+            tile_merge_kernel<<<div_up(n, 64), 256, 0, s>>>(keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], (uint32_t)n, merge_tiles, tile_keys, mask);
             RT_HIP(ctx, hipGetLastError());
             cur ^= 1;
         }
         *cur_io = cur;
         return RTHIP_OK;
     }
+    if (codes_of) return rthip_fail(ctx, RTHIP_E_INVALID, "sort: codes of boxes asked for where the sort cannot make them");
     // A one-sweep form (digit totals of all passes from one pass over the keys, tile offsets by decoupled look-back over
     // per-tile status words instead of the histogram and offsets kernels) was built and measured at 10^7 keys: 94 us
     // per pass against 61 + 18 + 6 here -- with ~600 tiles in flight a tile's predecessors have published their own
@@ -2115,7 +2286,7 @@ int lbvh_reserve_workspace(rthip_ctx* ctx, uint64_t n, LbvhWorkspace* ws) {
     RT_TRY(rthip_reserve(ctx, w.block_hist, (hist_elems + 256) * 4));
     RT_TRY(rthip_reserve(ctx, w.prio, n + 8));
     RT_TRY(rthip_reserve(ctx, w.child, 2 * n * sizeof(ChildRec)));
-    RT_TRY(rthip_reserve(ctx, w.vis, (size_t)div_up(n, kVisTile) * (sizeof(ulonglong2) + sizeof(VisF))));
+    RT_TRY(rthip_reserve(ctx, w.vis, vis_bytes(n)));
     RT_TRY(rthip_reserve(ctx, w.flags, n * 4));
     RT_TRY(rthip_reserve(ctx, w.starters, (n + 1) * 4));  // the start list of the upper kernel (at most n / 2 nodes), or every gap above the chunks (range form)
     RT_TRY(rthip_reserve(ctx, w.lefts, n + 32));
@@ -2146,6 +2317,8 @@ int lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, float4* 
     A.child = (ChildRec*)w.child.p;
     A.flags = (uint32_t*)w.flags.p;
     A.lefts = lefts;
+    A.lefts_w = lefts;
+    A.chunk_f = nullptr;
     A.starters = (uint32_t*)w.starters.p;
     A.start_count = (uint32_t*)w.flags.p + (n - 1);
     A.nodes = d_nodes;
@@ -2178,8 +2351,14 @@ int lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, float4* 
     }
     ctx->bounds_of = nullptr;
     // values: see identity_vals; the arrival counters of the n - 1 gaps + the starter count are cleared on the way
-    morton_kernel<<<div_up(n, kBlock) < 4096u ? div_up(n, kBlock) : 4096u, kBlock, 0, s>>>(d_aabb6, n, bounds, keys[0], nullptr, (uint32_t*)w.flags.p);
-    RT_HIP(ctx, hipGetLastError());
+    // The range form has no arrival counters, only its list's length to clear: when nobody asks for the unsorted codes
+    // and the sort is one in tiles, the tile sort makes the codes itself and clears that word (one launch fewer).
+    const bool sort_codes = A.ranges && !d_codes_unsorted && sort_makes_codes(ctx, n);
+    const MortonSource codes_of = {d_aabb6, bounds, A.start_count};
+    if (!sort_codes) {
+        morton_kernel<<<div_up(n, kBlock) < 4096u ? div_up(n, kBlock) : 4096u, kBlock, 0, s>>>(d_aabb6, n, bounds, keys[0], nullptr, (uint32_t*)w.flags.p);
+        RT_HIP(ctx, hipGetLastError());
+    }
     if (d_codes_unsorted)
         RT_HIP(ctx, hipMemcpyAsync(d_codes_unsorted, keys[0], n * 8, hipMemcpyDeviceToDevice, s));
 
@@ -2192,7 +2371,7 @@ int lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, float4* 
     bool sorted = false;
     hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
     if (s) (void)hipStreamIsCapturing(s, &capturing);
-    if (n > kTopSortMin && ctx->sort_top_bytes < 8 && ctx->sort_top_gave_up_n != n && capturing == hipStreamCaptureStatusNone) {
+    if (n > ctx->sort_merge_max && n > kTopSortMin && ctx->sort_top_bytes < 8 && ctx->sort_top_gave_up_n != n && capturing == hipStreamCaptureStatusNone) {
         uint32_t* gave_up = (uint32_t*)w.bounds.p + kBoundSlots * kBoundStride;  // a word behind the bounds' copies
         RT_HIP(ctx, hipMemsetAsync(gave_up, 0, 4, s));
         RT_TRY(radix_sort_workspace_device(ctx, n, 8, s, &cur, &w, true, 8 - ctx->sort_top_bytes));
@@ -2210,7 +2389,7 @@ int lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, float4* 
             cur = 0;
         }
     }
-    if (!sorted) RT_TRY(radix_sort_workspace_device(ctx, n, 8, s, &cur, &w, true));
+    if (!sorted) RT_TRY(radix_sort_workspace_device(ctx, n, 8, s, &cur, &w, true, 0, sort_codes ? &codes_of : nullptr));
     if (d_keys_sorted) RT_HIP(ctx, hipMemcpyAsync(d_keys_sorted, keys[cur], n * 8, hipMemcpyDeviceToDevice, s));
     if (d_ids_sorted) RT_HIP(ctx, hipMemcpyAsync(d_ids_sorted, vals[cur], n * 4, hipMemcpyDeviceToDevice, s));
 
@@ -2222,10 +2401,16 @@ int lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, float4* 
     const uint32_t vtiles = div_up(n, kVisTile);
     ulonglong2* tile_in = (ulonglong2*)w.vis.p;
     VisF* tile_f = (VisF*)(tile_in + vtiles);
-    vis_tile_kernel<<<vtiles, kBlock, 0, s>>>(keys[cur], (uint32_t)n, prio, tile_f);
-    RT_HIP(ctx, hipGetLastError());
-    if (vtiles > kVisFusedTiles) vis_tiles_kernel<<<1, kVisTilesBlock, 0, s>>>(tile_f, vtiles, tile_in);
-    vis_leaf_kernel<<<vtiles, kBlock, 0, s>>>(prio, (uint32_t)n, tile_f, vtiles, vtiles > kVisFusedTiles ? tile_in : nullptr, lefts);
+    if (A.ranges) {
+        // the range form's chunk kernel finishes the scan for its own leaves: one stretch per chunk is all it needs
+        A.chunk_f = (const VisF*)w.vis.p;
+        vis_tile_kernel<kChunk / kBlock><<<chunks, kBlock, 0, s>>>(keys[cur], (uint32_t)n, prio, (VisF*)w.vis.p);
+    } else {
+        vis_tile_kernel<kVisItems><<<vtiles, kBlock, 0, s>>>(keys[cur], (uint32_t)n, prio, tile_f);
+        RT_HIP(ctx, hipGetLastError());
+        if (vtiles > kVisFusedTiles) vis_tiles_kernel<<<1, kVisTilesBlock, 0, s>>>(tile_f, vtiles, tile_in);
+        vis_leaf_kernel<<<vtiles, kBlock, 0, s>>>(prio, (uint32_t)n, tile_f, vtiles, vtiles > kVisFusedTiles ? tile_in : nullptr, lefts);
+    }
     RT_HIP(ctx, hipGetLastError());
     // boxes: every node's record goes to its pre-order place
     if (A.ranges) {
@@ -2302,7 +2487,7 @@ int lbvh_static_workspace_init(rthip_ctx* ctx) {
               carve(w.vals[1], base, off, n * 4) &&
               carve(w.block_hist, base, off, hist_bytes) &&
               carve(w.prio, base, off, n + 8) && carve(w.child, base, off, 2 * n * sizeof(ChildRec)) &&
-              carve(w.vis, base, off, (size_t)div_up(n, kVisTile) * (sizeof(ulonglong2) + sizeof(VisF))) && carve(w.flags, base, off, n * 4) &&
+              carve(w.vis, base, off, vis_bytes(n)) && carve(w.flags, base, off, n * 4) &&
               carve(w.starters, base, off, (n + 1) * 4) && carve(w.lefts, base, off, n + 32) && carve(w.bounds, base, off, kBoundBytes);
     if (!ok) return rthip_fail(ctx, RTHIP_E_LIMIT, "the static workspace of %zu bytes is too small for %llu boxes", kStaticBytes, (unsigned long long)n);
     ctx->ws_static_ready = true;

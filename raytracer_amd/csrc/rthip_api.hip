@@ -181,6 +181,12 @@ int rthip_create(rthip_ctx** out_ctx, int device_id) {
     if (top_bytes && (top_bytes[0] == '4' || top_bytes[0] == '8')) ctx->sort_top_bytes = top_bytes[0] - '0';
     const char* small_tile = getenv("RTHIP_SORT_SMALL_TILE_MAX");
     if (small_tile && small_tile[0]) ctx->sort_small_tile_max = strtoull(small_tile, nullptr, 10);
+    const char* merge_tile = getenv("RTHIP_SORT_MERGE_TILE");
+    if (merge_tile && (atoi(merge_tile) == 1024 || atoi(merge_tile) == 2048 || atoi(merge_tile) == 4096)) ctx->sort_merge_tile = (uint32_t)atoi(merge_tile);
+    const char* merge_max = getenv("RTHIP_SORT_MERGE_MAX");
+    if (merge_max && merge_max[0]) ctx->sort_merge_max = strtoull(merge_max, nullptr, 10);
+    if (ctx->sort_merge_max > 128ull * (ctx->sort_merge_tile ? ctx->sort_merge_tile : 2048u))  // tile_merge_kernel: 32 tiles per wave
+        ctx->sort_merge_max = 128ull * (ctx->sort_merge_tile ? ctx->sort_merge_tile : 2048u);
     const char* ranges = getenv("RTHIP_UPPER_RANGES");
     if (ranges && (ranges[0] == '0' || ranges[0] == '1')) ctx->upper_ranges = ranges[0] - '0';
     const char* wide = getenv("RTHIP_UPPER_DEVICE_WIDE");

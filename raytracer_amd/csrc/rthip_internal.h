@@ -149,6 +149,8 @@ struct rthip_ctx {
     int sort_top_bytes = 4;     // large LBVH builds sort by this many upper key bytes and finish locally; 8: all passes (RTHIP_SORT_TOP_BYTES)
     uint64_t sort_top_gave_up_n = 0;  // a build of this many boxes needed all eight passes after all: not tried again
     int sort_by_passes = 0;     // RTHIP_SORT_BY_PASSES=1: small sorts also go pass by pass through HBM (diagnostic)
+    uint32_t sort_merge_tile = 0;           // keys per tile of the sort-in-LDS-then-merge path: 1024, 2048 or 4096; 0: by size (RTHIP_SORT_MERGE_TILE)
+    uint64_t sort_merge_max = 1ull << 17;   // sorts of up to this many keys take that path, at most 128 tiles (RTHIP_SORT_MERGE_MAX)
     uint64_t sort_small_tile_max = 1ull << 18;  // sorts of up to this many keys use 1024-key tiles (RTHIP_SORT_SMALL_TILE_MAX)
     int upper_ranges = 1;       // builds of up to 2^17 leaves take the nodes above the chunks from leaf ranges (RTHIP_UPPER_RANGES=0: the chain of hand-offs in one workgroup)
     int upper_device_wide = 0;  // RTHIP_UPPER_DEVICE_WIDE=1: never run the upper climbs in one workgroup (diagnostic)
@@ -284,8 +286,15 @@ int lbvh_static_workspace_init(rthip_ctx* ctx);
 // reserved both ping-pong pairs) by the key's low n_bytes bytes; *cur names the pair that holds the result.
 // identity_vals: the values are the positions 0 .. n-1 and need not be stored before the call (vals[*cur] is not read).
 // first_byte > 0: only the passes over bytes first_byte .. n_bytes-1 (a stable sort by those bytes alone).
+// codes_of: the keys are not in keys[*cur] yet; they are the Morton codes of these boxes and the sort makes them itself
+// (eight-byte keys, identity values, a sort in tiles only: see lbvh_build_device).
+struct MortonSource {
+    const float* aabb6;       // the boxes
+    const uint32_t* bounds;   // the centroid bounds' slots
+    uint32_t* zero_word;      // a word to clear on the way
+};
 int radix_sort_workspace_device(rthip_ctx* ctx, uint64_t n, int n_bytes, hipStream_t stream, int* cur, LbvhWorkspace* ws = nullptr,
-                                bool identity_vals = false, int first_byte = 0);
+                                bool identity_vals = false, int first_byte = 0, const MortonSource* codes_of = nullptr);
 // In-place inclusive prefix sum of n uint32.
 int scan_inclusive_u32_device(rthip_ctx* ctx, uint32_t* d, uint64_t n, hipStream_t stream);
 

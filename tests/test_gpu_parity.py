@@ -140,10 +140,10 @@ def test_hierarchy_hand_off_modes_build_the_same_tree(oracle):
             os.environ["RTHIP_REFIT_FENCE"] = old
 
 
-@pytest.mark.parametrize("n", [513, 1023, 1024, 1025, 2049, 4097, 65_537, 131_072, 131_073, 262_144, 262_145])
+@pytest.mark.parametrize("n", [513, 1023, 1024, 1025, 2048, 2049, 4097, 16_384, 16_385, 65_537, 131_072, 131_073, 262_144, 262_145])
 def test_lbvh_sizes_at_the_seams_of_the_builder(oracle, n):
     """Sizes just below, at and above the points where the builder changes its path: one workgroup (512), tiles of the
-    tile sort (1024), tile sort + merge against radix passes (131 072), small against large radix tiles (262 144), the
+    tile sort (1024 keys up to 16 384 boxes, 2048 above), tile sort + merge against radix passes (131 072), small against large radix tiles (262 144), the
     upper box climb in one workgroup (131 072).  Half of the boxes sit on a lattice (runs of equal codes, pairs among
     them, as the two triangles of a quad give).  Every size against the oracle, and the same tree when the sort goes
     pass by pass, when the upper climb runs device-wide, and when builds of up to 131 072 leaves climb by hand-offs in one
@@ -228,6 +228,59 @@ def test_lbvh_sort_by_upper_bytes(oracle, capfd, case):
             os.environ.pop("RTHIP_TUNE_LOG", None)
         else:
             os.environ["RTHIP_TUNE_LOG"] = saved
+
+
+@pytest.mark.parametrize("case", ["uniform", "clusters", "dense_cloud", "identical", "stretch_31", "stretch_32", "stretch_200"])
+def test_lbvh_tile_sort_by_upper_bytes(oracle, case):
+    """Builds of up to 131 072 boxes sort tiles of keys in LDS by the upper four key bytes, finish the stretches of keys
+    that share them by ranking inside the tile (up to 31 keys), start the tile again with all eight digits when a
+    stretch is longer, and merge the tiles by rank; in the default form of the climb the tile sort makes the Morton
+    codes itself.  Every case against the oracle -- uniform boxes, clusters of 20 boxes within 1e-5 (every stretch needs
+    work, many straddle tiles), a cloud inside 1e-4 of the scene and identical boxes (long stretches: all digits),
+    stretches of exactly 31, 32 and 200 keys in descending order -- with each tile size, with all eight digits from the
+    start, and with the climb by hand-offs (codes from their own kernel)."""
+    n = 60_000
+    rng = np.random.default_rng(17)
+    cen = rng.random((n, 3)).astype(np.float32)
+    if case == "clusters":
+        centres = rng.random((3000, 3)).astype(np.float32)
+        cen = centres[rng.integers(0, 3000, n)] + (rng.random((n, 3)).astype(np.float32) - 0.5) * 1e-5
+    elif case == "dense_cloud":
+        cen[: n // 2] = 0.5 + (rng.random((n // 2, 3)).astype(np.float32) - 0.5) * 1e-4
+    elif case == "identical":
+        cen[: n // 2] = 0.375
+    elif case.startswith("stretch_"):
+        length = int(case.split("_")[1])
+        cells = 20_000 // length
+        j = np.arange(length, dtype=np.float64)[::-1]
+        xs = (np.arange(cells, dtype=np.float64)[:, None] + 17) / 1024.0 + (j[None, :] + 1) * 2.0 ** -20
+        m = cells * length
+        cen[:m, 0] = xs.reshape(-1).astype(np.float32)  # one stretch per 2^-10 wide cell of x, handed over in reverse
+        cen[:m, 1:] = 0.25
+        cen[m:, 0] = 0.9 + 0.1 * cen[m:, 0]  # the rest lies beyond the cells
+    cen[-2], cen[-1] = (0.0, 0.0, 0.0), (1.0, 1.0, 1.0)  # fix the bounds
+    half = np.full((n, 3), 1e-6, dtype=np.float32)
+    boxes = np.concatenate([cen - half, cen + half], axis=1).astype(np.float32)
+    want = oracle.lbvh_build(boxes)[3]
+    names = ("RTHIP_SORT_MERGE_TILE", "RTHIP_SORT_TOP_BYTES", "RTHIP_UPPER_RANGES")
+    saved = {k: os.environ.get(k) for k in names}
+    try:
+        for env in ({}, {"RTHIP_SORT_MERGE_TILE": "1024"}, {"RTHIP_SORT_MERGE_TILE": "4096"}, {"RTHIP_SORT_TOP_BYTES": "8"},
+                    {"RTHIP_UPPER_RANGES": "0"}):
+            for k in names:
+                os.environ.pop(k, None)
+            os.environ.update(env)
+            t = T.rt_make_tracer(T.RT_TracerSettings(max_bounces=1, sky=True), device_id=0)
+            try:
+                assert_same_tree(T.lbvh_build(t, boxes)[3], want, f"{case}, {env}")
+            finally:
+                T.rt_tracer_cleanup(t)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
 
 
 def test_large_build_can_be_captured_in_a_hip_graph(gpu_tracer):
