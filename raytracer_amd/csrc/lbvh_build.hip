@@ -531,7 +531,11 @@ __global__ __launch_bounds__(BLOCK) void tile_sort_kernel(const uint64_t* __rest
             // pass's later barriers), so clearing them needs no barrier
 #pragma unroll
             for (int q = 0; q < 4; q++) wave_cnt[wave][q * 64 + lane] = 0;
-            uint32_t rank[ITEMS];
+            // the first lane of every group of equal digits adds the group's size to the wave's counter; the items' adds
+            // are issued one behind the other (LDS keeps a wave's order, so item j counts before item j + 1) and waited
+            // for together
+            uint32_t rank[ITEMS], old[ITEMS];
+            int leader[ITEMS];
 #pragma unroll
             for (int j = 0; j < ITEMS; j++) {
                 const uint32_t d = (uint32_t)(key[j] >> shift) & 255u;
@@ -542,15 +546,13 @@ __global__ __launch_bounds__(BLOCK) void tile_sort_kernel(const uint64_t* __rest
                     const uint64_t bal = __ballot(bit);
                     same &= bit ? bal : ~bal;
                 }
-                const uint32_t below = __popcll(same & lt_mask);
-                uint32_t old = 0;
-                if (below == 0) {
-                    old = wave_cnt[wave][d];
-                    wave_cnt[wave][d] = old + __popcll(same);
-                }
-                old = __shfl(old, __ffsll((long long)same) - 1);
-                rank[j] = old + below;
+                rank[j] = __popcll(same & lt_mask);
+                leader[j] = __ffsll((long long)same) - 1;
+                old[j] = 0;
+                if (rank[j] == 0) old[j] = atomicAdd(&wave_cnt[wave][d], (uint32_t)__popcll(same));
             }
+#pragma unroll
+            for (int j = 0; j < ITEMS; j++) rank[j] += __shfl(old[j], leader[j]);
             __syncthreads();
             {   // thread d: offsets of each wave inside digit d, then the exclusive scan over the digits
                 uint32_t run = 0;
@@ -1270,7 +1272,7 @@ struct ClimbArgs {
     uint16_t* tab;             // per chunk 256 entries: [q] the rightmost window entry in 0 .. kChunk-1 with a priority below q,
                                // [128 + q] the leftmost window entry in 1 .. kChunk with a priority below q (0xffff: none)
     uint8_t* cmin;             // per chunk 2 bytes: the smallest priority among window entries 0 .. kChunk-1, and among 1 .. kChunk
-    uint32_t ranges;           // 1: this form
+    uint32_t ranges;           // 1: this form above the chunks; 2: inside the chunks as well (chunk_local_ranges)
 };
 
 #ifdef RT_CLIMB_STAMP
@@ -1288,7 +1290,7 @@ struct ClimbLds {
     uint16_t queue[3][kChunk / 2];     // the gaps (relative to c0) whose second child arrived in the generation before
     uint16_t pend[kChunk];             // gap - c0 + 1 of the parents that span chunks at which this chunk left a record
     uint16_t stage[kChunk];            // of those, the ones that this chunk found complete: for the upper kernel
-    uint32_t qn[3], n_pend, n_start;
+    uint32_t qn[3], n_pend, n_start, range_cmin0;
     uint32_t wmin_l[kChunk / 64], wmin_r[kChunk / 64];
     // window of gap priorities: entry k is gap c0 - 1 + k, k = 0 .. kChunk; bit 7 marks a local gap.
     // Gaps that do not exist (-1, >= n-1) read as 0, below every real priority (>= 1).
@@ -1499,13 +1501,40 @@ __device__ __forceinline__ void chunk_climb(ClimbLds& L, uint32_t c0, const Clim
     }
 }
 
+// The chunk's part of the list of gaps above the chunks goes to memory: one device-wide atomic per chunk, whose answer
+// takes a microsecond or two -- only wave 0 waits for it.  After a barrier behind chunk_ranges' last wave_push.
+// chunk_ranges_claim asks for the chunk's place in the list (thread 0; the answer is first used in chunk_ranges_flush, so
+// whatever lies between the two calls runs while it is on its way).
+__device__ __forceinline__ uint32_t chunk_ranges_claim(ClimbLds& L, uint32_t c0, const ClimbArgs& A) {
+    const uint64_t end_gap = (uint64_t)c0 - 1u + kChunk;
+    uint32_t base = 0;
+    if (threadIdx.x == 0u) base = atomicAdd(A.start_count, L.n_start + (end_gap + 1u < A.n ? 1u : 0u));
+    return base;
+}
+__device__ __forceinline__ void chunk_ranges_flush(ClimbLds& L, uint32_t c0, const ClimbArgs& A, uint32_t base) {
+    const uint32_t n = A.n, tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t e_end = (uint32_t)L.win[kChunk] & 0x7fu;
+    const uint32_t cmin0 = L.range_cmin0;
+    const uint32_t total = L.n_start;
+    const uint64_t end_gap = (uint64_t)c0 - 1u + kChunk;
+    const bool end_exists = end_gap + 1u < n;
+    if (tid < 64u) {
+        base = __shfl(base, 0);
+        for (uint32_t k = lane; k < total; k += 64u) {
+            const uint32_t v = L.stage[k], entry = v & 0x3fffu;
+            A.starters[base + k] = (c0 - 1u + entry) | (((uint32_t)L.win[entry] & 0x7fu) << 17) | ((v & 0xc000u) << 16);
+        }
+        if (lane == 0u && end_exists) A.starters[base + total] = (uint32_t)end_gap | (e_end << 17) | (cmin0 < e_end ? 0x40000000u : 0u);
+    }
+}
+
 // What the range form of the climb above the chunks needs from a chunk (see range_upper_kernel): every leaf's prefix
 // and suffix box inside the chunk, the chunk's two tables of "nearest gap with a priority below q", and the list of
 // the chunk's gaps whose nodes reach beyond it.  Window entry k is gap c0 - 1 + k (chunk_window); a gap beyond the
 // array's ends has priority 0, below every real one, and so ends every search.  Call after chunk_window, by all threads.
 __device__ __forceinline__ void merge_after(float* acc, const float* later) { merge_sibling(acc, later, true); }
 __device__ __forceinline__ void chunk_ranges(ClimbLds& L, uint32_t c0, const ClimbArgs& A, const float* box, uint32_t min_before,
-                                             uint32_t min_after) {
+                                             uint32_t min_after, bool flush_now) {
     const uint32_t n = A.n, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t chunk = c0 / (uint32_t)kChunk;
     const float inf = __uint_as_float(0x7f800000u);
@@ -1608,6 +1637,7 @@ __device__ __forceinline__ void chunk_ranges(ClimbLds& L, uint32_t c0, const Cli
     __syncthreads();
     if (tid < 256u) A.tab[256u * chunk + tid] = tab[tid];
     if (tid < 2u) A.cmin[2u * chunk + tid] = (uint8_t)cmins[tid];
+    if (tid == 0u) L.range_cmin0 = cmins[0];  // for chunk_ranges_flush
     // ---- the gaps whose nodes reach beyond the chunk: entries 1 .. kChunk-1 that are not local, and entry kChunk.
     // List word: the gap, its priority in bits 17-23, bit 30: a smaller priority among the entries before it in the
     // window, bit 31: among those after it.
@@ -1617,22 +1647,195 @@ __device__ __forceinline__ void chunk_ranges(ClimbLds& L, uint32_t c0, const Cli
         const bool upper = exists && (L.win[tid] & 0x80u) == 0u;
         wave_push(upper, tid | (min_before < e ? 0x4000u : 0u) | (min_after < e ? 0x8000u : 0u), &L.n_start, L.stage);
     }
-    lds_barrier();
-    const uint32_t total = L.n_start;
-    const uint64_t end_gap = (uint64_t)c0 - 1u + kChunk;
-    const bool end_exists = end_gap + 1u < n;
-    if (tid < 64u) {
-        uint32_t base = 0;
-        if (lane == 0u) base = atomicAdd(A.start_count, total + (end_exists ? 1u : 0u));
-        base = __shfl(base, 0);
-        for (uint32_t k = lane; k < total; k += 64u) {
-            const uint32_t v = L.stage[k], entry = v & 0x3fffu;
-            A.starters[base + k] = (c0 - 1u + entry) | (((uint32_t)L.win[entry] & 0x7fu) << 17) | ((v & 0xc000u) << 16);
+    if (flush_now) {  // otherwise the caller flushes, behind a barrier of its own
+        lds_barrier();
+        chunk_ranges_flush(L, c0, A, chunk_ranges_claim(L, c0, A));
+        lds_barrier();
+        if (tid == 0u) L.n_start = 0;
+    }
+}
+
+// The nodes INSIDE a chunk by leaf ranges as well (instead of chunk_climb's dozen generations of hand-offs): one thread
+// per gap of the window.  A local gap's node covers the leaves between the nearest entries of smaller priority on either
+// side; its box is the reduction of those leaves' boxes in leaf order, which has the bits of the nested merges however it
+// is bracketed (merge_after keeps the later operand on ties, as the reference's Min / Max do); its place follows from
+// the shape byte of its last leaf.
+//   * nearest smaller entry: inside the wave from ballots, one round per distinct priority among the wave's local gaps;
+//     beyond the wave from per-wave tables "rightmost / leftmost entry with a priority below q" (marked with LDS atomics,
+//     finished by a prefix maximum / minimum over q), looked up wave by wave;
+//   * boxes: per leaf the box from its block of 8's first leaf up to it and from it to the block's last leaf (segmented
+//     scans by shuffles), a sparse table over the 64 blocks' boxes (built by wave 0 with shuffles); a range is one
+//     suffix, at most two table entries and one prefix, or up to 8 leaves of one block.
+// The leaves' boxes, the prefixes and the waves' tables lie in ClimbLds::lrec, which this form does not use.
+struct LocalRangeLds {
+    float suf8[kChunk][6];       // leaf i .. the last leaf of its block
+    float sp[5][kChunk / 8][6];  // sp[k - 1][b]: blocks b .. b + 2^k - 1
+    uint8_t lefts[kChunk];
+};
+static_assert(sizeof(ChildRec) * 2 * kChunk >= 2 * kChunk * 6 * sizeof(float) + 2 * (kChunk / 64) * 128 * sizeof(uint32_t), "lrec holds the tables");
+
+template <bool PAIRED>
+__device__ __forceinline__ void chunk_local_ranges(ClimbLds& L, LocalRangeLds& R, uint32_t c0, const ClimbArgs& A, const LeafIn& in,
+                                                   const float* box) {
+    const uint32_t n = A.n, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    float(*lb)[6] = reinterpret_cast<float(*)[6]>(L.lrec);
+    float(*pre8)[6] = lb + kChunk;  // the block's first leaf .. leaf i
+    uint32_t(*near_r)[128] = reinterpret_cast<uint32_t(*)[128]>(pre8 + kChunk);  // [wave][q]: lane + 1 of the rightmost entry below q (0: none)
+    uint32_t(*near_l)[128] = near_r + kChunk / 64;                                // [wave][q]: lane of the leftmost (0xff: none)
+    const float inf = __uint_as_float(0x7f800000u);
+    const uint32_t i = c0 + tid;
+    if (i < n) {
+        const uint32_t pre = 2u * i + in.lefts;
+        put_node<PAIRED>(A.nodes, pre, box, pre + 1, in.prim + 1);  // id = idx + 1, lbvh.c:116
+    }
+    {
+        float p8[6], s8[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) p8[k] = s8[k] = (i < n) ? box[k] : (k < 3 ? inf : -inf);
+#pragma unroll
+        for (int k = 0; k < 6; k++) lb[tid][k] = p8[k];
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {
+            float up[6], down[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                up[k] = __shfl_up(p8[k], o);
+                down[k] = __shfl_down(s8[k], o);
+            }
+            if ((lane & 7u) >= (uint32_t)o) {
+                merge_after(up, p8);
+#pragma unroll
+                for (int k = 0; k < 6; k++) p8[k] = up[k];
+            }
+            if ((lane & 7u) + (uint32_t)o < 8u) merge_after(s8, down);
         }
-        if (lane == 0u && end_exists) A.starters[base + total] = (uint32_t)end_gap | (e_end << 17) | (cmins[0] < e_end ? 0x40000000u : 0u);
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            pre8[tid][k] = p8[k];
+            R.suf8[tid][k] = s8[k];
+        }
+        R.lefts[tid] = (uint8_t)in.lefts;
+    }
+    // ---- the wave's tables
+    const uint32_t e = (uint32_t)L.win[tid] & 0x7fu;  // entry tid: gap c0 - 1 + tid (0: there is none)
+    const bool local = (L.win[tid] & 0x80u) != 0u;
+    near_r[wave][lane] = near_r[wave][lane + 64u] = 0u;
+    near_l[wave][lane] = near_l[wave][lane + 64u] = 0xffu;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+    if (e < 127u) {
+        atomicMax(&near_r[wave][e + 1u], lane + 1u);
+        atomicMin(&near_l[wave][e + 1u], lane);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+    {   // prefix maximum / minimum over q, two slots per lane
+        uint32_t a = near_r[wave][2u * lane], b = near_r[wave][2u * lane + 1u];
+        uint32_t c = near_l[wave][2u * lane], d = near_l[wave][2u * lane + 1u];
+        b = a > b ? a : b;
+        d = c < d ? c : d;
+        uint32_t run_r = b, run_l = d;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t u = __shfl_up(run_r, o), v = __shfl_up(run_l, o);
+            if (lane >= (uint32_t)o) {
+                run_r = u > run_r ? u : run_r;
+                run_l = v < run_l ? v : run_l;
+            }
+        }
+        const uint32_t prev_r = __shfl_up(run_r, 1), prev_l = __shfl_up(run_l, 1);
+        if (lane > 0u) {
+            a = prev_r > a ? prev_r : a;
+            c = prev_l < c ? prev_l : c;
+        }
+        near_r[wave][2u * lane] = a;
+        near_r[wave][2u * lane + 1u] = run_r;
+        near_l[wave][2u * lane] = c;
+        near_l[wave][2u * lane + 1u] = run_l;
+    }
+    // ---- nearest smaller entries inside the wave
+    uint32_t jl = 0xffffu, jr = 0xffffu;
+    {
+        const uint64_t lt = (1ull << lane) - 1ull, gt = ~lt & ~(1ull << lane);
+        uint64_t todo = __ballot(local);
+        while (todo != 0ull) {
+            const uint32_t q = (uint32_t)__builtin_amdgcn_readlane((int)e, __ffsll((long long)todo) - 1);  // todo is uniform
+            const uint64_t smaller = __ballot(e < q), same = __ballot(e == q);
+            if (local && e == q) {
+                const uint64_t lo = smaller & lt, hi = smaller & gt;
+                if (lo != 0ull) jl = wave * 64u + 63u - (uint32_t)__clzll((long long)lo);
+                if (hi != 0ull) jr = wave * 64u + (uint32_t)__ffsll((long long)hi) - 1u;
+            }
+            todo &= ~same;
+        }
+    }
+    CLIMB_STAMP(6);
+    lds_barrier();
+    const uint32_t list_base = chunk_ranges_claim(L, c0, A);  // chunk_ranges' list is complete behind this barrier
+    if (wave == 0u) {  // the sparse table over the blocks' boxes: lane b holds blocks b .. b + 2^k - 1
+        float cur[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) cur[k] = pre8[8u * lane + 7u][k];
+#pragma unroll
+        for (int k = 1; k <= 5; k++) {
+            float other[6];
+#pragma unroll
+            for (int c = 0; c < 6; c++) other[c] = __shfl_down(cur[c], 1 << (k - 1));
+            if (lane + (1u << k) <= 64u) {
+                merge_after(cur, other);
+#pragma unroll
+                for (int c = 0; c < 6; c++) R.sp[k - 1][lane][c] = cur[c];
+            }
+        }
+    }
+    if (local) {  // beyond the wave; a local gap has both of its bounds inside the window
+        if (jl == 0xffffu) {
+            for (int w = (int)wave - 1; w >= 0; w--) {
+                const uint32_t v = near_r[w][e];
+                if (v != 0u) {
+                    jl = (uint32_t)w * 64u + v - 1u;
+                    break;
+                }
+            }
+        }
+        if (jr == 0xffffu) {
+            jr = (uint32_t)kChunk;
+            for (uint32_t w = wave + 1u; w < (uint32_t)kChunk / 64u; w++) {
+                const uint32_t v = near_l[w][e];
+                if (v != 0xffu) {
+                    jr = w * 64u + v;
+                    break;
+                }
+            }
+        }
     }
     lds_barrier();
-    if (tid == 0u) L.n_start = 0;
+    CLIMB_STAMP(7);
+    if (local) {
+        const uint32_t l = jl, r = jr - 1u;  // the leaf behind gap jl .. the leaf in front of gap jr, relative to c0
+        const uint32_t bl = l >> 3, br = r >> 3;
+        float b[6];
+        if (bl == br) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) b[k] = lb[l][k];
+            for (uint32_t t = l + 1u; t <= r; t++) merge_after(b, lb[t]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 6; k++) b[k] = R.suf8[l][k];
+            if (br > bl + 1u) {  // whole blocks bl + 1 .. br - 1
+                const uint32_t count = br - bl - 1u, k = 31u - (uint32_t)__clz(count);
+                const float* first = k == 0u ? pre8[8u * (bl + 1u) + 7u] : R.sp[k - 1u][bl + 1u];
+                const float* second = k == 0u ? pre8[8u * (br - 1u) + 7u] : R.sp[k - 1u][br - (1u << k)];
+                merge_after(b, first);
+                merge_after(b, second);
+            }
+            merge_after(b, pre8[r]);
+        }
+        put_inner<PAIRED>(A.nodes, b, c0 + l, c0 + r, (uint32_t)R.lefts[r]);
+    }
+    chunk_ranges_flush(L, c0, A, list_base);
 }
 
 template <bool PAIRED, bool RANGES = false>
@@ -1691,7 +1894,20 @@ __global__ __launch_bounds__(kChunk) void climb_local_kernel(ClimbArgs A) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     CLIMB_STAMP(2);
 #endif
-    if constexpr (RANGES) chunk_ranges(L, c0, A, box, min_before, min_after);  // its LDS exists in this instance only
+    if constexpr (RANGES) {  // their LDS exists in this instance only
+        __shared__ LocalRangeLds R;
+        chunk_ranges(L, c0, A, box, min_before, min_after, A.ranges != 2u);
+        CLIMB_STAMP(3);
+        if (A.ranges == 2u) {
+            chunk_local_ranges<PAIRED>(L, R, c0, A, in, box);  // flushes the list of the gaps above the chunk as well
+            CLIMB_STAMP(4);
+#ifdef RT_CLIMB_STAMP
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            CLIMB_STAMP(5);
+#endif
+            return;
+        }
+    }
     chunk_climb<PAIRED>(L, c0, A, in, box);
     CLIMB_STAMP(4);
 #ifdef RT_CLIMB_STAMP
@@ -2325,7 +2541,7 @@ int lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, float4* 
     // up to kOneGroupUpper leaves the nodes above the chunks can come from leaf ranges instead of a chain of hand-offs
     // (range_upper_kernel); the child records' and the counters' buffers then hold the range form's tables
     const uint32_t n_chunks = div_up(n, kChunk);
-    A.ranges = (n > (uint64_t)kChunk && n <= kOneGroupUpper && ctx->upper_ranges && !ctx->upper_device_wide) ? 1u : 0u;
+    A.ranges = (n > (uint64_t)kChunk && n <= kOneGroupUpper && ctx->upper_ranges && !ctx->upper_device_wide) ? (uint32_t)ctx->upper_ranges : 0u;
     A.pre_box = (float*)w.child.p;
     A.suf_box = A.pre_box + 6 * n;
     A.tab = (uint16_t*)w.flags.p;

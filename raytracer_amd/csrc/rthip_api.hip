@@ -188,7 +188,7 @@ int rthip_create(rthip_ctx** out_ctx, int device_id) {
     if (ctx->sort_merge_max > 128ull * (ctx->sort_merge_tile ? ctx->sort_merge_tile : 2048u))  // tile_merge_kernel: 32 tiles per wave
         ctx->sort_merge_max = 128ull * (ctx->sort_merge_tile ? ctx->sort_merge_tile : 2048u);
     const char* ranges = getenv("RTHIP_UPPER_RANGES");
-    if (ranges && (ranges[0] == '0' || ranges[0] == '1')) ctx->upper_ranges = ranges[0] - '0';
+    if (ranges && ranges[0] >= '0' && ranges[0] <= '2') ctx->upper_ranges = ranges[0] - '0';
     const char* wide = getenv("RTHIP_UPPER_DEVICE_WIDE");
     ctx->upper_device_wide = (wide && wide[0] == '1') ? 1 : 0;
     const char* mode = getenv("RTHIP_CAST");

@@ -152,7 +152,7 @@ struct rthip_ctx {
     uint32_t sort_merge_tile = 0;           // keys per tile of the sort-in-LDS-then-merge path: 1024, 2048 or 4096; 0: by size (RTHIP_SORT_MERGE_TILE)
     uint64_t sort_merge_max = 1ull << 17;   // sorts of up to this many keys take that path, at most 128 tiles (RTHIP_SORT_MERGE_MAX)
     uint64_t sort_small_tile_max = 1ull << 18;  // sorts of up to this many keys use 1024-key tiles (RTHIP_SORT_SMALL_TILE_MAX)
-    int upper_ranges = 1;       // builds of up to 2^17 leaves take the nodes above the chunks from leaf ranges (RTHIP_UPPER_RANGES=0: the chain of hand-offs in one workgroup)
+    int upper_ranges = 2;       // builds of up to 2^17 leaves take their inner nodes from leaf ranges: 2 all of them, 1 only those above the chunks (generations of hand-offs inside), 0 hand-offs throughout (RTHIP_UPPER_RANGES)
     int upper_device_wide = 0;  // RTHIP_UPPER_DEVICE_WIDE=1: never run the upper climbs in one workgroup (diagnostic)
     int refit_fence = 2;  // hand-offs of the upper hierarchy kernels: 0 release / acquire through the counter, 1 __threadfence(), 2 relaxed + s_waitcnt (default)
 

@@ -158,7 +158,7 @@ def test_lbvh_sizes_at_the_seams_of_the_builder(oracle, n):
     saved = {k: os.environ.get(k) for k in ("RTHIP_SORT_BY_PASSES", "RTHIP_UPPER_DEVICE_WIDE", "RTHIP_SORT_SMALL_TILE_MAX", "RTHIP_UPPER_RANGES")}
     try:
         for env in ({}, {"RTHIP_SORT_BY_PASSES": "1", "RTHIP_UPPER_DEVICE_WIDE": "1"}, {"RTHIP_SORT_BY_PASSES": "1", "RTHIP_SORT_SMALL_TILE_MAX": "0"},
-                    {"RTHIP_UPPER_RANGES": "0"}):
+                    {"RTHIP_UPPER_RANGES": "0"}, {"RTHIP_UPPER_RANGES": "1"}):
             for k in saved:
                 os.environ.pop(k, None)
             os.environ.update(env)
@@ -266,7 +266,7 @@ def test_lbvh_tile_sort_by_upper_bytes(oracle, case):
     saved = {k: os.environ.get(k) for k in names}
     try:
         for env in ({}, {"RTHIP_SORT_MERGE_TILE": "1024"}, {"RTHIP_SORT_MERGE_TILE": "4096"}, {"RTHIP_SORT_TOP_BYTES": "8"},
-                    {"RTHIP_UPPER_RANGES": "0"}):
+                    {"RTHIP_UPPER_RANGES": "0"}, {"RTHIP_UPPER_RANGES": "1"}):
             for k in names:
                 os.environ.pop(k, None)
             os.environ.update(env)
