@@ -240,8 +240,9 @@ __device__ __forceinline__ uint64_t morton_of_box(const float* __restrict__ aabb
 __global__ __launch_bounds__(kBlock) void morton_kernel(const float* __restrict__ aabb6, uint64_t n,
                                                         const uint32_t* __restrict__ bounds,
                                                         uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                                                        uint32_t* __restrict__ zero) {
+                                                        uint32_t* __restrict__ zero, uint32_t* __restrict__ zero_word = nullptr) {
     __shared__ uint32_t sb[6];
+    if (zero_word && blockIdx.x == 0 && threadIdx.x == 0) *zero_word = 0u;  // the sort's flag, cleared on the way as well
     bounds_fold(bounds, sb);  // once per workgroup of a bounded grid
     float mn[3], ext[3];
 #pragma unroll
@@ -259,17 +260,43 @@ __global__ __launch_bounds__(kBlock) void morton_kernel(const float* __restrict_
 // ---- K3: LSD radix sort, 8 bits per pass, stable ---------------------------------------
 // Replaces radsort(...) at lbvh.c:120.  Equal codes keep ascending primitive index.
 
-template <int BLOCK>  // threads per workgroup; a tile is BLOCK * kSortItems keys
-__global__ __launch_bounds__(BLOCK) void radix_hist_kernel(const uint64_t* __restrict__ keys, uint64_t n, int shift,
-                                                           uint32_t* __restrict__ block_hist, uint32_t tiles) {
+// MORTON (a build's first pass): the keys are made here, as morton_kernel would have made them -- the Morton codes of
+// the boxes go to `keys`, the climb's counters and the sort's flag are cleared -- and counted on the way.
+template <int BLOCK, bool MORTON = false>  // threads per workgroup; a tile is BLOCK * kSortItems keys
+__global__ __launch_bounds__(BLOCK) void radix_hist_kernel(uint64_t* __restrict__ keys, uint64_t n, int shift,
+                                                           uint32_t* __restrict__ block_hist, uint32_t tiles, MortonSource src = MortonSource{}) {
     __shared__ uint32_t hist[256];
+    float mn[3] = {0.f, 0.f, 0.f}, ext[3] = {0.f, 0.f, 0.f};
     if (threadIdx.x < 256) hist[threadIdx.x] = 0;
+    if constexpr (MORTON) {
+        __shared__ uint32_t sb[6];
+        bounds_fold(src.bounds, sb);
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            mn[k] = ord2f(sb[k]);
+            ext[k] = ord2f(sb[k + 3]) - mn[k];  // extents = max - min, lbvh.c:106
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            if (src.zero_word) *src.zero_word = 0u;
+            if (src.zero_word2) *src.zero_word2 = 0u;
+        }
+    }
     __syncthreads();
     uint64_t base = (uint64_t)blockIdx.x * (BLOCK * kSortItems);
 #pragma unroll
     for (int j = 0; j < kSortItems; j++) {
         uint64_t i = base + (uint64_t)j * BLOCK + threadIdx.x;
-        if (i < n) atomicAdd(&hist[(uint32_t)(keys[i] >> shift) & 255u], 1u);
+        if (i < n) {
+            uint64_t key;
+            if constexpr (MORTON) {
+                key = morton_of_box(src.aabb6, i, mn, ext);
+                keys[i] = key;
+                if (src.zero_all) src.zero_all[i] = 0u;
+            } else {
+                key = keys[i];
+            }
+            atomicAdd(&hist[(uint32_t)(key >> shift) & 255u], 1u);
+        }
     }
     __syncthreads();
     if (threadIdx.x < 256) block_hist[(uint64_t)threadIdx.x * tiles + blockIdx.x] = hist[threadIdx.x];
@@ -1068,7 +1095,7 @@ __device__ __forceinline__ VisF vis_block_suffix(const VisF& mine, VisF* total) 
 
 constexpr int kVisItems = 8;
 constexpr int kVisTile = kBlock * kVisItems;  // 2048 gaps per workgroup
-constexpr uint32_t kVisFusedTiles = kBlock;   // up to this many tiles, pass 3 finds the mask behind its tile by itself
+constexpr uint32_t kVisFusedTiles = 2 * kBlock;  // up to this many tiles (10^6 gaps), pass 3 finds the mask behind its tile by itself
 
 // Pass 1: priorities of a tile's gaps (written for the box climb) and the tile's stretch; a tile is kBlock * ITEMS gaps.
 template <int ITEMS>
@@ -1155,9 +1182,9 @@ __global__ __launch_bounds__(kBlock) void vis_leaf_kernel(const uint8_t* __restr
         const ulonglong2 in = tile_in[blockIdx.x];
         behind = VisF{0u, in.x, in.y};
     } else {
-        const uint32_t t = blockIdx.x + 1u + threadIdx.x;
+        const uint32_t t = blockIdx.x + 1u + 2u * threadIdx.x;  // two neighbouring tiles per thread
         VisF total;
-        (void)vis_block_suffix<kBlock>(t < tiles ? tile_f[t] : vis_identity(), &total);
+        (void)vis_block_suffix<kBlock>(vis_join(t < tiles ? tile_f[t] : vis_identity(), t + 1u < tiles ? tile_f[t + 1u] : vis_identity()), &total);
         behind = VisF{0u, total.lo, total.hi};
     }
     VisF mine = vis_identity();
@@ -2406,7 +2433,7 @@ int radix_sort_workspace_device(rthip_ctx* ctx, uint64_t n, int n_bytes, hipStre
         *cur_io = cur;
         return RTHIP_OK;
     }
-    if (codes_of) return rthip_fail(ctx, RTHIP_E_INVALID, "sort: codes of boxes asked for where the sort cannot make them");
+    if (codes_of && !(n_bytes == 8 && identity_vals)) return rthip_fail(ctx, RTHIP_E_INVALID, "sort: codes of boxes asked for where the sort cannot make them");
     // A one-sweep form (digit totals of all passes from one pass over the keys, tile offsets by decoupled look-back over
     // per-tile status words instead of the histogram and offsets kernels) was built and measured at 10^7 keys: 94 us
     // per pass against 61 + 18 + 6 here -- with ~600 tiles in flight a tile's predecessors have published their own
@@ -2415,7 +2442,10 @@ int radix_sort_workspace_device(rthip_ctx* ctx, uint64_t n, int n_bytes, hipStre
         const int shift = pass * 8;
         uint32_t* hist = (uint32_t*)w.block_hist.p;
         const uint32_t* v_in = (pass == first_byte && identity_vals) ? nullptr : vals[cur];
-        if (small_tile) radix_hist_kernel<kSmallSortBlock><<<tiles, kSmallSortBlock, 0, s>>>(keys[cur], n, shift, hist, tiles);
+        if (pass == first_byte && codes_of) {  // the keys are made on the way
+            if (small_tile) radix_hist_kernel<kSmallSortBlock, true><<<tiles, kSmallSortBlock, 0, s>>>(keys[cur], n, shift, hist, tiles, *codes_of);
+            else radix_hist_kernel<kSortBlock, true><<<tiles, kSortBlock, 0, s>>>(keys[cur], n, shift, hist, tiles, *codes_of);
+        } else if (small_tile) radix_hist_kernel<kSmallSortBlock><<<tiles, kSmallSortBlock, 0, s>>>(keys[cur], n, shift, hist, tiles);
         else radix_hist_kernel<kSortBlock><<<tiles, kSortBlock, 0, s>>>(keys[cur], n, shift, hist, tiles);
         RT_HIP(ctx, hipGetLastError());
         radix_offsets_kernel<<<256, kBlock, 0, s>>>(hist, tiles);
@@ -2569,10 +2599,26 @@ int lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, float4* 
     // values: see identity_vals; the arrival counters of the n - 1 gaps + the starter count are cleared on the way
     // The range form has no arrival counters, only its list's length to clear: when nobody asks for the unsorted codes
     // and the sort is one in tiles, the tile sort makes the codes itself and clears that word (one launch fewer).
-    const bool sort_codes = A.ranges && !d_codes_unsorted && sort_makes_codes(ctx, n);
-    const MortonSource codes_of = {d_aabb6, bounds, A.start_count};
+    // Larger builds: the first histogram pass of the sort makes the codes and clears the counters and the sort's flag.
+    const bool tiles_sort = n <= ctx->sort_merge_max && !ctx->sort_by_passes;  // radix_sort_workspace_device's choice
+    const bool sort_codes = !d_codes_unsorted && (!tiles_sort || (A.ranges != 0u && sort_makes_codes(ctx, n)));
+    MortonSource codes_of;
+    codes_of.aabb6 = d_aabb6;
+    codes_of.bounds = bounds;
+    codes_of.zero_word = A.start_count;
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    if (s) (void)hipStreamIsCapturing(s, &capturing);
+    const bool top_first = n > ctx->sort_merge_max && n > kTopSortMin && ctx->sort_top_bytes < 8 && ctx->sort_top_gave_up_n != n &&
+                           capturing == hipStreamCaptureStatusNone;
+    uint32_t* gave_up = (uint32_t*)w.bounds.p + kBoundSlots * kBoundStride;  // a word behind the bounds' copies
+    if (!tiles_sort) {
+        codes_of.zero_all = (uint32_t*)w.flags.p;  // n words, the list's length among them
+        codes_of.zero_word = nullptr;
+        codes_of.zero_word2 = top_first ? gave_up : nullptr;
+    }
     if (!sort_codes) {
-        morton_kernel<<<div_up(n, kBlock) < 4096u ? div_up(n, kBlock) : 4096u, kBlock, 0, s>>>(d_aabb6, n, bounds, keys[0], nullptr, (uint32_t*)w.flags.p);
+        morton_kernel<<<div_up(n, kBlock) < 4096u ? div_up(n, kBlock) : 4096u, kBlock, 0, s>>>(d_aabb6, n, bounds, keys[0], nullptr, (uint32_t*)w.flags.p,
+                                                                                               top_first ? gave_up : nullptr);
         RT_HIP(ctx, hipGetLastError());
     }
     if (d_codes_unsorted)
@@ -2585,12 +2631,8 @@ int lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, float4* 
     // attempt from then on.
     int cur = 0;
     bool sorted = false;
-    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
-    if (s) (void)hipStreamIsCapturing(s, &capturing);
-    if (n > ctx->sort_merge_max && n > kTopSortMin && ctx->sort_top_bytes < 8 && ctx->sort_top_gave_up_n != n && capturing == hipStreamCaptureStatusNone) {
-        uint32_t* gave_up = (uint32_t*)w.bounds.p + kBoundSlots * kBoundStride;  // a word behind the bounds' copies
-        RT_HIP(ctx, hipMemsetAsync(gave_up, 0, 4, s));
-        RT_TRY(radix_sort_workspace_device(ctx, n, 8, s, &cur, &w, true, 8 - ctx->sort_top_bytes));
+    if (top_first) {  // (the flag was cleared by morton_kernel)
+        RT_TRY(radix_sort_workspace_device(ctx, n, 8, s, &cur, &w, true, 8 - ctx->sort_top_bytes, sort_codes ? &codes_of : nullptr));
         sort_fix_kernel<<<div_up(n, kFixTile), 256, 0, s>>>(keys[cur], vals[cur], (uint32_t)n, gave_up);
         RT_HIP(ctx, hipGetLastError());
         uint32_t h_gave_up = 0;
@@ -2600,8 +2642,11 @@ int lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, float4* 
         if (!sorted) {
             ctx->sort_top_gave_up_n = n;
             if (getenv("RTHIP_TUNE_LOG")) fprintf(stderr, "rthip sort: a long stretch of keys with equal upper bytes was out of order: all eight passes\n");
-            morton_kernel<<<div_up(n, kBlock) < 4096u ? div_up(n, kBlock) : 4096u, kBlock, 0, s>>>(d_aabb6, n, bounds, keys[0], nullptr, (uint32_t*)w.flags.p);
-            RT_HIP(ctx, hipGetLastError());
+            if (!sort_codes) {
+                morton_kernel<<<div_up(n, kBlock) < 4096u ? div_up(n, kBlock) : 4096u, kBlock, 0, s>>>(d_aabb6, n, bounds, keys[0], nullptr, (uint32_t*)w.flags.p);
+                RT_HIP(ctx, hipGetLastError());
+            }
+            codes_of.zero_word2 = nullptr;
             cur = 0;
         }
     }

@@ -287,11 +287,13 @@ int lbvh_static_workspace_init(rthip_ctx* ctx);
 // identity_vals: the values are the positions 0 .. n-1 and need not be stored before the call (vals[*cur] is not read).
 // first_byte > 0: only the passes over bytes first_byte .. n_bytes-1 (a stable sort by those bytes alone).
 // codes_of: the keys are not in keys[*cur] yet; they are the Morton codes of these boxes and the sort makes them itself
-// (eight-byte keys, identity values, a sort in tiles only: see lbvh_build_device).
+// (eight-byte keys and identity values only: see lbvh_build_device), in its tile sort or in its first histogram pass.
 struct MortonSource {
-    const float* aabb6;       // the boxes
-    const uint32_t* bounds;   // the centroid bounds' slots
-    uint32_t* zero_word;      // a word to clear on the way
+    const float* aabb6 = nullptr;      // the boxes
+    const uint32_t* bounds = nullptr;  // the centroid bounds' slots
+    uint32_t* zero_word = nullptr;     // a word to clear on the way
+    uint32_t* zero_word2 = nullptr;    // another (sorts pass by pass only)
+    uint32_t* zero_all = nullptr;      // one word per key to clear (sorts pass by pass only)
 };
 int radix_sort_workspace_device(rthip_ctx* ctx, uint64_t n, int n_bytes, hipStream_t stream, int* cur, LbvhWorkspace* ws = nullptr,
                                 bool identity_vals = false, int first_byte = 0, const MortonSource* codes_of = nullptr);
