@@ -758,13 +758,15 @@ def random_world_case(seed: int):
     return w, sky, bounces, o, d, cam(24, 16, 1 + seed % 3)
 
 
-def random_boxes(seed: int):
-    """A seeded box set for fuzzing the LBVH build: a random size (1 ... 20 000) and one of several awkward
+def random_boxes(seed: int, max_n: int = 20_000):
+    """A seeded box set for fuzzing the LBVH build: a random size (1 ... max_n) and one of several awkward
     distributions -- uniform, tight clusters, points on a coarse lattice (many equal Morton codes), a plane or a line
     (zero extent on one or two axes), wildly different magnitudes, tiny (denormal) coordinates, all boxes equal,
     negative zeros.  Returns float32[n, 6] (min xyz, max xyz)."""
     rng = np.random.default_rng(seed)
     n = int(rng.choice([1, 2, 3, int(rng.integers(4, 64)), int(rng.integers(64, 2000)), int(rng.integers(2000, 20001))]))
+    if max_n > 20_000 and seed % 6 != 0:  # the large sets: mostly large
+        n = int(rng.integers(16_385, max_n + 1))
     kind = int(rng.integers(0, 9))
     cen = rng.uniform(-1, 1, (n, 3))
     half = rng.uniform(0, 0.05, (n, 3))

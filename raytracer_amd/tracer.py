@@ -117,11 +117,13 @@ def rt_tracer_cleanup(tracer: RT_Tracer) -> None:
 # ---- parity / measurement taps ---------------------------------------------
 
 
-def lbvh_build(tracer: RT_Tracer, aabbs: np.ndarray):
-    """lbvh_make (src/lbvh/lbvh.c:92-125) on the GPU.  Returns (codes, codes_sorted, ids_sorted, nodes, ms)."""
+def lbvh_build(tracer: RT_Tracer, aabbs: np.ndarray, want_codes: bool = True):
+    """lbvh_make (src/lbvh/lbvh.c:92-125) on the GPU.  Returns (codes, codes_sorted, ids_sorted, nodes, ms).
+    want_codes=False does not ask for the unsorted codes (None is returned for them): the build then runs as it does
+    for a scene, where the sort's first kernel makes the codes instead of a kernel of their own."""
     aabbs = np.ascontiguousarray(aabbs, dtype=np.float32).reshape(-1, 6)
     n = aabbs.shape[0]
-    codes = np.zeros(n, dtype=np.uint64)
+    codes = np.zeros(n, dtype=np.uint64) if want_codes else None
     codes_sorted = np.zeros(n, dtype=np.uint64)
     ids_sorted = np.zeros(n, dtype=np.uint32)
     nodes = np.zeros(max(2 * n - 1, 0), dtype=abi.NODE)

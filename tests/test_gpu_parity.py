@@ -23,6 +23,10 @@ def check_lbvh(oracle, gpu_tracer, boxes, what):
     assert (cs == ocs).all(), f"{what}: sorted codes"
     assert (ids == oids).all(), f"{what}: sorted ids"
     assert_same_tree(nodes, onodes, what)
+    # once more as a scene's build runs: nobody asks for the unsorted codes, so the sort's first kernel makes them
+    _, cs2, ids2, nodes2, _ = T.lbvh_build(gpu_tracer, boxes, want_codes=False)
+    assert (cs2 == ocs).all() and (ids2 == oids).all(), f"{what}: sorted codes / ids of the build without the codes' output"
+    assert_same_tree(nodes2, onodes, what + " (build without the codes' output)")
     return codes, nodes
 
 
@@ -96,7 +100,9 @@ def test_lbvh_one_million_digest(oracle, gpu_tracer):
         cen = rng.random((n, 3)).astype(np.float32)
         half = (rng.random((n, 3)) * 0.001).astype(np.float32)
         boxes = np.concatenate([cen - half, cen + half], axis=1).astype(np.float32)
+        nodes2 = T.lbvh_build(gpu_tracer, boxes, want_codes=False)[3]
         codes, cs, ids, nodes, ms = T.lbvh_build(gpu_tracer, boxes)
+        assert nodes2.tobytes() == nodes.tobytes(), "the build whose sort makes the codes gives another tree"
         assert hashlib.sha256(codes.tobytes()).hexdigest() == str(g[f"n{n}_codes"])
         assert hashlib.sha256(ids.tobytes()).hexdigest() == str(g[f"n{n}_ids"])
         assert hashlib.sha256(oracle.dump_bytes(nodes)).hexdigest() == str(g[f"n{n}_dump"]), "tree differs from the reference's"
@@ -129,8 +135,8 @@ def test_hierarchy_hand_off_modes_build_the_same_tree(oracle):
             os.environ["RTHIP_REFIT_FENCE"] = mode
             t = T.rt_make_tracer(T.RT_TracerSettings(max_bounces=1, sky=True), device_id=0)
             try:
-                for _ in range(2):
-                    assert_same_tree(T.lbvh_build(t, boxes)[3], want, f"hand-off mode {mode}")
+                for want_codes in (True, False):
+                    assert_same_tree(T.lbvh_build(t, boxes, want_codes=want_codes)[3], want, f"hand-off mode {mode}")
             finally:
                 T.rt_tracer_cleanup(t)
     finally:
@@ -165,6 +171,7 @@ def test_lbvh_sizes_at_the_seams_of_the_builder(oracle, n):
             t = T.rt_make_tracer(T.RT_TracerSettings(max_bounces=1, sky=True), device_id=0)
             try:
                 assert_same_tree(T.lbvh_build(t, boxes)[3], want, f"n = {n}, {env}")
+                assert_same_tree(T.lbvh_build(t, boxes, want_codes=False)[3], want, f"n = {n}, {env}, codes made by the sort")
             finally:
                 T.rt_tracer_cleanup(t)
     finally:
@@ -217,7 +224,7 @@ def test_lbvh_sort_by_upper_bytes(oracle, capfd, case):
     t = T.rt_make_tracer(T.RT_TracerSettings(max_bounces=1, sky=True), device_id=0)
     try:
         capfd.readouterr()
-        assert_same_tree(T.lbvh_build(t, boxes)[3], want, case)
+        assert_same_tree(T.lbvh_build(t, boxes, want_codes=False)[3], want, case)
         said = "all eight passes" in capfd.readouterr().err
         assert said == falls_back, f"{case}: fell back {said}, expected {falls_back}"
         assert_same_tree(T.lbvh_build(t, boxes)[3], want, case + ", second build")  # after a fallback: no second attempt
@@ -273,6 +280,7 @@ def test_lbvh_tile_sort_by_upper_bytes(oracle, case):
             t = T.rt_make_tracer(T.RT_TracerSettings(max_bounces=1, sky=True), device_id=0)
             try:
                 assert_same_tree(T.lbvh_build(t, boxes)[3], want, f"{case}, {env}")
+                assert_same_tree(T.lbvh_build(t, boxes, want_codes=False)[3], want, f"{case}, {env}, codes made by the sort")
             finally:
                 T.rt_tracer_cleanup(t)
     finally:

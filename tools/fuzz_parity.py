@@ -1,9 +1,10 @@
 """dev probe: long fuzz runs of the GPU path against the CPU oracle, bit for bit.
   worlds: seeded random worlds (scenes.random_world) -- trees, closest hits and occlusion of aimed rays, whole frames
           from every cast kernel (the oracle draws the same counter-based random numbers)
-  boxes:  random box sets (scenes.random_boxes) -- Morton codes, sorted order, every tree node
+  boxes:  random box sets (scenes.random_boxes) -- Morton codes, sorted order, every tree node, in both forms of the build
+  bigboxes: the same with up to 150 000 boxes (the sizes of the sort in tiles and of the range form of the climb, and above)
   obj:    random OBJ texts (scenes.random_obj_text) -- vertices and indices
-Usage: fuzz_parity.py [worlds|boxes|obj] [first_seed [count]]"""
+Usage: fuzz_parity.py [worlds|boxes|bigboxes|obj] [first_seed [count]]"""
 import sys, os, tempfile
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root)
@@ -24,12 +25,15 @@ tmp = tempfile.mkdtemp()
 def one(seed):
     if kind == "worlds":
         check_random_world(oracle, tr, seed)
-    elif kind == "boxes":
-        boxes = scenes.random_boxes(seed)
+    elif kind in ("boxes", "bigboxes"):
+        boxes = scenes.random_boxes(seed, 150_000 if kind == "bigboxes" else 20_000)
         codes, cs, ids, nodes, _ = T.lbvh_build(tr, boxes)
         ocodes, ocs, oids, onodes = oracle.lbvh_build(boxes)
         assert (codes == ocodes).all() and (cs == ocs).all() and (ids == oids).all(), f"codes / order of {boxes.shape[0]} boxes"
         assert_same_tree(nodes, onodes, f"{boxes.shape[0]} boxes")
+        _, cs, ids, nodes, _ = T.lbvh_build(tr, boxes, want_codes=False)  # as a scene builds: the sort makes the codes
+        assert (cs == ocs).all() and (ids == oids).all(), f"order of {boxes.shape[0]} boxes, codes made by the sort"
+        assert_same_tree(nodes, onodes, f"{boxes.shape[0]} boxes, codes made by the sort")
     else:
         text, attrs = scenes.random_obj_text(seed)
         path = os.path.join(tmp, "fuzz.obj")
