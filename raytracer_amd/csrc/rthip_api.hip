@@ -250,6 +250,7 @@ void rthip_destroy(rthip_ctx* ctx) {
     delete ctx->movers;
     ctx->movers = nullptr;
     if (ctx->host_stage) (void)hipHostFree(ctx->host_stage);
+    if (ctx->inst_stage) (void)hipHostFree(ctx->inst_stage);
     for (hipStream_t b : ctx->band_stream)
         if (b) (void)hipStreamDestroy(b);
     for (hipStream_t b : ctx->band_copy_stream)
@@ -510,7 +511,23 @@ int rthip_tlas_build(rthip_ctx* ctx, const rthip_instance* instances, uint32_t n
     if (n_instances && !instances) return rthip_fail(ctx, RTHIP_E_INVALID, "instances is NULL");
     if (n_materials && !materials) return rthip_fail(ctx, RTHIP_E_INVALID, "materials is NULL");
     if (n_instances > (1u << 30)) return rthip_fail(ctx, RTHIP_E_LIMIT, "more than 2^30 instances");
-    std::vector<DevInstance> dev(n_instances);
+    // The device's records are written straight into page-locked memory of the context (grown on demand), from where the
+    // copy is one DMA; out of a pageable vector the runtime stages it itself, which took longer than the TLAS build.
+    std::vector<DevInstance> pageable;
+    const size_t stage_bytes = (size_t)n_instances * sizeof(DevInstance);
+    if (ctx->inst_stage_bytes < stage_bytes) {
+        if (ctx->inst_stage) (void)hipHostFree(ctx->inst_stage);
+        ctx->inst_stage = nullptr;
+        ctx->inst_stage_bytes = 0;
+        const size_t want = stage_bytes + stage_bytes / 4 + 4096;
+        if (hipHostMalloc(&ctx->inst_stage, want, hipHostMallocDefault) == hipSuccess && ctx->inst_stage) ctx->inst_stage_bytes = want;
+        else {
+            (void)hipGetLastError();
+            ctx->inst_stage = nullptr;
+        }
+    }
+    if (!ctx->inst_stage) pageable.resize(n_instances);
+    DevInstance* dev = ctx->inst_stage ? (DevInstance*)ctx->inst_stage : pageable.data();
     for (uint32_t k = 0; k < n_instances; k++) {
         const rthip_instance& s = instances[k];
         DevInstance& d = dev[k];
@@ -544,10 +561,10 @@ int rthip_tlas_build(rthip_ctx* ctx, const rthip_instance* instances, uint32_t n
 
     {   // mesh instances of a few triangles each (at most 32 nodes on average): rays enter an instance every few steps
         uint64_t mesh_instances = 0, nodes = 0;
-        for (const DevInstance& d : dev)
-            if (d.type == RTHIP_INST_MESH) {
+        for (uint32_t k = 0; k < n_instances; k++)
+            if (dev[k].type == RTHIP_INST_MESH) {
                 mesh_instances++;
-                nodes += d.n_nodes;
+                nodes += dev[k].n_nodes;
             }
         ctx->small_meshes = mesh_instances != 0 && nodes <= 32 * mesh_instances;
     }
@@ -564,7 +581,7 @@ int rthip_tlas_build(rthip_ctx* ctx, const rthip_instance* instances, uint32_t n
     if (n_materials)
         RT_HIP(ctx, hipMemcpyAsync(ctx->mats.p, materials, (size_t)n_materials * sizeof(rthip_material), hipMemcpyHostToDevice, ctx->stream));
     if (n_instances) {
-        RT_HIP(ctx, hipMemcpyAsync(ctx->inst.p, dev.data(), (size_t)n_instances * sizeof(DevInstance), hipMemcpyHostToDevice, ctx->stream));
+        RT_HIP(ctx, hipMemcpyAsync(ctx->inst.p, dev, (size_t)n_instances * sizeof(DevInstance), hipMemcpyHostToDevice, ctx->stream));
         RT_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
         RT_TRY(instance_aabbs_device(ctx, (const DevInstance*)ctx->inst.p, n_instances, (const float4*)ctx->blas_nodes.p,
                                      (float*)ctx->inst_aabb.p, ctx->stream));

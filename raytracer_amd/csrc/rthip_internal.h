@@ -168,6 +168,8 @@ struct rthip_ctx {
     static constexpr int kBandChunks = 4;    // a band's copy into staging goes in this many pieces, each with an event
     hipEvent_t chunk_done[kMaxBands * kBandChunks] = {};
     int cast_bands = 4;  // RTHIP_CAST_BANDS; 1 = one launch, one copy
+    void* inst_stage = nullptr;  // page-locked memory in which rthip_tlas_build writes the device's instance records (grown on demand)
+    size_t inst_stage_bytes = 0;
     void* host_stage = nullptr;  // page-locked staging for rthip_cast into pageable memory (grown on demand)
     HostPool* movers = nullptr;  // the threads that move staged bands into the caller's buffer (started at first use)
     size_t host_stage_bytes = 0;
