@@ -1697,14 +1697,18 @@ __device__ __forceinline__ void chunk_ranges(ClimbLds& L, uint32_t c0, const Cli
 struct LocalRangeLds {
     float suf8[kChunk][6];       // leaf i .. the last leaf of its block
     float sp[5][kChunk / 8][6];  // sp[k - 1][b]: blocks b .. b + 2^k - 1
+    float bpre[kChunk / 8][6];   // blocks 0 .. b
+    float bsuf[kChunk / 8][6];   // blocks b .. 63
     uint8_t lefts[kChunk];
+    uint32_t cmin1;              // the smallest priority among the window's entries 1 .. kChunk
 };
 static_assert(sizeof(ChildRec) * 2 * kChunk >= 2 * kChunk * 6 * sizeof(float) + 2 * (kChunk / 64) * 128 * sizeof(uint32_t), "lrec holds the tables");
 
 template <bool PAIRED>
 __device__ __forceinline__ void chunk_local_ranges(ClimbLds& L, LocalRangeLds& R, uint32_t c0, const ClimbArgs& A, const LeafIn& in,
-                                                   const float* box) {
+                                                   const float* box, uint32_t min_before, uint32_t min_after) {
     const uint32_t n = A.n, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t chunk = c0 / (uint32_t)kChunk;
     float(*lb)[6] = reinterpret_cast<float(*)[6]>(L.lrec);
     float(*pre8)[6] = lb + kChunk;  // the block's first leaf .. leaf i
     uint32_t(*near_r)[128] = reinterpret_cast<uint32_t(*)[128]>(pre8 + kChunk);  // [wave][q]: lane + 1 of the rightmost entry below q (0: none)
@@ -1753,7 +1757,7 @@ __device__ __forceinline__ void chunk_local_ranges(ClimbLds& L, LocalRangeLds& R
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
     if (e < 127u) {
         atomicMax(&near_r[wave][e + 1u], lane + 1u);
-        atomicMin(&near_l[wave][e + 1u], lane);
+        if (tid != 0u) atomicMin(&near_l[wave][e + 1u], lane);  // entry 0 is nobody's bound on the right (and not in the chunk's table)
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();
@@ -1798,9 +1802,66 @@ __device__ __forceinline__ void chunk_local_ranges(ClimbLds& L, LocalRangeLds& R
             todo &= ~same;
         }
     }
+    {   // the gaps whose nodes reach beyond the chunk go on the list for range_upper_kernel (see chunk_ranges)
+        const uint64_t gap = (uint64_t)c0 - 1u + tid;
+        const bool upper = tid >= 1u && gap + 1u < n && !local;
+        wave_push(upper, tid | (min_before < e ? 0x4000u : 0u) | (min_after < e ? 0x8000u : 0u), &L.n_start, L.stage);
+        if (tid == 0u) R.cmin1 = min_after;
+    }
     CLIMB_STAMP(6);
     lds_barrier();
-    const uint32_t list_base = chunk_ranges_claim(L, c0, A);  // chunk_ranges' list is complete behind this barrier
+    const uint32_t list_base = chunk_ranges_claim(L, c0, A);  // the list is complete behind this barrier
+    // What range_upper_kernel needs from the chunk, from the same tables: waves 1 and 2 scan the blocks' boxes from the
+    // left and from the right (a leaf's box up to / from the chunk's end is its block's part and one of these), wave 3
+    // joins the waves' nearest-entry tables into the chunk's two and notes the chunk's smallest priorities.
+    if (wave == 1u || wave == 2u) {
+        float cur[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) cur[k] = pre8[8u * lane + 7u][k];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            float other[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) other[k] = wave == 1u ? __shfl_up(cur[k], o) : __shfl_down(cur[k], o);
+            if (wave == 1u) {
+                if (lane >= (uint32_t)o) {
+                    merge_after(other, cur);
+#pragma unroll
+                    for (int k = 0; k < 6; k++) cur[k] = other[k];
+                }
+            } else if (lane + (uint32_t)o < 64u) {
+                merge_after(cur, other);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 6; k++) (wave == 1u ? R.bpre : R.bsuf)[lane][k] = cur[k];
+    }
+    if (wave == 3u) {
+        const uint32_t e_end = (uint32_t)L.win[kChunk] & 0x7fu;
+#pragma unroll
+        for (uint32_t half = 0; half < 2u; half++) {
+            const uint32_t q = lane + 64u * half;
+            uint32_t right = 0xffffu, left = 0xffffu;
+            for (int w = kChunk / 64 - 1; w >= 0; w--) {
+                const uint32_t v = near_r[w][q];
+                if (v != 0u && right == 0xffffu) right = (uint32_t)w * 64u + v - 1u;
+            }
+            for (uint32_t w = 0; w < (uint32_t)kChunk / 64u; w++) {
+                const uint32_t v = near_l[w][q];
+                if (v != 0xffu && left == 0xffffu) left = w * 64u + v;
+            }
+            if (left == 0xffffu && e_end < q) left = (uint32_t)kChunk;
+            A.tab[256u * chunk + q] = (uint16_t)right;         // among the entries 0 .. kChunk - 1
+            A.tab[256u * chunk + 128u + q] = (uint16_t)left;   // among the entries 1 .. kChunk
+        }
+        if (lane == 0u) {
+            uint32_t m = 0xffu;
+            for (uint32_t w = 0; w < (uint32_t)kChunk / 64u; w++) m = L.wmin_l[w] < m ? L.wmin_l[w] : m;
+            L.range_cmin0 = m;
+            A.cmin[2u * chunk] = (uint8_t)m;
+            A.cmin[2u * chunk + 1u] = (uint8_t)R.cmin1;
+        }
+    }
     if (wave == 0u) {  // the sparse table over the blocks' boxes: lane b holds blocks b .. b + 2^k - 1
         float cur[6];
 #pragma unroll
@@ -1840,6 +1901,29 @@ __device__ __forceinline__ void chunk_local_ranges(ClimbLds& L, LocalRangeLds& R
     }
     lds_barrier();
     CLIMB_STAMP(7);
+    if (i < n) {  // for range_upper_kernel: the box of the leaves from the chunk's first up to this one, and from this one to the last
+        const uint32_t b = tid >> 3;
+        float pre[6], suf[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            pre[k] = pre8[tid][k];
+            suf[k] = R.suf8[tid][k];
+        }
+        if (b > 0u) {
+            float acc[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) acc[k] = R.bpre[b - 1u][k];
+            merge_after(acc, pre);
+#pragma unroll
+            for (int k = 0; k < 6; k++) pre[k] = acc[k];
+        }
+        if (b + 1u < (uint32_t)kChunk / 8u) merge_after(suf, R.bsuf[b + 1u]);
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            A.pre_box[6 * (uint64_t)i + k] = pre[k];
+            A.suf_box[6 * (uint64_t)i + k] = suf[k];
+        }
+    }
     if (local) {
         const uint32_t l = jl, r = jr - 1u;  // the leaf behind gap jl .. the leaf in front of gap jr, relative to c0
         const uint32_t bl = l >> 3, br = r >> 3;
@@ -1923,10 +2007,9 @@ __global__ __launch_bounds__(kChunk) void climb_local_kernel(ClimbArgs A) {
 #endif
     if constexpr (RANGES) {  // their LDS exists in this instance only
         __shared__ LocalRangeLds R;
-        chunk_ranges(L, c0, A, box, min_before, min_after, A.ranges != 2u);
         CLIMB_STAMP(3);
-        if (A.ranges == 2u) {
-            chunk_local_ranges<PAIRED>(L, R, c0, A, in, box);  // flushes the list of the gaps above the chunk as well
+        if (A.ranges == 2u) {  // everything from leaf ranges: the chunk's own nodes, and what range_upper_kernel needs from it
+            chunk_local_ranges<PAIRED>(L, R, c0, A, in, box, min_before, min_after);
             CLIMB_STAMP(4);
 #ifdef RT_CLIMB_STAMP
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1934,6 +2017,7 @@ __global__ __launch_bounds__(kChunk) void climb_local_kernel(ClimbArgs A) {
 #endif
             return;
         }
+        chunk_ranges(L, c0, A, box, min_before, min_after, true);
     }
     chunk_climb<PAIRED>(L, c0, A, in, box);
     CLIMB_STAMP(4);

@@ -30,11 +30,11 @@ st = st.reshape(-1, 8)[:groups].astype(np.int64)
 t = (st[:, :6] - st[:, :1]) / 100.0  # us (100 MHz clock)
 names = ["start", "window done (ids, priorities read)", "boxes arrived", "climb done (all waves)", "list flushed", "stores drained"]
 if n <= (1 << 17) and os.environ.get("RTHIP_UPPER_RANGES", "2") == "2":  # the range form: other phases behind the same stamps
-    names = ["start", "shape scan and window done", "boxes arrived", "chunk tables and list written", "nodes inside the chunk", "stores drained"]
+    names = ["start", "shape scan and window done", "boxes arrived", "(nothing)", "all nodes of the chunk, its tables and its list", "stores drained"]
     for k in range(1, 6):
         d = t[:, k] - t[:, k - 1]
         print(f"{names[k]:40s} +{d.mean():6.2f} us (median {np.median(d):6.2f}, p95 {np.percentile(d, 95):6.2f})")
-    print(f"inside the chunk: tables and nearest entries in the wave +{((st[:, 6] - st[:, 3]) / 100.0).mean():.2f} us, block table and entries beyond the wave +{((st[:, 7] - st[:, 6]) / 100.0).mean():.2f}, boxes, records and the list +{((st[:, 4] - st[:, 7]) / 100.0).mean():.2f}")
+    print(f"of that: block scans, tables and nearest entries in the wave +{((st[:, 6] - st[:, 3]) / 100.0).mean():.2f} us, block tables, chunk tables and entries beyond the wave +{((st[:, 7] - st[:, 6]) / 100.0).mean():.2f}, leaves' boxes to the chunk's ends, nodes' boxes, records and the list +{((st[:, 4] - st[:, 7]) / 100.0).mean():.2f}")
     print(f"workgroup lifetime {t[:, 5].mean():.2f} us; kernel span {(st[:, 5].max() - st[:, 0].min()) / 100.0:.1f} us for {groups} workgroups")
     sys.exit(0)
 for k in range(1, 6):
