@@ -475,9 +475,9 @@ __global__ __launch_bounds__(BLOCK) void radix_scatter_kernel(const uint64_t* __
 
 // ---- sorts of at most 128 tiles: every tile sorted completely in LDS, then merged by rank ----------------
 // Up to 2^17 keys the pass-by-pass sort is a chain of 24 small launches (its keys fit the L2 many times over), so
-// these sizes take two.  tile_sort_kernel sorts each tile of 1024 keys through all n_bytes digits without leaving LDS
-// (the same wave-ballot ranking as the scatter kernel, the tile ping-ponging between registers and LDS; small tiles,
-// so that a sort of 80 000 keys is spread over 80 CUs and a pass is one wave per SIMD).  tile_merge_kernel gives every
+// these sizes take two.  tile_sort_kernel sorts each tile of 1024 or 2048 keys (merge_tile_keys) without leaving LDS
+// (the same wave-ballot ranking as the scatter kernel, the tile ping-ponging between registers and LDS; tiles this
+// small, so that a sort of 80 000 keys is spread over 40 - 80 CUs).  tile_merge_kernel gives every
 // key its final position: its position in its own tile plus, for every other tile, the number of keys there that must
 // come before it (keys <= in earlier tiles, < in later ones, which keeps equal keys in their original order).
 constexpr int kSmallSortBlock = 256;
