@@ -597,19 +597,18 @@ __global__ __launch_bounds__(BLOCK) void tile_sort_kernel(const uint64_t* __rest
                     const uint32_t up = __shfl_up(incl, o);
                     if (lane >= o) incl += up;
                 }
-                if (owner && lane == 63) wave_tot[wave] = incl;
-                __syncthreads();
                 if (owner) {
-                    uint32_t wsum = 0;
-                    for (int w = 0; w < wave; w++) wsum += wave_tot[w];
-                    bin_start[tid] = wsum + incl - run;
+                    if (lane == 63) wave_tot[wave] = incl;
+                    bin_start[tid] = incl - run;  // among the 64 digits of this thread's wave; the waves before it: below
                 }
             }
             __syncthreads();
+            const uint32_t g1 = wave_tot[0], g2 = g1 + wave_tot[1], g3 = g2 + wave_tot[2];
 #pragma unroll
             for (int j = 0; j < ITEMS; j++) {
                 const uint32_t d = (uint32_t)(key[j] >> shift) & 255u;
-                const uint32_t pos = bin_start[d] + wave_cnt[wave][d] + rank[j];
+                const uint32_t group = d < 64u ? 0u : (d < 128u ? g1 : (d < 192u ? g2 : g3));  // keys with digits of earlier groups of 64
+                const uint32_t pos = group + bin_start[d] + wave_cnt[wave][d] + rank[j];
                 skeys[pos] = key[j];
                 svals[pos] = val[j];
             }
