@@ -2110,9 +2110,11 @@ __global__ __launch_bounds__(kOneGroupThreads) void range_upper_kernel(ClimbArgs
     __shared__ float cbox[kRangeLevels - 1][256][6];
     const uint32_t n = A.n, tid = threadIdx.x;
     const uint32_t chunks = (n + (uint32_t)kChunk - 1u) / (uint32_t)kChunk;  // <= 256
-    const uint32_t count = *A.start_count;
     const uint32_t first = blockIdx.x * (uint32_t)kOneGroupThreads + tid;
-    uint32_t word = first < count ? A.starters[first] : 0u;  // asked for before the tables are made
+    // asked for before the tables are made, and together with the count (the list has room for n + 1 words; what lies
+    // behind the count is not used)
+    uint32_t word = A.starters[first < n ? first : n];
+    const uint32_t count = *A.start_count;
     if (tid < chunks) {
         minA[0][tid] = A.cmin[2u * tid];
         minB[0][tid] = A.cmin[2u * tid + 1u];
