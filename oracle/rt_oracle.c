@@ -766,8 +766,12 @@ static inline uint32_t hash32(uint32_t x) {
     return x;
 }
 static inline uint64_t counter_key(uint64_t seed, uint32_t pixel, uint32_t sample) {
-    const uint32_t a = hash32(pixel + hash32(sample ^ (uint32_t)seed));
-    const uint32_t b = hash32(a ^ (uint32_t)(seed >> 32) ^ 0x85ebca6bu);
+    /* the seed is hashed before it meets the sample index, and b is a hash of (seed, pixel, sample) of its own */
+    const uint32_t lo = (uint32_t)seed, hi = (uint32_t)(seed >> 32);
+    const uint32_t s1 = hash32(lo ^ hash32(hi + 0x6a09e667u));
+    const uint32_t s2 = hash32(hi ^ hash32(lo + 0xbb67ae85u));
+    const uint32_t a = hash32(pixel + hash32(sample + s1));
+    const uint32_t b = hash32(sample + hash32(pixel + s2));
     return (uint64_t)a | ((uint64_t)b << 32);
 }
 static inline uint32_t counter_draw(uint64_t key, uint32_t draw) {

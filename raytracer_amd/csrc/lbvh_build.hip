@@ -2429,7 +2429,7 @@ __global__ __launch_bounds__(kBlock) void wide_emit_kernel(const float4* __restr
     out[7] = make_float4(__uint_as_float(node[0]), __uint_as_float(node[1]), __uint_as_float(node[2]), __uint_as_float(node[3]));
 }
 
-inline uint32_t div_up(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+constexpr uint32_t div_up(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
 
 // exclusive / inclusive prefix sum of n uint32 in place; tmp holds the block sums of every level
 template <bool INCLUSIVE>
@@ -2449,7 +2449,7 @@ int scan_u32(rthip_ctx* ctx, uint32_t* d, uint64_t n, uint32_t* tmp, hipStream_t
 }
 
 // the shape scan's records: a mask and a stretch per tile of kVisTile gaps, or a stretch per chunk (range form)
-size_t vis_bytes(uint64_t n) {
+constexpr size_t vis_bytes(uint64_t n) {
     const size_t tiles = (size_t)div_up(n, kVisTile) * (sizeof(ulonglong2) + sizeof(VisF)), chunks = (size_t)div_up(n, kChunk) * sizeof(VisF);
     return tiles > chunks ? tiles : chunks;
 }
@@ -2788,19 +2788,38 @@ int lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, float4* 
 // ---- a workspace that is not allocated ------------------------------------------------------------
 // Callers that cannot allocate (code under HIP graph capture, serving loops, harnesses that forbid hipMalloc) build in
 // this file-scope device array instead.  Every GPU the library runs on holds its own copy at its own address until the
-// process ends (about 17 MB); the array's name is only a host-side stand-in, so its device address is looked up once
+// process ends (about 13 MB); the array's name is only a host-side stand-in, so its device address is looked up once
 // per device with hipGetSymbolAddress and only that pointer is ever handed to kernels and memsets.
 namespace {
 
-constexpr size_t kStaticSlack = 1u << 20;  // block histograms, scan sums, bounds, alignment padding
-constexpr size_t kStaticBytes = kStaticBuildMaxBoxes * 120u + kStaticSlack;  // 96 bytes per box: keys, values, priorities, child slots, one byte of shape, counters, lists
+// What a build of kStaticBuildMaxBoxes boxes carves out of the array, in carve order (every piece rounded up to 256
+// bytes): about 98 bytes per box -- key / value ping-pong 24, priorities 1, child slots 64, counters 4, list 4, one
+// byte of shape -- plus the tile histograms of the finer tiling, the shape scan's records and the bounds.
+constexpr size_t carve_round(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
+constexpr uint64_t kStaticN = kStaticBuildMaxBoxes;
+constexpr size_t kStaticHistBytes = (256ull * div_up(kStaticN, kSmallTile) + 256) * 4;
+constexpr size_t kStaticCarves[] = {
+    kStaticN * 8, kStaticN * 8, kStaticN * 4, kStaticN * 4,      // keys[0], keys[1], vals[0], vals[1]
+    kStaticHistBytes,                                            // block_hist
+    kStaticN + 8, 2 * kStaticN * sizeof(ChildRec),               // prio, child
+    vis_bytes(kStaticN), kStaticN * 4,                           // vis, flags
+    (kStaticN + 1) * 4, kStaticN + 32, kBoundBytes,              // starters, lefts, bounds
+};
+constexpr size_t carve_total() {
+    size_t t = 0;
+    for (size_t b : kStaticCarves) t += carve_round(b);
+    return t;
+}
+constexpr size_t kStaticBytes = carve_total();
+static_assert(kStaticBytes <= kStaticBuildMaxBoxes * 128u, "the static workspace has outgrown 128 bytes per box: check the carve list");
 static __device__ __align__(256) unsigned char scratch[kStaticBytes];
 
 constexpr int kMaxDevices = 64;
-void* g_scratch_ptr[kMaxDevices];  // device address of `scratch` on device d, once looked up
+void* g_scratch_ptr[kMaxDevices];  // device address of `scratch` on device d, once looked up; guarded by g_scratch_mutex
+std::mutex g_scratch_mutex;        // contexts are created from any thread
 
 bool carve(DevBuf& b, unsigned char* base, size_t& off, size_t bytes) {
-    bytes = (bytes + 255) & ~(size_t)255;
+    bytes = carve_round(bytes);
     if (off + bytes > kStaticBytes) return false;
     b.p = base + off;
     b.cap = bytes;
@@ -2816,26 +2835,27 @@ int lbvh_static_workspace_init(rthip_ctx* ctx) {
     if (ctx->device < 0 || ctx->device >= kMaxDevices)
         return rthip_fail(ctx, RTHIP_E_LIMIT, "device %d is beyond the %d devices the static workspace is kept for", ctx->device, kMaxDevices);
     RT_HIP(ctx, hipSetDevice(ctx->device));
-    if (!g_scratch_ptr[ctx->device]) {
-        void* ptr = nullptr;
-        RT_HIP(ctx, hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
-        if (!ptr) return rthip_fail(ctx, RTHIP_E_HIP, "hipGetSymbolAddress returned a null address for the static workspace");
-        g_scratch_ptr[ctx->device] = ptr;
+    unsigned char* base = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        if (!g_scratch_ptr[ctx->device]) {
+            void* ptr = nullptr;
+            RT_HIP(ctx, hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+            if (!ptr) return rthip_fail(ctx, RTHIP_E_HIP, "hipGetSymbolAddress returned a null address for the static workspace");
+            g_scratch_ptr[ctx->device] = ptr;
+        }
+        base = (unsigned char*)g_scratch_ptr[ctx->device];
     }
-    unsigned char* base = (unsigned char*)g_scratch_ptr[ctx->device];
-    const uint64_t n = kStaticBuildMaxBoxes;
-    const uint32_t tiles = div_up(n, kSmallTile);  // the finer of the two tilings
-    const uint64_t hist_elems = 256ull * tiles;
-    const size_t hist_bytes = (hist_elems + 256) * 4;
+    // the same list as kStaticCarves, which sized the array (a piece that no longer fits fails the build of the library's
+    // own sizes at compile time, not a caller's at run time)
     LbvhWorkspace& w = ctx->ws_static;
+    DevBuf* const pieces[] = {&w.keys[0], &w.keys[1], &w.vals[0], &w.vals[1], &w.block_hist, &w.prio, &w.child,
+                              &w.vis, &w.flags, &w.starters, &w.lefts, &w.bounds};
+    static_assert(sizeof(pieces) / sizeof(pieces[0]) == sizeof(kStaticCarves) / sizeof(kStaticCarves[0]), "one size per piece");
     size_t off = 0;
-    bool ok = carve(w.keys[0], base, off, n * 8) && carve(w.keys[1], base, off, n * 8) && carve(w.vals[0], base, off, n * 4) &&
-              carve(w.vals[1], base, off, n * 4) &&
-              carve(w.block_hist, base, off, hist_bytes) &&
-              carve(w.prio, base, off, n + 8) && carve(w.child, base, off, 2 * n * sizeof(ChildRec)) &&
-              carve(w.vis, base, off, vis_bytes(n)) && carve(w.flags, base, off, n * 4) &&
-              carve(w.starters, base, off, (n + 1) * 4) && carve(w.lefts, base, off, n + 32) && carve(w.bounds, base, off, kBoundBytes);
-    if (!ok) return rthip_fail(ctx, RTHIP_E_LIMIT, "the static workspace of %zu bytes is too small for %llu boxes", kStaticBytes, (unsigned long long)n);
+    bool ok = true;
+    for (size_t k = 0; k < sizeof(pieces) / sizeof(pieces[0]); k++) ok = ok && carve(*pieces[k], base, off, kStaticCarves[k]);
+    if (!ok) return rthip_fail(ctx, RTHIP_E_LIMIT, "the static workspace of %zu bytes is too small for %llu boxes", kStaticBytes, (unsigned long long)kStaticN);
     ctx->ws_static_ready = true;
     return RTHIP_OK;
 }

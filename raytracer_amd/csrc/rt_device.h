@@ -659,8 +659,8 @@ __device__ __forceinline__ void finish_hit(const DevScene& S, V3 o, V3 d, const 
 // to 2^31).  All of it is 32-bit arithmetic: a 32-bit integer multiply runs at a quarter of the VALU rate here and a
 // 64-bit one is four of them, and a generator built on two 64-bit multiplies per draw (the splitmix64 finaliser, which
 // this one replaced) was half of what a pixel costs before its ray meets anything.  hash32 is a two-multiply integer
-// hash with low avalanche bias; a path's key is two hashed words (a, b) of (seed, pixel, sample), draw d is
-// hash32(a + d * 0x9E3779B9) ^ b.
+// hash with low avalanche bias; a path's key is two independently hashed words (a, b) of (seed, pixel, sample),
+// draw d is hash32(a + d * 0x9E3779B9) ^ b.
 __device__ __forceinline__ uint32_t hash32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352du;
     x ^= x >> 15; x *= 0x846ca68bu;
@@ -673,8 +673,14 @@ struct Rng {
 };
 __device__ __forceinline__ Rng rng_make(uint64_t seed, uint32_t pixel, uint32_t sample) {
     Rng g;
-    const uint32_t a = hash32(pixel + hash32(sample ^ (uint32_t)seed));
-    const uint32_t b = hash32(a ^ (uint32_t)(seed >> 32) ^ 0x85ebca6bu);
+    // the seed is hashed before it meets the sample index (seeds that differ in their low bits must not hand the
+    // same streams to other strata), and the second word is a hash of (seed, pixel, sample) of its own, not of the
+    // first: the key has 64 independent bits.  Both seed words are wave-uniform, so they cost scalar instructions.
+    const uint32_t lo = (uint32_t)seed, hi = (uint32_t)(seed >> 32);
+    const uint32_t s1 = hash32(lo ^ hash32(hi + 0x6a09e667u));
+    const uint32_t s2 = hash32(hi ^ hash32(lo + 0xbb67ae85u));
+    const uint32_t a = hash32(pixel + hash32(sample + s1));
+    const uint32_t b = hash32(sample + hash32(pixel + s2));
     g.key = (uint64_t)a | ((uint64_t)b << 32);
     g.draw = 0;
     return g;

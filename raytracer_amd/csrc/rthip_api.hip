@@ -691,6 +691,8 @@ int rthip_cast(rthip_ctx* ctx, const rthip_cast_settings* cast, uint64_t seed, f
         }
     }
     RT_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    // (a lambda, so that a failure half-way leaves through one place: below, behind a drain of everything enqueued)
+    const auto render_and_copy = [&]() -> int {
     if (bands <= 1) {
         RT_TRY(rthip_cast_device(ctx, cast, seed, (float*)ctx->frame.p, width, height, nullptr, ctx->stream));
         RT_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
@@ -761,6 +763,21 @@ int rthip_cast(rthip_ctx* ctx, const rthip_cast_settings* cast, uint64_t seed, f
             for (uint32_t t = 0; t < used * per_band; t++) RT_HIP(ctx, status[t]);
         }
         RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return RTHIP_OK;
+    };
+    const int rc = render_and_copy();
+    if (rc != RTHIP_OK) {
+        // Band launches and copies into the caller's buffer or the staging may still be in flight: the caller is free to
+        // release out_rgb once this call has returned, so nothing may be writing to it any more.  (The message of the
+        // failure is already in the context; what the drains return is not reported on top of it.)
+        for (uint32_t k = 0; k < rthip_ctx::kMaxBands; k++) {
+            if (ctx->band_stream[k]) (void)hipStreamSynchronize(ctx->band_stream[k]);
+            if (ctx->band_copy_stream[k]) (void)hipStreamSynchronize(ctx->band_copy_stream[k]);
+        }
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipGetLastError();
+        return rc;
     }
     RT_HIP(ctx, hipEventElapsedTime(&ctx->last_cast_ms, ctx->ev0, ctx->ev1));
     ctx->frame_w = width;  // the image stays in device memory for rthip_hdr_encode(rgb = NULL)

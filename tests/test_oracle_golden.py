@@ -169,6 +169,32 @@ def test_counter_modes_agree_statistically(oracle):
     assert abs(lum(img) - lum(a)) <= 0.01 * lum(a) + 2.0 * abs(lum(a) - lum(b))
 
 
+def test_counter_streams_of_neighbouring_seeds_are_unrelated(oracle):
+    """Frames of consecutive seeds are averaged (accumulation, weak-scaling ranks), so a pixel's streams under seed s
+    must not be the streams of seed s ^ 1 handed to other strata, and the upper seed word must not merely XOR the
+    draws with a constant."""
+    L = oracle.lib()
+    draws = lambda seed, pixel, sample: tuple(L.ora_counter_rand(seed, pixel, sample, d) for d in range(4))
+    for spp in (4, 16, 64):
+        for pixel in (0, 1, 777, 1920 * 1080 - 1):
+            sets = [{draws(seed, pixel, s) for s in range(spp)} for seed in range(8)]
+            for i in range(8):
+                assert len(sets[i]) == spp
+                for j in range(i + 1, 8):
+                    assert not (sets[i] & sets[j]), f"seeds {i} and {j} share streams at pixel {pixel}, {spp} spp"
+    # the first draws alone must differ too (a shared key word with another XOR mask would pass the test above)
+    firsts = [{L.ora_counter_rand(seed, 5, s, 0) ^ L.ora_counter_rand(seed, 5, s, 1) for s in range(16)} for seed in range(4)]
+    for i in range(4):
+        for j in range(i + 1, 4):
+            assert not (firsts[i] & firsts[j])
+    hi = 1 << 32
+    x = {L.ora_counter_rand(1, 9, 0, d) ^ L.ora_counter_rand(1 | hi, 9, 0, d) for d in range(16)}
+    assert len(x) == 16, "the upper seed word only XORs the stream with a constant"
+    # two (pixel, sample) pairs never share a whole key: 64 bits of it are independent
+    keys = {(L.ora_counter_rand(3, p, s, 0), L.ora_counter_rand(3, p, s, 1)) for p in range(4096) for s in range(4)}
+    assert len(keys) == 4096 * 4
+
+
 def _occlusion_scenes():
     verts, indices = scenes.bunny_class_mesh()
     return {"cornell": (scenes.cornell(), 8), "bunny": (scenes.bunny(verts, indices), 2)}
