@@ -243,28 +243,61 @@ def obj_load_figure(tr, want_cpu):
         os.unlink(path)
 
 
-def recorded_traffic(workload: str, kernel_name: str):
-    """HBM bytes per launch of the cast kernel from the PMC passes kept under profiles/ (FETCH_SIZE and
-    WRITE_SIZE, separate rocprofv3 runs of this same command; tools/pmc_traffic.py writes the file).
-    None when no pass was recorded for this workload and kernel."""
-    path = os.path.join(ROOT, "profiles", "traffic.json")
-    if not os.path.exists(path):
-        return None
-    with open(path) as f:
-        table = json.load(f)
+CSRC = os.path.join(ROOT, "raytracer_amd", "csrc")
+# the sources a kernel family is compiled from: a recorded counter is only valid for the revision it was recorded on
+RENDER_SOURCES = ("rt_device.h", "trace.hip", "wavefront.hip", "rthip_internal.h")
+BUILD_SOURCES = ("lbvh_build.hip", "rthip_internal.h")
+
+
+def blob_hash(path: str) -> str:
+    """`git hash-object` of a file (sha1 over 'blob <size>\\0' + contents), without git."""
+    import hashlib
+
+    with open(path, "rb") as f:
+        data = f.read()
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+
+
+def source_hashes() -> dict:
+    return {f: blob_hash(os.path.join(CSRC, f)) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h"))}
+
+
+_RECORDED = {}
+
+
+def recorded_table():
+    """profiles/traffic.json (tools/pmc_traffic.py writes it from rocprofv3 --pmc passes of this same command) and the
+    list of kernel sources that have changed since it was recorded."""
+    if "table" not in _RECORDED:
+        path = os.path.join(ROOT, "profiles", "traffic.json")
+        table, changed = {}, None
+        if os.path.exists(path):
+            with open(path) as f:
+                table = json.load(f)
+            stamp = table.get("_recorded_on", {}).get("sources")
+            now = source_hashes()
+            changed = sorted(now) if not stamp else sorted(f for f in now if stamp.get(f) != now[f])
+        _RECORDED["table"], _RECORDED["changed"] = table, changed
+    return _RECORDED["table"], _RECORDED["changed"]
+
+
+def recorded_counters(workload: str, kernel_name: str, sources=RENDER_SOURCES):
+    """(HBM bytes per launch, VALU instructions per launch, provenance) of a kernel from the recorded PMC passes
+    (FETCH_SIZE, WRITE_SIZE, SQ_INSTS_VALU: separate rocprofv3 runs).  The counters are constants of a revision, not
+    measurements of this run: they are handed out only while the sources the kernel is compiled from have the hashes
+    they were recorded on, otherwise (None, None, reason)."""
+    table, changed = recorded_table()
+    if changed is None:
+        return None, None, "no counter pass recorded (profiles/traffic.json is absent)"
     rec = table.get(workload, {}).get(kernel_name.split(" ")[0])
-    return None if rec is None else rec["hbm_bytes_per_launch"]
-
-
-def recorded_valu_insts(workload: str, kernel_name: str):
-    """Vector-ALU instructions per launch of the cast kernel (SQ_INSTS_VALU, a rocprofv3 pass of its own of this same
-    command, kept in profiles/traffic.json), or None."""
-    path = os.path.join(ROOT, "profiles", "traffic.json")
-    if not os.path.exists(path):
-        return None
-    with open(path) as f:
-        table = json.load(f)
-    return table.get(workload, {}).get(kernel_name.split(" ")[0], {}).get("valu_insts_per_launch")
+    if rec is None:
+        return None, None, f"no counter pass recorded for {workload} / {kernel_name.split(' ')[0]}"
+    stale = [f for f in changed if f in sources]
+    if stale:
+        return None, None, "stale: recorded on another revision of " + ", ".join(stale)
+    on = table.get("_recorded_on", {})
+    return rec["hbm_bytes_per_launch"], rec.get("valu_insts_per_launch"), \
+        f"recorded rocprofv3 --pmc passes of this command ({on.get('when', 'undated')}), sources unchanged since"
 
 
 SIMDS = 256 * 4           # compute units x SIMDs
@@ -396,6 +429,17 @@ def parse_args(argv=None):
                     help="N ranks only join the process group, add up their ranks and rank 0 prints one JSON line: a test of "
                          "the launch path that needs no GPU with --backend gloo")
     ap.add_argument("--build-sizes", default="81920,1000000,10000000")
+    ap.add_argument("--multi", default="ranks", choices=["ranks", "group"],
+                    help="N > 1: 'ranks' = one process per GPU, torch.distributed over RCCL (what a launcher starts; the default); "
+                         "'group' = ONE process drives all N GPUs through rthip_group_cast_device (one context and one host "
+                         "thread per GPU, the shares exchanged over RCCL inside the library, peer copies without it): needs "
+                         "no launcher and no torch.distributed")
+    ap.add_argument("--group-devices", default="",
+                    help="--multi group: the device ids, comma separated (default 0..N-1; an id may repeat, which is how the "
+                         "path is rehearsed on a one-GPU box)")
+    ap.add_argument("--c5-samples", type=int, default=32,
+                    help="samples per pixel axis of the `cornell_mesh_4k_*` strong-scaling entries (BASELINE config 5: 32 = 1024 spp)")
+    ap.add_argument("--no-config5", action="store_true", help="skip the config-5 strong-scaling entries of a multi-GPU run")
     return ap.parse_args(argv)
 
 
@@ -441,13 +485,19 @@ def launch_check(args, rank, world):
         print(json.dumps({"launch_check": True, "n_gpus": world, "backend": args.backend, "rank_sum": float(t.item())}), flush=True)
 
 
-def ceilings(algo_bytes, traffic, valu_insts, kernel_ms, ms_per_step, n_streams):
+def ceilings(algo_bytes, traffic, valu_insts, kernel_ms, ms_per_step, n_streams, why_no_counters=None):
     """What bounds a launch.  `cost_ms` is the time one launch costs on the chip: its own duration when launches run one
     after the other, the timed region / steps when several overlap.  HBM is the bounding ceiling only when the measured
     traffic is of the order of the algorithmic bytes (the scene does not fit the caches); cache-resident scenes are priced
     against vector-ALU issue instead, and an HBM fraction is not printed for more bytes than HBM moved."""
     cost_ms = ms_per_step if n_streams > 1 else kernel_ms
-    out = {"cost_ms_per_launch": round(cost_ms, 4), "hbm_algorithmic_frac": round(algo_bytes / (cost_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    algo_frac = algo_bytes / (cost_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+    out = {"cost_ms_per_launch": round(cost_ms, 4)}
+    if algo_frac <= 1.0:
+        out["hbm_algorithmic_frac"] = round(algo_frac, 4)
+    else:  # more algorithmic bytes per second than HBM can move: the scene is served by the caches
+        out["hbm_algorithmic_frac"] = None
+        out["hbm_algorithmic_note"] = "cache-resident: the algorithmic bytes per second exceed the HBM peak, so this is no HBM statement"
     measured = None
     if traffic:
         measured = traffic / (cost_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
@@ -467,7 +517,7 @@ def ceilings(algo_bytes, traffic, valu_insts, kernel_ms, ms_per_step, n_streams)
         out["bounding"] = "caches (L2 / Infinity Cache) and valu issue: HBM moved a fraction of the algorithmic bytes; no SQ_INSTS_VALU pass recorded"
         out["frac_of_bounding"] = None
     else:
-        out["bounding"] = "unknown: no counter pass recorded for this workload (profiles/traffic.json)"
+        out["bounding"] = "unknown: " + (why_no_counters or "no counter pass recorded for this workload (profiles/traffic.json)")
         out["frac_of_bounding"] = None
     return out
 
@@ -486,7 +536,7 @@ def cached_workload(name):
 
 
 def measure(args, name, steps, warmup, n_streams_arg, rank, world, device_index, want_cpu, cpu_budget_s=20.0, cpu_max_paths=1 << 21,
-            extras=True, traversal=None):
+            extras=True, traversal=None, min_region_s=0.5, max_regions=64):
     """One workload: scene build, counted launches, warm-up, the timed steps, and the figures derived from them."""
     import torch
     import torch.distributed as dist
@@ -545,7 +595,7 @@ def measure(args, name, steps, warmup, n_streams_arg, rank, world, device_index,
     step_no = [0]
     # --combine every: two framebuffers, the RCCL reduce of frame k overlaps the render of frame k + 1
     pipe = rdist.FramePipeline([torch.zeros((H, W, 3), dtype=torch.float32, device="cuda") for _ in range(2)],
-                               args.shard, wl["samples"], world, dst=0)
+                               args.shard, wl["samples"], world, dst=0, tracer=tr)
     seed = 1 + (rank if args.shard == "frames" else 0)
     shard = rdist.shard_record(args.shard, rank, world)
 
@@ -631,36 +681,52 @@ def measure(args, name, steps, warmup, n_streams_arg, rank, world, device_index,
         step()
     pipe.drain()
     finish_image(warmup + 1)
-    if accums is not None:
-        for a in accums:
-            a.zero_()
-    step_no[0] = 0
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
-    t0 = time.perf_counter()
-    for k in range(steps):
-        step(ev[k])
-    host_enqueue_ms = (time.perf_counter() - t0) * 1e3 / steps
-    pipe.drain()
-    finish_image(steps)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
-    t_all = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    r_all = torch.tensor([float(rays)], dtype=torch.float64, device="cuda")
-    if world > 1:
-        if dist.get_backend() == "gloo":
-            t_all, r_all = t_all.cpu(), r_all.cpu()
-        dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
-        dist.all_reduce(r_all, op=dist.ReduceOp.SUM)
-    elapsed = float(t_all.item())
-    total_rays = float(r_all.item())
+    def all_ranks(value, op):
+        """One number per rank -> the MAX / SUM over ranks (the same on every rank)."""
+        if world == 1:
+            return float(value)
+        t = torch.tensor([float(value)], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
+        dist.all_reduce(t, op=op)
+        return float(t.item())
+
+    def timed_region():
+        """EXACTLY `steps` steps, bracketed by a barrier and a device synchronisation on both sides; the image's exchange
+        (--combine end) lies inside.  Returns (seconds: MAX over ranks, mean launch duration in ms, host enqueue ms)."""
+        if accums is not None:
+            for a in accums:
+                a.zero_()
+        step_no[0] = 0
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        t0 = time.perf_counter()
+        for k in range(steps):
+            step(ev[k])
+        enqueue_ms = (time.perf_counter() - t0) * 1e3 / steps
+        pipe.drain()
+        finish_image(steps)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        seconds = time.perf_counter() - t0
+        launch_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        return all_ranks(seconds, dist.ReduceOp.MAX if world > 1 else None), launch_ms, enqueue_ms
+
+    # A region of `steps` steps can be a few milliseconds (the default frame: 20 steps = 3 ms), which is shorter than the
+    # clocks take to settle and than one scheduling hiccup of the host.  The region is therefore run again and again, each
+    # time bracketed as above, until about `min_region_s` of timed work has been done, and the MEDIAN region is the one
+    # reported (the first region decides how many: the same number on every rank, since its time is the MAX over ranks).
+    regions = [timed_region()]
+    repeats = int(min(max_regions, max(1, np.ceil(min_region_s / max(regions[0][0], 1e-6))))) if min_region_s > 0 else 1
+    for _ in range(repeats - 1):
+        regions.append(timed_region())
+    order = sorted(range(len(regions)), key=lambda k: regions[k][0])
+    elapsed, kernel_ms, host_enqueue_ms = regions[order[(len(order) - 1) // 2]]  # the median region (the lower one of two)
+    region_ms = [r[0] * 1e3 / steps for r in regions]
+    total_rays = all_ranks(rays, dist.ReduceOp.SUM if world > 1 else None)
 
     last = T.get_stats(tr)
     kernel_name = {0: f"cast_kernel (persistent, refill {last['last_cast_refill']})", 1: "cast_static_kernel", 4: "cast_samples_kernel",
@@ -668,19 +734,19 @@ def measure(args, name, steps, warmup, n_streams_arg, rank, world, device_index,
     if ray_o is not None:
         kernel_name = "trace_rays_kernel"
     table_key = name + ("+fast" if traversal == "fast" else "")
-    traffic = recorded_traffic(table_key, kernel_name)
+    traffic, valu_insts, counters_from = recorded_counters(table_key, kernel_name)
     if ray_o is not None and traffic is None:  # deep scenes: the library takes the ray stream's persistent kernel
-        traffic = recorded_traffic(table_key, "trace_rays_persistent_kernel")
-        if traffic is not None:
+        t2, v2, from2 = recorded_counters(table_key, "trace_rays_persistent_kernel")
+        if t2 is not None:
+            traffic, valu_insts, counters_from = t2, v2, from2
             kernel_name = "trace_rays_persistent_kernel"
-    valu_insts = recorded_valu_insts(table_key, kernel_name)
     line = None
     if rank == 0:
         value = total_rays * steps / elapsed / 1e6
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
         ms_per_step = elapsed / steps * 1e3
         overlapped = algo_bytes * steps / elapsed / 1e9
-        bound = ceilings(algo_bytes, traffic, valu_insts, kernel_ms, ms_per_step, n_streams)
+        bound = ceilings(algo_bytes, traffic, valu_insts, kernel_ms, ms_per_step, n_streams, counters_from)
         line = {
             "metric": "Mrays/sec (whole node); LBVH build ms per 1M triangles",
             "value": round(value, 2),
@@ -689,6 +755,9 @@ def measure(args, name, steps, warmup, n_streams_arg, rank, world, device_index,
             "steps": steps,
             "warmup": warmup,
             "ms_per_step": round(ms_per_step, 4),
+            # `value` / `ms_per_step` are the MEDIAN of `count` timed regions of exactly `steps` steps each (see timed_region)
+            "regions": {"count": len(regions), "ms_per_step_min": round(min(region_ms), 4), "ms_per_step_median": round(ms_per_step, 4),
+                        "ms_per_step_max": round(max(region_ms), 4), "first_region_ms_per_step": round(region_ms[0], 4)},
             "host_enqueue_ms_per_step": round(host_enqueue_ms, 4),
             "higher_is_better": True,
             "scaling": "weak" if args.shard == "frames" else "strong",
@@ -702,19 +771,21 @@ def measure(args, name, steps, warmup, n_streams_arg, rank, world, device_index,
                                "framebuffers summed onto rank 0 with RCCL every step" if combine == "every" else
                                "every step adds its sample set to the rank's accumulator, ONE RCCL sum onto rank 0 at the end "
                                "of the timed steps (inside the timed region)"),
-                           "tiles": "ranks render interleaved 64x64 tiles of one frame; shares summed onto rank 0 with RCCL",
+                           "tiles": "ranks render interleaved 64x64 tiles of one frame; every rank's own tiles (1/N of the frame) gathered onto rank 0 with RCCL, nothing is added",
                            "samples": "ranks render sample indices s % N == rank of one frame; sums added onto rank 0 with RCCL"}[args.shard]},
             # `achieved` / `frac`: ALGORITHMIC bytes of one launch over the mean duration of one launch (HIP events on its
             # stream; with --streams > 1 other launches run beside it, as rocprofv3 reports it).  Whether HBM is the ceiling
             # that binds is said by `bounding` (see ceilings()): `traffic` far below the algorithmic bytes = cache-resident.
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "kernel": kernel_name,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": counters_from, "kernel": kernel_name,
                          "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": int(algo_bytes),
                          "per_ray": {"nodes": round(st["nodes_tested"] / max(rays, 1), 2),
                                      "triangles": round(st["tris_tested"] / max(rays, 1), 3),
                                      "instances": round(st["inst_entered"] / max(rays, 1), 3)},
-                         # box tests per lane and wave step (the ordered walk tests two boxes in a step)
-                         "lane_utilisation": round(st["nodes_tested"] / max((128 if traversal == "fast" else 64) * st["wave_steps"], 1), 4),
+                         # share of the lanes at work in a step of the walk (lane steps / 64 x wave steps, from the kernel's
+                         # own counters; the same meaning in both traversal modes, never above 1)
+                         "lane_utilisation": round(st["lane_steps"] / max(64 * st["wave_steps"], 1), 4),
+                         "box_tests_per_lane_step": round(st["nodes_tested"] / max(st["lane_steps"], 1), 3),
                          "concurrent_launches": n_streams,
                          "algorithmic_rate_overlapped_gbs": round(overlapped, 2),
                          # a fraction of the HBM peak only where that is a statement about HBM: never above 1
@@ -790,6 +861,8 @@ EXTRA_RUNS = [
     ("instanced_rays", "instanced-rays", 4, 8, 2, "exact"),
     ("cornell", "cornell", 4, 40, 5, "exact"),
     ("cornell_mesh_4k", "cornell-mesh", 1, 4, 1, "exact"),
+    # BASELINE config 5's frame itself (1024 spp: --c5-samples 32), one step: the N = 1 end of its strong-scaling curve
+    ("cornell_mesh_4k_1024spp", "cornell-mesh", 1, 1, 0, "exact"),
     # the opt-in ordered walk (rthip_set_traversal(RTHIP_TRAV_FAST)) on the deep scenes
     ("bunny_fast", "bunny", 4, 40, 5, "fast"),
     ("instanced_fast", "instanced", 4, 12, 2, "fast"),
@@ -800,11 +873,124 @@ EXTRA_RUNS = [
 ]
 
 
+def config5_entries(args, rank, world, device_index):
+    """One frame of the Cornell + mesh scene at --c5-samples^2 spp, sharded by tiles and by samples over the ranks."""
+    import copy
+
+    out = {}
+    for shard in ("tiles", "samples"):
+        a = copy.copy(args)
+        a.shard, a.combine, a.samples = shard, "every", args.c5_samples
+        sub = measure(a, "cornell-mesh", 1, 0, 1, rank, world, device_index, False, extras=False, min_region_s=0.0)
+        if rank == 0:
+            c = compact(sub)
+            c["scaling"], c["n_gpus"], c["sharding"] = "strong", world, sub["config"]["sharding"]
+            out[f"cornell_mesh_4k_{args.c5_samples * args.c5_samples}spp_{shard}"] = c
+    return out
+
+
+def group_main(args):
+    """`--multi group`: the whole node from ONE process.  A group of contexts (rthip_group_*, one per GPU, one host thread
+    each) renders ONE frame per step, split by 64x64 tiles (--shard tiles, also what `frames` means here) or by sample
+    index (--shard samples), and the shares meet on the first device inside the library -- over RCCL when the devices are
+    distinct and the RCCL library loads, by peer copies otherwise.  No launcher, no torch.distributed: a box on which
+    those fail still yields a number.  Strong scaling; `value` = rays of the frame / time of a call."""
+    import torch
+
+    from raytracer_amd import tracer as T
+
+    ids = [int(x) for x in args.group_devices.split(",") if x] or list(range(args.gpus))
+    if len(ids) != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but --group-devices names {len(ids)} devices")
+    torch.cuda.set_device(ids[0])
+
+    def run(name, shard, samples, steps, warmup):
+        wl = cached_workload(name)
+        if samples > 0:
+            wl["samples"] = samples
+        if args.width > 0 and args.height > 0:
+            wl["width"], wl["height"] = args.width, args.height
+            wl["label"] += f" [frame overridden: {args.width}x{args.height}]"
+        W, H = wl["width"], wl["height"]
+        if shard == "samples" and wl["samples"] < 2:
+            raise SystemExit("--shard samples needs a workload with samples >= 2")
+        g = T.RT_TracerGroup(ids, T.RT_TracerSettings(max_bounces=wl["bounces"], sky=wl["sky"]), shard=shard)
+        if args.traversal == "fast":
+            g.check(g.lib.rthip_group_set_traversal(g.g, T.TRAVERSALS["fast"]), "rthip_group_set_traversal")
+        t0 = time.perf_counter()
+        g.build_blas(wl["world"])
+        g.build_tlas(wl["world"])
+        build_ms = (time.perf_counter() - t0) * 1e3
+        cast = wl["cam"](W, H, wl["samples"])
+        fb = torch.zeros((H, W, 3), dtype=torch.float32, device=f"cuda:{ids[0]}")
+        ctxs = [g.ctx(k) for k in range(len(ids))]
+        for c in ctxs:
+            T.set_counting(c, True)
+            T.get_stats(c)
+        g.cast_device(cast, fb.data_ptr(), W, H, seed=1)
+        st = [T.get_stats(c) for c in ctxs]
+        for c in ctxs:
+            T.set_counting(c, False)
+        tot = {k: sum(s[k] for s in st) for k in ("rays", "nodes_tested", "tris_tested", "inst_entered", "wave_steps", "lane_steps")}
+        algo = 48 * tot["rays"] + 32 * tot["nodes_tested"] + 48 * tot["tris_tested"] + 64 * tot["inst_entered"]
+        for k in range(warmup):
+            g.cast_device(cast, fb.data_ptr(), W, H, seed=1)
+
+        def region():
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for k in range(steps):
+                g.cast_device(cast, fb.data_ptr(), W, H, seed=1)  # returns when the frame is whole on the first device
+            torch.cuda.synchronize()
+            return time.perf_counter() - t0
+
+        regions = [region()]
+        repeats = int(min(16, max(1, np.ceil(0.5 / max(regions[0], 1e-6)))))
+        regions += [region() for _ in range(repeats - 1)]
+        elapsed = sorted(regions)[(len(regions) - 1) // 2]
+        ms = elapsed / steps * 1e3
+        transport = g.transport()
+        g.close()
+        per_gpu = algo / len(ids) / (ms * 1e-3) / 1e9  # every device walks its share while the others walk theirs
+        return {"workload": wl["label"] + f", samples={wl['samples']}", "value": round(tot["rays"] / ms / 1e3, 2), "unit": "Mrays/s",
+                "ms_per_step": round(ms, 4), "steps": steps,
+                "regions": {"count": len(regions), "ms_per_step_min": round(min(regions) / steps * 1e3, 4),
+                            "ms_per_step_max": round(max(regions) / steps * 1e3, 4)},
+                "rays_per_frame": int(tot["rays"]), "shard": shard, "transport": transport, "devices": ids,
+                "scene_build_ms_all_devices": round(build_ms, 2), "algorithmic_bytes_per_frame": int(algo),
+                "per_ray": {"nodes": round(tot["nodes_tested"] / max(tot["rays"], 1), 2), "triangles": round(tot["tris_tested"] / max(tot["rays"], 1), 3),
+                            "instances": round(tot["inst_entered"] / max(tot["rays"], 1), 3)},
+                "lane_utilisation": round(tot["lane_steps"] / max(64 * tot["wave_steps"], 1), 4),
+                "algorithmic_gbs_per_gpu": round(per_gpu, 2)}
+
+    shard = "tiles" if args.shard == "frames" else args.shard
+    main_run = run(args.workload, shard, args.samples, args.steps, args.warmup)
+    line = {
+        "metric": "Mrays/sec (whole node); LBVH build ms per 1M triangles", "value": main_run["value"], "unit": "Mrays/s",
+        "n_gpus": len(ids), "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_run["ms_per_step"],
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": main_run["workload"], "multi": "group: one process, rthip_group_cast_device", "shard": shard,
+                   "transport": main_run["transport"], "devices": ids, "rays_per_frame": main_run["rays_per_frame"]},
+        # whole-call time (render on every device + exchange + placement), algorithmic bytes of the frame / devices
+        "roofline": {"bound": "hbm", "achieved": main_run["algorithmic_gbs_per_gpu"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(main_run["algorithmic_gbs_per_gpu"] / HBM_PEAK_GBS, 5), "traffic": None,
+                     "traffic_source": "not recorded for the group path", "per_ray": main_run["per_ray"],
+                     "lane_utilisation": main_run["lane_utilisation"], "kernel": "the cast kernels of every device + exchange"},
+        "regions": main_run["regions"],
+    }
+    if not args.no_config5 and args.workload == "bunny" and args.samples == 0:
+        line["workloads"] = {f"cornell_mesh_4k_{args.c5_samples * args.c5_samples}spp_{m}": run("cornell-mesh", m, args.c5_samples, 1, 0)
+                             for m in ("tiles", "samples")}
+    print(json.dumps(line), flush=True)
+
+
 def compact(line):
     r = line["roofline"]
     out = {"workload": line["config"]["workload"], "value": line["value"], "unit": line["unit"], "ms_per_step": line["ms_per_step"],
-           "steps": line["steps"], "streams": line["config"]["streams"], "rays_per_frame": line["config"]["rays_per_frame_per_gpu"],
+           "steps": line["steps"], "regions": line["regions"], "streams": line["config"]["streams"],
+           "rays_per_frame": line["config"]["rays_per_frame_per_gpu"],
            "kernel": r["kernel"], "kernel_ms": r["kernel_ms"], "per_ray": r["per_ray"], "lane_utilisation": r["lane_utilisation"],
+           "box_tests_per_lane_step": r["box_tests_per_lane_step"], "traffic_source": r["traffic_source"],
            "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_launch"], "traffic": r["traffic"], "ceilings": r["ceilings"],
            "bounding": r["bounding"], "frac_of_bounding": r["frac_of_bounding"], "scene_build_ms": line["scene_build_ms"]}
     if "cpu_baseline" in line:
@@ -815,6 +1001,9 @@ def compact(line):
 def main():
     argv = sys.argv[1:]
     args = parse_args(argv)
+    if args.multi == "group":
+        group_main(args)
+        return
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(self_launch(args, argv))  # nothing in this process has touched the GPU yet
 
@@ -845,11 +1034,25 @@ def main():
                    and args.traversal == "exact")
     if rank == 0 and default_run:
         others = {}
+        import copy
+
         for key, name, n_streams, steps, warmup, traversal in EXTRA_RUNS:
-            sub = measure(args, name, steps, warmup, n_streams, rank, world, device_index, want_cpu and traversal == "exact",
-                          cpu_budget_s=4.0, cpu_max_paths=1 << 17, extras=False, traversal=traversal)
+            a, c5 = args, key.endswith("spp")
+            if c5:
+                a = copy.copy(args)
+                a.samples = args.c5_samples
+                key = f"cornell_mesh_4k_{args.c5_samples * args.c5_samples}spp"
+            sub = measure(a, name, steps, warmup, n_streams, rank, world, device_index, want_cpu and traversal == "exact" and not c5,
+                          cpu_budget_s=4.0, cpu_max_paths=1 << 17, extras=False, traversal=traversal, min_region_s=0.0 if c5 else 0.3)
             others[key] = compact(sub)
         line["workloads"] = others
+    if world > 1 and not args.no_config5 and args.workload == "bunny" and args.shard == "frames":
+        # BASELINE config 5 proper beside the weak-scaling headline: ONE Cornell + mesh frame at 3840x2160 and 1024 spp
+        # split between the ranks by tiles (an RCCL gather of disjoint tiles) and by sample index (an RCCL sum), one
+        # exchange per frame: strong scaling.  Every rank takes part; rank 0 keeps the figures.
+        others = config5_entries(args, rank, world, device_index)
+        if rank == 0:
+            line["workloads"] = others
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:

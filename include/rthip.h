@@ -50,7 +50,7 @@
 extern "C" {
 #endif
 
-#define RTHIP_ABI_VERSION 1
+#define RTHIP_ABI_VERSION 2
 
 enum {
     RTHIP_OK = 0,
@@ -149,14 +149,17 @@ typedef struct rthip_stats {
     uint64_t nodes_tested;  /* BVH nodes whose box was tested (both levels)   */
     uint64_t tris_tested;   /* triangles handed to the triangle test          */
     uint64_t inst_entered;  /* TLAS leaves entered                            */
-    uint64_t wave_steps;    /* traversal-loop iterations summed over waves:
-                               nodes_tested / (64 * wave_steps) = lane utilisation */
+    uint64_t wave_steps;    /* traversal-loop iterations summed over waves    */
     float last_cast_ms;     /* device time of the last cast / trace kernel(s) */
     float last_build_ms;    /* device time of the last LBVH build             */
     uint32_t last_cast_kernel; /* RTHIP_KERNEL_* the last cast ran (never AUTO)  */
     uint32_t last_cast_refill; /* persistent kernel: idle lanes that end a traversal phase; else 0 */
     float last_encode_ms;   /* device time of the last rthip_hdr_encode       */
     uint32_t reserved;
+    uint64_t lane_steps;    /* the same iterations summed over the lanes that took part in them:
+                               lane_steps / (64 * wave_steps) = share of the lanes at work, in either
+                               traversal mode (a step of the ordered walk tests up to four boxes, so
+                               nodes_tested is no measure of it there) */
 } rthip_stats;
 
 typedef struct rthip_ctx rthip_ctx;
@@ -244,15 +247,22 @@ int rthip_cast_accumulate_device(rthip_ctx* ctx, const rthip_cast_settings* cast
 /* The reference has one tracer and no notion of devices (raytracer_core.h:180-184); a host that wants the whole node
  * behind those five hooks makes ONE group instead of one context.  A group holds one context per entry of device_ids
  * (an id may repeat: contexts then share a GPU, which is how the path is tested on a one-GPU box).  The scene calls
- * mirror the single-context ones and replicate the scene on every device (one host thread per device; every device
- * builds its own BVHs from the same host data).  rthip_group_cast renders ONE frame with all devices:
+ * mirror the single-context ones and replicate the scene on every device (one host thread per device, started with
+ * the group and ended with it; every device builds its own BVHs from the same host data).  rthip_group_cast renders
+ * ONE frame with all devices:
  *   shard_mode 1 (tiles)    device k renders the 64x64 tiles t with t % n == k and ships only those (1/n of the frame),
  *                           packed: straight to the host buffer (rthip_group_cast: each device copies its own tiles over
- *                           its own PCIe link into page-locked staging and its thread places the rows), or by peer copy
- *                           over xGMI to the first device (rthip_group_cast_device).  Bit-identical to rthip_cast.
- *   shard_mode 2 (samples)  device k renders the samples s with s % n == k of every pixel; the partial sums go to the
- *                           first device by peer copy and are added there in rank order, then scaled by 1/samples^2:
- *                           equal to rthip_cast up to the rounding of another order of additions.
+ *                           its own PCIe link into page-locked staging and its thread places the rows), or over xGMI to
+ *                           the first device (rthip_group_cast_device).  Bit-identical to rthip_cast.
+ *   shard_mode 2 (samples)  device k renders the samples s with s % n == k of every pixel; the partial sums are added
+ *                           on the first device, then scaled by 1/samples^2: equal to rthip_cast up to the rounding of
+ *                           another order of additions.
+ * Transport between the devices (rthip_group_transport names the one in use): RCCL -- one communicator per device
+ * (ncclCommInitAll), the tiles by grouped ncclSend / ncclRecv, the partial sums by ncclReduce -- when the group's
+ * devices are distinct and the RCCL library can be loaded at run time (it is not linked); otherwise
+ * hipMemcpyPeerAsync into the first device and a sum there in rank order.  RTHIP_GROUP_TRANSPORT=peer|rccl in the
+ * environment insists on one of them (rccl: group creation fails without it, and a group of one device runs its
+ * exchange through RCCL as well).
  * d_out_rgb of rthip_group_cast_device is memory of the first device (rthip_group_ctx(g, 0)); both calls return when
  * the frame is complete.  Settings that are per context (cast kernel, counting, statistics, taps, tree read-back) go
  * through rthip_group_ctx.  A group is driven from one thread at a time, like a context. */
@@ -262,6 +272,7 @@ void rthip_group_destroy(rthip_group* group);
 int rthip_group_size(const rthip_group* group);
 rthip_ctx* rthip_group_ctx(rthip_group* group, int rank);
 const char* rthip_group_last_error(const rthip_group* group);
+const char* rthip_group_transport(const rthip_group* group);
 int rthip_group_set_tracer(rthip_group* group, uint32_t max_bounces, int sky);
 int rthip_group_set_morton_bounds(rthip_group* group, int mode);
 int rthip_group_set_traversal(rthip_group* group, int mode);
@@ -276,6 +287,17 @@ int rthip_group_cast(rthip_group* group, const rthip_cast_settings* cast, uint64
                      int height, int shard_mode);
 int rthip_group_cast_device(rthip_group* group, const rthip_cast_settings* cast, uint64_t seed, float* d_out_rgb, int width,
                             int height, int shard_mode);
+
+/* The tile exchange's two kernels, for hosts that move the tiles themselves (one process per GPU, a gather over RCCL):
+ * rank r's tiles are the 64x64 tiles t with t % world == r in row-major tile order (rthip_shard mode 1);
+ * rthip_tiles_of_rank is how many there are.  Packed, tile s of the rank occupies floats [s * 12288, (s + 1) * 12288):
+ * 64 rows of 64 rgb pixels, the part outside the image zero.  pack reads them out of a frame, unpack places them into
+ * one (other pixels untouched).  Both enqueue on `stream` and return.  No counterpart in the reference. */
+uint32_t rthip_tiles_of_rank(int width, int height, uint32_t rank, uint32_t world);
+int rthip_tiles_pack_device(rthip_ctx* ctx, const float* d_rgb, int width, int height, uint32_t rank, uint32_t world,
+                            float* d_packed, void* stream);
+int rthip_tiles_unpack_device(rthip_ctx* ctx, const float* d_packed, int width, int height, uint32_t rank, uint32_t world,
+                              float* d_rgb, void* stream);
 
 /* ---- parity and measurement taps -------------------------------------- */
 

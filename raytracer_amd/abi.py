@@ -42,7 +42,7 @@ STATS = np.dtype(
     [("rays", "<u8"), ("nodes_tested", "<u8"), ("tris_tested", "<u8"), ("inst_entered", "<u8"),
      ("wave_steps", "<u8"), ("last_cast_ms", "<f4"), ("last_build_ms", "<f4"),
      ("last_cast_kernel", "<u4"), ("last_cast_refill", "<u4"),
-     ("last_encode_ms", "<f4"), ("reserved", "<u4")],
+     ("last_encode_ms", "<f4"), ("reserved", "<u4"), ("lane_steps", "<u8")],
     align=False,
 )
 # rthip_ray_record
@@ -54,7 +54,7 @@ OBJ_INFO = np.dtype([("vertex_count", "<u4"), ("index_count", "<u4"), ("attrs", 
                      ("parse_ms", "<f4"), ("dedup_ms", "<f4"), ("total_ms", "<f4"), ("host_threads", "<u4")], align=False)
 assert OBJ_INFO.itemsize == 32
 assert MATERIAL.itemsize == 40 and INSTANCE.itemsize == 68 and CAST.itemsize == 84
-assert NODE.itemsize == 32 and SHARD.itemsize == 12 and STATS.itemsize == 64
+assert NODE.itemsize == 32 and SHARD.itemsize == 12 and STATS.itemsize == 72
 
 MAT_LAMBERTIAN, MAT_DIELECTRIC, MAT_METAL, MAT_NORMAL, MAT_LIGHT = range(5)
 INST_SPHERE, INST_MESH = 0, 1
@@ -83,6 +83,7 @@ SYMBOLS = [
     ("rthip_group_size", C.c_int, [_P]),
     ("rthip_group_ctx", _P, [_P, C.c_int]),
     ("rthip_group_last_error", C.c_char_p, [_P]),
+    ("rthip_group_transport", C.c_char_p, [_P]),
     ("rthip_group_set_tracer", C.c_int, [_P, C.c_uint32, C.c_int]),
     ("rthip_group_set_morton_bounds", C.c_int, [_P, C.c_int]),
     ("rthip_group_set_traversal", C.c_int, [_P, C.c_int]),
@@ -93,6 +94,9 @@ SYMBOLS = [
     ("rthip_group_tlas_build", C.c_int, [_P, _P, C.c_uint32, _P, C.c_uint32]),
     ("rthip_group_cast", C.c_int, [_P, _P, C.c_uint64, _P, C.c_int, C.c_int, C.c_int]),
     ("rthip_group_cast_device", C.c_int, [_P, _P, C.c_uint64, _P, C.c_int, C.c_int, C.c_int]),
+    ("rthip_tiles_of_rank", C.c_uint32, [C.c_int, C.c_int, C.c_uint32, C.c_uint32]),
+    ("rthip_tiles_pack_device", C.c_int, [_P, _P, C.c_int, C.c_int, C.c_uint32, C.c_uint32, _P, _P]),
+    ("rthip_tiles_unpack_device", C.c_int, [_P, _P, C.c_int, C.c_int, C.c_uint32, C.c_uint32, _P, _P]),
     ("rthip_lbvh_build", C.c_int, [_P, _P, C.c_uint64, _P, _P, _P, _P, _P]),
     ("rthip_lbvh_build_device", C.c_int, [_P, _P, C.c_uint64, _P, _P]),
     ("rthip_lbvh_reserve", C.c_int, [_P, C.c_uint64]),

@@ -1,15 +1,23 @@
 // Several GPUs of one node behind one handle: the scene is replicated (every device builds its own BVHs from the same
 // host data), a frame is split by 64x64 tiles or by sample index (rthip_shard), and the shares are brought together with
 // peer copies over xGMI: in tile mode every device ships only its own tiles (1/N of the frame), packed; in sample mode
-// the devices' partial sums are added on the first device in rank order, so the result does not depend on timing.
-// One host thread per device drives its context; nothing here computes on the host except placing tile rows into the
-// caller's buffer.
+// the devices' partial sums are added on the first device.  Transport between devices: RCCL (one communicator per device
+// from ncclCommInitAll, the tiles gathered with grouped ncclSend / ncclRecv, the partial sums with ncclReduce) when the
+// RCCL library can be loaded and the group's devices are distinct; otherwise hipMemcpyPeerAsync into the first device and
+// a sum there in rank order.  One persistent host thread per device drives its context (started with the group, ended
+// with it); nothing here computes on the host except placing tile rows into the caller's buffer.
 
+#include <dlfcn.h>
 #include <string.h>
 
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
+
+#include <rccl/rccl.h>  // types and prototypes only: the library is loaded at run time (rccl_load), not linked
 
 #include "rthip_internal.h"
 
@@ -68,6 +76,69 @@ uint32_t tiles_of_rank(int w, int h, uint32_t rank, uint32_t world) {
     return tiles > rank ? (tiles - rank + world - 1) / world : 0u;
 }
 
+// The RCCL entry points the group uses, looked up in the library at run time: a process that never makes a group of
+// several devices never loads it, and a box without it still gets the peer-copy transport.
+struct RcclApi {
+    void* lib = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclReduce) Reduce = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    bool ok = false;
+};
+
+// One host thread per device beyond the first, alive for as long as the group: a call hands every thread its piece and
+// runs the first device's piece itself.
+struct DeviceWorker {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::function<int()> job;
+    bool has_job = false, done = false, stop = false;
+    int rc = RTHIP_OK;
+    void start() {
+        th = std::thread([this] {
+            for (;;) {
+                std::unique_lock<std::mutex> lock(m);
+                cv.wait(lock, [&] { return stop || has_job; });
+                if (stop) return;
+                std::function<int()> fn = std::move(job);
+                has_job = false;
+                lock.unlock();
+                const int r = fn();
+                lock.lock();
+                rc = r;
+                done = true;
+                cv.notify_all();
+            }
+        });
+    }
+    void post(std::function<int()> fn) {
+        std::lock_guard<std::mutex> lock(m);
+        job = std::move(fn);
+        has_job = true;
+        done = false;
+        cv.notify_all();
+    }
+    int wait() {
+        std::unique_lock<std::mutex> lock(m);
+        cv.wait(lock, [&] { return done; });
+        return rc;
+    }
+    void end() {
+        {
+            std::lock_guard<std::mutex> lock(m);
+            stop = true;
+        }
+        cv.notify_all();
+        if (th.joinable()) th.join();
+    }
+};
+
 }  // namespace
 
 struct rthip_group {
@@ -76,7 +147,12 @@ struct rthip_group {
     std::vector<DevBuf> packed;     // per device: its tiles, packed
     std::vector<void*> host_stage;  // per device: page-locked staging for rthip_group_cast
     std::vector<size_t> host_stage_bytes;
-    DevBuf gather;                  // on device 0: every rank's packed tiles / partial frames
+    std::vector<DeviceWorker*> workers;  // workers[k - 1] drives device k
+    DevBuf gather;                  // on device 0: every rank's packed tiles / partial frames (RCCL: the reduced frame)
+    RcclApi rccl;
+    std::vector<ncclComm_t> comms;  // one per device when the transport is RCCL
+    bool use_rccl = false;
+    std::string transport = "peer copies (hipMemcpyPeerAsync)";
     std::string err;
 };
 
@@ -87,19 +163,77 @@ int group_fail(rthip_group* g, int code, const std::string& msg) {
     return code;
 }
 
-// fn(k) on one host thread per device; the first failure is reported with the device's message
+// fn(k) for every device: device 0 on the calling thread, the others on their own threads; the first failure is
+// reported with the device's message
 template <class F>
 int for_each_device(rthip_group* g, F fn) {
     const size_t n = g->ctx.size();
+    for (size_t k = 1; k < n; k++) g->workers[k - 1]->post([&fn, k] { return fn((int)k); });
     std::vector<int> rc(n, RTHIP_OK);
-    std::vector<std::thread> th;
-    for (size_t k = 1; k < n; k++) th.emplace_back([&, k] { rc[k] = fn((int)k); });
     rc[0] = fn(0);
-    for (auto& t : th) t.join();
+    for (size_t k = 1; k < n; k++) rc[k] = g->workers[k - 1]->wait();
     for (size_t k = 0; k < n; k++)
         if (rc[k] != RTHIP_OK) return group_fail(g, rc[k], "device " + std::to_string(g->ctx[k]->device) + " (rank " + std::to_string(k) + "): " + g->ctx[k]->err);
     return RTHIP_OK;
 }
+
+bool rccl_load(RcclApi& a) {
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* name : names)  // a copy the process already holds first (a host program that links RCCL, torch's own)
+        if (!a.lib) a.lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
+    for (const char* name : names)
+        if (!a.lib) a.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+    if (!a.lib) return false;
+#define RT_RCCL_SYM(field, symbol) a.field = (decltype(a.field))dlsym(a.lib, symbol)
+    RT_RCCL_SYM(CommInitAll, "ncclCommInitAll");
+    RT_RCCL_SYM(CommDestroy, "ncclCommDestroy");
+    RT_RCCL_SYM(GetErrorString, "ncclGetErrorString");
+    RT_RCCL_SYM(GroupStart, "ncclGroupStart");
+    RT_RCCL_SYM(GroupEnd, "ncclGroupEnd");
+    RT_RCCL_SYM(Reduce, "ncclReduce");
+    RT_RCCL_SYM(Send, "ncclSend");
+    RT_RCCL_SYM(Recv, "ncclRecv");
+#undef RT_RCCL_SYM
+    a.ok = a.CommInitAll && a.CommDestroy && a.GetErrorString && a.GroupStart && a.GroupEnd && a.Reduce && a.Send && a.Recv;
+    return a.ok;
+}
+
+// RTHIP_GROUP_TRANSPORT: "peer" never loads RCCL; "rccl" insists on it (group creation fails without it, and a group of
+// ONE device runs its exchange through it too: the rehearsal on a one-GPU box); unset / "auto": RCCL for several distinct
+// devices when it can be had, peer copies otherwise.
+int transport_setup(rthip_group* g) {
+    const char* want = getenv("RTHIP_GROUP_TRANSPORT");
+    const bool force_rccl = want && strcmp(want, "rccl") == 0, force_peer = want && strcmp(want, "peer") == 0;
+    const size_t n = g->ctx.size();
+    bool distinct = true;
+    for (size_t a = 0; a < n; a++)
+        for (size_t b = a + 1; b < n; b++) distinct = distinct && g->ctx[a]->device != g->ctx[b]->device;
+    if (force_peer || (!force_rccl && (n < 2 || !distinct))) return RTHIP_OK;
+    if (!distinct) return group_fail(g, RTHIP_E_INVALID, "RTHIP_GROUP_TRANSPORT=rccl needs distinct devices (one communicator per GPU)");
+    if (!rccl_load(g->rccl)) {
+        if (force_rccl) return group_fail(g, RTHIP_E_HIP, std::string("RTHIP_GROUP_TRANSPORT=rccl but the RCCL library cannot be loaded: ") + (dlerror() ? dlerror() : "symbols missing"));
+        return RTHIP_OK;
+    }
+    std::vector<int> devs(n);
+    for (size_t k = 0; k < n; k++) devs[k] = g->ctx[k]->device;
+    g->comms.assign(n, nullptr);
+    const ncclResult_t r = g->rccl.CommInitAll(g->comms.data(), (int)n, devs.data());
+    if (r != ncclSuccess) {
+        g->comms.clear();
+        (void)hipGetLastError();
+        if (force_rccl) return group_fail(g, RTHIP_E_HIP, std::string("ncclCommInitAll failed: ") + g->rccl.GetErrorString(r));
+        return RTHIP_OK;  // the peer copies remain
+    }
+    g->use_rccl = true;
+    g->transport = "RCCL (ncclCommInitAll; tiles by grouped ncclSend / ncclRecv, sample sums by ncclReduce)";
+    return RTHIP_OK;
+}
+
+#define RT_RCCL(g, call)                                                                                                  \
+    do {                                                                                                                  \
+        const ncclResult_t r_ = (call);                                                                                   \
+        if (r_ != ncclSuccess) return group_fail(g, RTHIP_E_HIP, std::string(#call) + ": " + (g)->rccl.GetErrorString(r_)); \
+    } while (0)
 
 int check_group_cast(rthip_group* g, const rthip_cast_settings* cast, int w, int h, int mode) {
     if (!cast) return group_fail(g, RTHIP_E_INVALID, "cast settings are NULL");
@@ -158,12 +292,34 @@ int rthip_group_create(rthip_group** out, int n, const int* device_ids) {
     g->packed.resize(n);
     g->host_stage.assign(n, nullptr);
     g->host_stage_bytes.assign(n, 0);
+    for (int k = 1; k < n; k++) {
+        g->workers.push_back(new DeviceWorker());
+        g->workers.back()->start();
+    }
+    const int rc = transport_setup(g);
+    if (rc != RTHIP_OK) {
+        fprintf(stderr, "rthip_group_create: %s\n", g->err.c_str());
+        rthip_group_destroy(g);
+        return rc;
+    }
     *out = g;
     return RTHIP_OK;
 }
 
 void rthip_group_destroy(rthip_group* g) {
     if (!g) return;
+    for (DeviceWorker* w : g->workers) {
+        w->end();
+        delete w;
+    }
+    g->workers.clear();
+    for (size_t k = 0; k < g->ctx.size(); k++) {
+        (void)hipSetDevice(g->ctx[k]->device);
+        (void)hipDeviceSynchronize();
+    }
+    for (ncclComm_t c : g->comms)
+        if (c) (void)g->rccl.CommDestroy(c);
+    g->comms.clear();
     for (size_t k = 0; k < g->ctx.size(); k++) {
         (void)hipSetDevice(g->ctx[k]->device);
         (void)hipDeviceSynchronize();
@@ -182,6 +338,7 @@ void rthip_group_destroy(rthip_group* g) {
 int rthip_group_size(const rthip_group* g) { return g ? (int)g->ctx.size() : 0; }
 rthip_ctx* rthip_group_ctx(rthip_group* g, int rank) { return (g && rank >= 0 && (size_t)rank < g->ctx.size()) ? g->ctx[rank] : nullptr; }
 const char* rthip_group_last_error(const rthip_group* g) { return g ? g->err.c_str() : "null group"; }
+const char* rthip_group_transport(const rthip_group* g) { return g ? g->transport.c_str() : "null group"; }
 
 int rthip_group_set_tracer(rthip_group* g, uint32_t max_bounces, int sky) {
     if (!g) return RTHIP_E_INVALID;
@@ -272,16 +429,19 @@ int rthip_group_cast_device(rthip_group* g, const rthip_cast_settings* cast, uin
     const uint32_t world = (uint32_t)g->ctx.size();
     rthip_ctx* c0 = g->ctx[0];
     const uint64_t floats = (uint64_t)width * height * 3;
-    // where every rank's share lands on the first device
+    const bool rccl = g->use_rccl;
+    // where every rank's share lands on the first device (RCCL sums the partial frames of sample mode itself: one frame)
     std::vector<size_t> offset(world + 1, 0);
     for (uint32_t k = 0; k < world; k++)
-        offset[k + 1] = offset[k] + (shard_mode == 1 ? (size_t)tiles_of_rank(width, height, k, world) * kTileFloats * 4 : (size_t)floats * 4);
+        offset[k + 1] = offset[k] + (shard_mode == 1 ? (size_t)tiles_of_rank(width, height, k, world) * kTileFloats * 4
+                                                     : ((rccl && k > 0) ? 0 : (size_t)floats * 4));
     RT_HIP(c0, hipSetDevice(c0->device));
     RT_TRY(rthip_reserve(c0, g->gather, offset[world] ? offset[world] : 256));
     {
         const int rc = for_each_device(g, [&](int k) -> int {
             rthip_ctx* c = g->ctx[k];
             RT_TRY(render_share(g, k, cast, seed, width, height, shard_mode));
+            if (rccl) return RTHIP_OK;  // the exchange is enqueued for all devices together below
             const size_t bytes = offset[k + 1] - offset[k];
             if (bytes) {
                 const void* src = shard_mode == 1 ? g->packed[k].p : g->frame[k].p;
@@ -291,6 +451,26 @@ int rthip_group_cast_device(rthip_group* g, const rthip_cast_settings* cast, uin
             return RTHIP_OK;
         });
         if (rc != RTHIP_OK) return rc;
+    }
+    if (rccl) {
+        // one grouped call over every device's communicator and stream, behind the renders already enqueued there
+        RT_RCCL(g, g->rccl.GroupStart());
+        for (uint32_t k = 0; k < world; k++) {
+            rthip_ctx* c = g->ctx[k];
+            if (shard_mode == 1) {
+                const size_t n = (offset[k + 1] - offset[k]) / 4;
+                if (!n) continue;
+                RT_RCCL(g, g->rccl.Send(g->packed[k].p, n, ncclFloat32, 0, g->comms[k], c->stream));
+                RT_RCCL(g, g->rccl.Recv((char*)g->gather.p + offset[k], n, ncclFloat32, (int)k, g->comms[0], c0->stream));
+            } else {
+                RT_RCCL(g, g->rccl.Reduce(g->frame[k].p, g->gather.p, floats, ncclFloat32, ncclSum, 0, g->comms[k], c->stream));
+            }
+        }
+        RT_RCCL(g, g->rccl.GroupEnd());
+        for (uint32_t k = 1; k < world; k++) {
+            RT_HIP(g->ctx[k], hipSetDevice(g->ctx[k]->device));
+            RT_HIP(g->ctx[k], hipStreamSynchronize(g->ctx[k]->stream));
+        }
     }
     RT_HIP(c0, hipSetDevice(c0->device));
     if (shard_mode == 1) {
@@ -303,11 +483,43 @@ int rthip_group_cast_device(rthip_group* g, const rthip_cast_settings* cast, uin
         }
     } else {
         const float scale = 1.f / ((float)cast->samples * (float)cast->samples);
-        parts_sum_kernel<<<(uint32_t)((floats + kBlock - 1) / kBlock), kBlock, 0, c0->stream>>>((const float*)g->gather.p, world, floats,
+        parts_sum_kernel<<<(uint32_t)((floats + kBlock - 1) / kBlock), kBlock, 0, c0->stream>>>((const float*)g->gather.p, rccl ? 1u : world, floats,
                                                                                                 world > 1 ? scale : 1.f, d_out_rgb);
         RT_HIP(c0, hipGetLastError());
     }
     RT_HIP(c0, hipStreamSynchronize(c0->stream));
+    return RTHIP_OK;
+}
+
+/* ---- the tile exchange's two kernels for callers that move the tiles themselves (one process per GPU over RCCL) ---- */
+
+uint32_t rthip_tiles_of_rank(int width, int height, uint32_t rank, uint32_t world) {
+    return (width > 0 && height > 0 && world > 0 && rank < world) ? tiles_of_rank(width, height, rank, world) : 0u;
+}
+
+int rthip_tiles_pack_device(rthip_ctx* ctx, const float* d_rgb, int width, int height, uint32_t rank, uint32_t world, float* d_packed,
+                            void* stream) {
+    if (!ctx) return RTHIP_E_INVALID;
+    if (!d_rgb || !d_packed || width <= 0 || height <= 0 || world == 0 || rank >= world)
+        return rthip_fail(ctx, RTHIP_E_INVALID, "rthip_tiles_pack_device: bad arguments");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    const uint32_t slots = tiles_of_rank(width, height, rank, world);
+    if (!slots) return RTHIP_OK;
+    tiles_pack_kernel<<<slots * (kTile * kTile / kBlock), kBlock, 0, (hipStream_t)stream>>>(d_rgb, width, height, rank, world, d_packed);
+    RT_HIP(ctx, hipGetLastError());
+    return RTHIP_OK;
+}
+
+int rthip_tiles_unpack_device(rthip_ctx* ctx, const float* d_packed, int width, int height, uint32_t rank, uint32_t world, float* d_rgb,
+                              void* stream) {
+    if (!ctx) return RTHIP_E_INVALID;
+    if (!d_rgb || !d_packed || width <= 0 || height <= 0 || world == 0 || rank >= world)
+        return rthip_fail(ctx, RTHIP_E_INVALID, "rthip_tiles_unpack_device: bad arguments");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    const uint32_t slots = tiles_of_rank(width, height, rank, world);
+    if (!slots) return RTHIP_OK;
+    tiles_unpack_kernel<<<slots * (kTile * kTile / kBlock), kBlock, 0, (hipStream_t)stream>>>(d_packed, width, height, rank, world, d_rgb);
+    RT_HIP(ctx, hipGetLastError());
     return RTHIP_OK;
 }
 

@@ -85,6 +85,7 @@ struct Hit {
 struct Counters {
     uint32_t nodes, tris, insts;
     uint32_t wave_steps;  // node steps issued by this lane's wave (counted on one lane per step)
+    uint32_t lane_steps;  // node steps this lane took part in: sum over lanes / (64 * wave_steps) = share of the lanes at work
 };
 
 // lbvh_aabb_query_ray, lbvh.c:127-149, with 1/d hoisted (the same correctly rounded
@@ -302,6 +303,7 @@ __device__ __forceinline__ Hit closest_hit_query(const DevScene& S, V3 wo, V3 wd
         if (COUNT) {
             const uint64_t walking = __ballot(1);
             if ((int)(threadIdx.x & 63) == __ffsll((long long)walking) - 1) cnt.wave_steps++;
+            cnt.lane_steps++;
         }
         if (trav_step<COUNT>(T, S, cnt)) break;
     }
@@ -320,6 +322,7 @@ __device__ __forceinline__ Hit closest_hit_query_batched(const DevScene& S, V3 w
     for (;;) {
         const uint64_t walking = __ballot(1);  // the lanes still in this loop
         if (COUNT && (int)(threadIdx.x & 63) == __ffsll((long long)walking) - 1) cnt.wave_steps++;
+        if (COUNT) cnt.lane_steps++;
         const uint64_t parked = __ballot(T.pend_id != 0);
         const bool enter_now = parked != 0 && ((uint32_t)__popcll(parked) >= batch || parked == walking);
         if (T.pend_id != 0) {
@@ -474,6 +477,13 @@ __device__ __forceinline__ bool trav_fast_step(TravFast& T, const DevScene& S, C
             return false;
         }
         const DevInstance* it = &S.inst[id - 1];
+        if (S.n_inst == 1u) {
+            // The TLAS is this one leaf and has no record, so no step has tested its box: the reference does
+            // (lbvh.c:151-156), and a ray that misses it is spared the change to model space.
+            const float4 ra = S.tlas[0], rb = S.tlas[1];
+            if (COUNT) cnt.nodes++;
+            if (!slab(make_float4(ra.x, ra.z, rb.x, 0.f), make_float4(ra.y, ra.w, rb.y, 0.f), T.o, T.inv, kEps, T.tmax)) return false;
+        }
         if (COUNT) cnt.insts++;
         if (it->type == RTHIP_INST_SPHERE) {
             const float4 cr = *(const float4*)it->sphere_center;
@@ -584,6 +594,7 @@ __device__ __forceinline__ Hit closest_hit_query_fast(const DevScene& S, V3 wo, 
         if (COUNT) {
             const uint64_t walking = __ballot(1);
             if ((int)(threadIdx.x & 63) == __ffsll((long long)walking) - 1) cnt.wave_steps++;
+            cnt.lane_steps++;
         }
         if (trav_fast_step<COUNT>(T, S, cnt, st)) break;
     }
@@ -602,6 +613,7 @@ __device__ __forceinline__ bool any_hit_query_fast(const DevScene& S, V3 wo, V3 
         if (COUNT) {
             const uint64_t walking = __ballot(1);
             if ((int)(threadIdx.x & 63) == __ffsll((long long)walking) - 1) cnt.wave_steps++;
+            cnt.lane_steps++;
         }
         if (trav_fast_step<COUNT>(T, S, cnt, st) || T.h.inst != 0) break;
     }
@@ -620,6 +632,7 @@ __device__ __forceinline__ bool any_hit_query(const DevScene& S, V3 wo, V3 wd, f
         if (COUNT) {
             const uint64_t walking = __ballot(1);
             if ((int)(threadIdx.x & 63) == __ffsll((long long)walking) - 1) cnt.wave_steps++;
+            cnt.lane_steps++;
         }
         if (trav_step<COUNT>(T, S, cnt) || T.h.inst != 0) break;
     }
@@ -877,9 +890,9 @@ __device__ __forceinline__ V3 path_fold(const DevScene& S, PathState& P, V3 L, c
 
 __device__ __forceinline__ void flush_counters(uint64_t* counters, const Counters& c, uint32_t rays) {
     // one atomic per wave and counter
-    uint32_t v[5] = {rays, c.nodes, c.tris, c.insts, c.wave_steps};
+    uint32_t v[6] = {rays, c.nodes, c.tris, c.insts, c.wave_steps, c.lane_steps};
 #pragma unroll
-    for (int k = 0; k < 5; k++) {
+    for (int k = 0; k < 6; k++) {
         uint32_t x = v[k];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);

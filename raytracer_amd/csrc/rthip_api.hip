@@ -1055,6 +1055,7 @@ int rthip_get_stats(rthip_ctx* ctx, rthip_stats* out) {
     out->tris_tested = c[2];
     out->inst_entered = c[3];
     out->wave_steps = c[4];
+    out->lane_steps = c[5];
     out->last_cast_ms = ctx->last_cast_ms;
     out->last_build_ms = ctx->last_build_ms;
     out->last_cast_kernel = ctx->last_cast_kernel;

@@ -233,6 +233,7 @@ __global__ __launch_bounds__(kBlock, FAST ? 4 : RT_PERSIST_WAVES) void cast_kern
             // else can step): the same work per lane, in fewer executions of the long branch.  It pays where
             // rays enter instances often (many small instances); elsewhere the plain step is faster.
             if (COUNT && (int)lane == __ffsll((long long)walking) - 1) cnt.wave_steps++;
+            if (COUNT && state == ST_TRAVERSE) cnt.lane_steps++;
             if constexpr (DEFER && !FAST) {
                 const uint64_t parked = __ballot(state == ST_TRAVERSE && Wk.T.pend_id != 0);
                 const bool enter_now =
@@ -606,6 +607,7 @@ __global__ __launch_bounds__(kBlock) void trace_rays_persistent_kernel(DevScene 
             if (COUNT) {
                 const uint64_t walking = __ballot(active);
                 if ((int)lane == __ffsll((long long)walking) - 1) cnt.wave_steps++;
+                if (active) cnt.lane_steps++;
             }
             if (active && Wk.template step<COUNT, false>(S, cnt)) {
                 write_ray_result(S, ray, Wk.T.h, Wk.T.wo, Wk.T.wd, hits4, uv, normal);

@@ -162,6 +162,7 @@ __global__ __launch_bounds__(kBlock) void wf_trace_kernel(DevScene S, WfArrays A
             continue;
         }
         if (COUNT && (int)lane == __ffsll((long long)walking) - 1) cnt.wave_steps++;
+        if (COUNT && active) cnt.lane_steps++;
         if (active) {
             if (trav_step<COUNT>(T, S, cnt)) {
                 A.hit[pid] = make_uint4(T.h.inst, T.h.tri, __float_as_uint(T.h.u), __float_as_uint(T.h.v));

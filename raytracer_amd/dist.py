@@ -28,13 +28,13 @@ def shard_record(mode: str, rank: int, world: int) -> np.ndarray:
     return sh
 
 
-def combine_framebuffer(fb, mode: str, samples: int, world: int, dst: int = 0):
+def combine_framebuffer(fb, mode: str, samples: int, world: int, dst: int = 0, tracer=None):
     """Sums the ranks' framebuffers onto `dst` (in place, one collective) and applies the mode's scale
     there.  `fb` is a torch tensor on the backend's device.  Returns fb (meaningful on dst only)."""
     import torch.distributed as dist
 
     if world > 1 and mode == "tiles" and fb.dim() == 3:
-        return gather_tiles(fb, fb.shape[1], fb.shape[0], world, dst)  # disjoint shares: moved, not added
+        return gather_tiles(fb, fb.shape[1], fb.shape[0], world, dst, tracer=tracer)  # disjoint shares: moved, not added
     if world > 1:
         dist.reduce(fb, dst=dst, op=dist.ReduceOp.SUM)
         if dist.get_rank() == dst:
@@ -68,16 +68,48 @@ def tile_pixels(width: int, height: int, rank: int, world: int, device="cpu"):
     return _tile_index_cache[key]
 
 
-def gather_tiles(fb, width: int, height: int, world: int, dst: int = 0):
+_TILE_FLOATS = _TILE * _TILE * 3
+
+
+def gather_tiles(fb, width: int, height: int, world: int, dst: int = 0, tracer=None):
     """Tile mode: every rank sends only the pixels of its own tiles (1/world of the frame) and `dst` places them; the
     frame on `dst` is then complete, bit-identical to a single-GPU render (the shares are disjoint, nothing is added).
-    `fb` is this rank's framebuffer [height, width, 3] on the backend's device.  One collective (gather)."""
+    `fb` is this rank's framebuffer [height, width, 3] on the backend's device.  One collective (gather).
+
+    With `tracer` (an RT_Tracer on fb's GPU) the tiles are packed and placed by the library's own kernels
+    (rthip_tiles_pack_device / rthip_tiles_unpack_device on the current stream: whole 64x64 tiles, 48 KiB each); without
+    one -- the CPU rehearsals over gloo -- by index tensors."""
     import torch
     import torch.distributed as dist
 
     if world == 1:
         return fb
     rank = dist.get_rank()
+    if tracer is not None and fb.is_cuda:
+        lib = tracer.lib
+        stream = torch.cuda.current_stream().cuda_stream
+        slots = [int(lib.rthip_tiles_of_rank(width, height, r, world)) for r in range(world)]
+        send = torch.empty(max(slots) * _TILE_FLOATS, dtype=fb.dtype, device=fb.device)
+        tracer.check(lib.rthip_tiles_pack_device(tracer.h, fb.data_ptr(), width, height, rank, world, send.data_ptr(), stream),
+                     "rthip_tiles_pack_device")
+        recv = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
+        if dist.get_backend() == "gloo":  # rehearsal: gloo moves host memory only
+            host = send.cpu()
+            hrecv = [torch.empty_like(host) for _ in range(world)] if rank == dst else None
+            dist.gather(host, hrecv, dst=dst)
+            if rank == dst:
+                for r in range(world):
+                    recv[r].copy_(hrecv[r])
+        else:
+            dist.gather(send, recv, dst=dst)
+        if rank == dst:
+            for r in range(world):
+                if r != rank and slots[r]:
+                    tracer.check(lib.rthip_tiles_unpack_device(tracer.h, recv[r].data_ptr(), width, height, r, world, fb.data_ptr(),
+                                                               stream), "rthip_tiles_unpack_device")
+            for t in recv:  # the unpack kernels read them on this stream after this function has returned
+                t.record_stream(torch.cuda.current_stream())
+        return fb
     flat = fb.view(-1, 3)
     counts = [int(tile_pixels(width, height, r, world, "cpu").numel()) for r in range(world)]
     longest = max(counts)
@@ -114,8 +146,9 @@ class FramePipeline:
     keeps enqueueing; on "gloo" it blocks, which is all a CPU rehearsal needs.
     """
 
-    def __init__(self, buffers, mode: str, samples: int, world: int, dst: int = 0):
+    def __init__(self, buffers, mode: str, samples: int, world: int, dst: int = 0, tracer=None):
         assert len(buffers) >= 1
+        self.tracer = tracer  # an RT_Tracer on the buffers' GPU: tile shares are packed / placed by the library's kernels
         self.buffers = list(buffers)
         self.pending = [None] * len(self.buffers)
         self.mode, self.samples, self.world, self.dst = mode, samples, world, dst
@@ -150,9 +183,9 @@ class FramePipeline:
     def submit(self, fb) -> None:
         k = self.next
         assert fb is self.buffers[k], "submit the buffer acquire() returned"
-        if self.world > 1 and self.mode == "tiles" and not (fb.is_cuda and self._gloo()):
+        if self.world > 1 and self.mode == "tiles" and (self.tracer is not None or not (fb.is_cuda and self._gloo())):
             # disjoint shares: one gather of 1/world of the frame per rank; stream-ordered on RCCL, blocking on gloo
-            gather_tiles(fb, fb.shape[1], fb.shape[0], self.world, self.dst)
+            gather_tiles(fb, fb.shape[1], fb.shape[0], self.world, self.dst, tracer=self.tracer)
             self.pending[k] = None
         elif self.world > 1:
             import torch.distributed as dist

@@ -344,6 +344,16 @@ class RT_TracerGroup:
         self.check(self.lib.rthip_group_cast(self.g, abi.ptr(cast), int(seed) & (2**64 - 1), abi.ptr(out_radiance), width, height,
                                              self.shard_mode), "rthip_group_cast")
 
+    def cast_device(self, settings: np.ndarray, d_out_ptr: int, width: int, height: int, seed: int = 0, shard: str = None) -> None:
+        """rthip_group_cast_device: the frame is left in memory of the group's first device (`d_out_ptr`, W*H*3 floats)."""
+        cast = np.ascontiguousarray(settings, dtype=abi.CAST).reshape(1)
+        mode = self.shard_mode if shard is None else {"tiles": 1, "samples": 2}[shard]
+        self.check(self.lib.rthip_group_cast_device(self.g, abi.ptr(cast), int(seed) & (2**64 - 1), C.c_void_p(d_out_ptr), width, height,
+                                                    mode), "rthip_group_cast_device")
+
+    def transport(self) -> str:
+        return self.lib.rthip_group_transport(self.g).decode()
+
     def close(self):
         if getattr(self, "g", None) is not None and self.g.value:
             self.lib.rthip_group_destroy(self.g)

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"librthip.so lacks {n}"
     assert sorted(n for n, _, _ in abi.SYMBOLS) == names, "abi.SYMBOLS and include/rthip.h disagree"
-    assert lib.rthip_abi_version() == 1
+    assert lib.rthip_abi_version() == 2
 
 
 def test_struct_layouts_match_the_header(tmp_path):

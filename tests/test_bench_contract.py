@@ -27,14 +27,35 @@ def check_common(d, steps, warmup):
     assert d["unit"] == "Mrays/s" and d["higher_is_better"] is True and d["vs_baseline"] is None
     assert d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms"):
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "kernel", "kernel_ms"):
         assert k in r, k
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert d["value"] > 0 and d["ms_per_step"] > 0
+    # the reported region is the median of `count` regions of exactly `steps` steps
+    g = d["regions"]
+    assert g["count"] >= 1 and g["ms_per_step_min"] <= d["ms_per_step"] <= g["ms_per_step_max"]
+    assert d["ms_per_step"] == g["ms_per_step_median"]
+    check_derived(r)
+    # a counter that was not recorded on these sources is not handed out, and nothing is derived from it
+    if r["traffic"] is None:
+        assert "hbm_measured_frac" not in r["ceilings"] and r["valu"] is None and r["traffic_source"]
+        assert r["bounding"].startswith("unknown") and r["frac_of_bounding"] is None
     # value = rays of all steps / time of the timed region
     rays = d["config"]["rays_per_frame_per_gpu"]
     assert abs(d["value"] - rays / (d["ms_per_step"] * 1e-3) / 1e6) < 0.02 * d["value"]
+
+
+def check_derived(r):
+    """Derived figures that must never contradict themselves: no share of the lanes above 1, no HBM fraction above 1."""
+    assert 0.0 < r["lane_utilisation"] <= 1.0, r["lane_utilisation"]
+    c = r["ceilings"]
+    assert c["hbm_algorithmic_frac"] is None or c["hbm_algorithmic_frac"] <= 1.0
+    if c["hbm_algorithmic_frac"] is None:
+        assert "cache-resident" in c["hbm_algorithmic_note"]
+    assert c.get("hbm_measured_frac", 0.0) <= 1.0
+    if "frac_overlapped" in r:
+        assert r["frac_overlapped"] is None or r["frac_overlapped"] <= 1.0
 
 
 def test_default_workload_line():
@@ -75,15 +96,51 @@ def test_default_run_carries_every_configuration():
         assert w[key]["value"] > 0
     assert w["bunny_one_stream"]["streams"] == 1 and w["soup_rays"]["rays_per_frame"] == 1 << 24
     assert w["soup_rays"]["per_ray"]["nodes"] > 100
+    for key, sub in w.items():
+        check_derived(sub)
+        assert sub["regions"]["count"] >= 1
+    # both walks enter an instance only behind its box: the same count on the same frame
+    assert w["bunny_fast"]["per_ray"]["instances"] == w["bunny_one_stream"]["per_ray"]["instances"]
+    assert "cornell_mesh_4k_1024spp" in w and w["cornell_mesh_4k_1024spp"]["value"] > 0
+
+
+def test_twenty_and_two_hundred_steps_agree():
+    """The driver runs a short region: the median over repeated regions must make its figure the long run's."""
+    a = run_bench("--steps", "20", "--warmup", "5", "--build-sizes", "", "--no-cpu-baseline", "--no-workloads")
+    b = run_bench("--steps", "200", "--warmup", "20", "--build-sizes", "", "--no-cpu-baseline", "--no-workloads")
+    assert a["regions"]["count"] > b["regions"]["count"] >= 1
+    assert abs(a["value"] - b["value"]) <= 0.05 * b["value"], (a["value"], b["value"], a["regions"], b["regions"])
 
 
 def test_two_ranks_start_themselves():
     """`python bench.py --gpus 2` without a launcher starts its own ranks (here both on the one GPU, gloo) and prints
     rank 0's line."""
     d = run_bench("--gpus", "2", "--backend", "gloo", "--steps", "3", "--warmup", "1", "--width", "256", "--height", "144",
-                  "--no-cpu-baseline", "--build-sizes", "")
+                  "--no-cpu-baseline", "--build-sizes", "", "--c5-samples", "4")
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and d["scaling"] == "weak"
+    # beside the weak-scaling headline: config 5's scene as ONE frame split by tiles and by samples (strong scaling)
+    for shard in ("tiles", "samples"):
+        sub = d["workloads"][f"cornell_mesh_4k_16spp_{shard}"]
+        assert sub["scaling"] == "strong" and sub["n_gpus"] == 2 and sub["value"] > 0 and "Cornell" in sub["workload"]
+    assert "gathered" in d["workloads"]["cornell_mesh_4k_16spp_tiles"]["sharding"]
     for shard in ("tiles", "samples"):  # one frame split over the ranks, a combined frame delivered per step
         d = run_bench("--gpus", "2", "--backend", "gloo", "--shard", shard, "--workload", "cornell", "--steps", "3", "--warmup", "1",
                       "--width", "192", "--height", "128", "--no-cpu-baseline", "--build-sizes", "")
         assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+
+
+def test_one_process_drives_the_group():
+    """`--multi group`: no launcher, no torch.distributed; here both contexts on the one GPU (peer-copy transport) and a
+    group of one device whose exchange is forced through RCCL."""
+    d = run_bench("--gpus", "2", "--multi", "group", "--group-devices", "0,0", "--steps", "3", "--warmup", "1", "--width", "256",
+                  "--height", "144", "--c5-samples", "4")
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and "peer" in d["config"]["transport"]
+    for shard in ("tiles", "samples"):
+        assert d["workloads"][f"cornell_mesh_4k_16spp_{shard}"]["value"] > 0
+    env = dict(os.environ, RTHIP_GROUP_TRANSPORT="rccl")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--multi", "group", "--workload", "cornell", "--shard",
+                        "samples", "--steps", "2", "--warmup", "1", "--width", "192", "--height", "128"], cwd=ROOT, capture_output=True,
+                       text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert "RCCL" in d["config"]["transport"] and d["value"] > 0

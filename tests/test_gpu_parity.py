@@ -879,10 +879,10 @@ def test_edge_case_rays(oracle, gpu_tracer):
     assert (bits(img) == bits(want)).all() and float(img.min()) > 0.3
 
 
-def test_full_size_frame_agrees_across_kernels_and_shards(gpu_tracer):
-    """The instanced benchmark workload at full size (10 000 instances, 1920x1080, 4 spp, 8 bounces): too big for the
-    CPU oracle, so the three renderer kernels (each bit-exact against the oracle at small sizes) must agree with
-    each other bit for bit, and three tile shards must add up to the frame."""
+def test_full_size_frame_agrees_across_kernels_and_shards(oracle, gpu_tracer):
+    """The instanced benchmark workload at full size (10 000 instances, 1920x1080, 4 spp, 8 bounces): the whole frame is
+    too big for the CPU oracle, so the three renderer kernels must agree with each other bit for bit, three tile shards
+    must add up to the frame, and four of its 64x64 tiles are compared with the oracle."""
     import torch
 
     verts, indices = scenes.bunny_class_mesh()
@@ -916,6 +916,68 @@ def test_full_size_frame_agrees_across_kernels_and_shards(gpu_tracer):
         assert torch.equal((total + 0.0).view(torch.int32), (frames["static"] + 0.0).view(torch.int32)), "tile shards"
     finally:
         T.set_cast_kernel(gpu_tracer, "auto")
+    # ... and the frame itself is pinned to the oracle tile by tile: the CPU renders single 64x64 tiles of the SAME
+    # full-size frame (a tile shard of as many ranks as there are tiles), one among the instances, one across the
+    # horizon, one of sky, one in the ragged bottom row
+    sc = oracle.Scene(world.flatten_world(w), 8, sky)
+    frame = frames["static"].cpu().numpy()
+    tiles_x, tiles_y = (wd + 63) // 64, (ht + 63) // 64
+    for name, tile in (("instances", (tiles_y * 2 // 3) * tiles_x + tiles_x // 2), ("horizon", (tiles_y // 2 - 1) * tiles_x + tiles_x // 3),
+                       ("sky", tiles_x + 3), ("ragged bottom row", (tiles_y - 1) * tiles_x + tiles_x - 1)):
+        assert_tile_matches_oracle(oracle, sc, c, 7, frame, tile, name)
+
+
+def assert_tile_matches_oracle(oracle, sc, cast, seed, frame, tile, name):
+    """One 64x64 tile of a full-size frame against the oracle's render of exactly that tile (bit for bit)."""
+    ht, wd = frame.shape[0], frame.shape[1]
+    tiles_x, tiles_y = (wd + 63) // 64, (ht + 63) // 64
+    want, cnt = sc.cast(cast, seed, wd, ht, rng_mode=oracle.RNG_COUNTER, shard=(1, tile, tiles_x * tiles_y), threads=16)
+    x0, y0 = (tile % tiles_x) * 64, (tile // tiles_x) * 64
+    got_tile, want_tile = frame[y0:y0 + 64, x0:x0 + 64], want[y0:y0 + 64, x0:x0 + 64]
+    assert got_tile.size > 0 and cnt["rays"] > 0, name
+    bad = int((bits(got_tile) != bits(want_tile)).any(axis=2).sum())
+    assert bad == 0, f"tile {tile} ({name}): {bad} of {got_tile.shape[0] * got_tile.shape[1]} pixels differ from the oracle"
+    return float(want_tile.mean())
+
+
+def test_config5_frame_is_pinned_to_the_oracle_tile_by_tile(oracle, gpu_tracer):
+    """BASELINE config 5's frame -- Cornell box + the full bunny-class mesh at 3840x2160, 8 bounces -- whole on the GPU
+    (64 spp), four of its 64x64 tiles against the oracle; and at the configuration's own 1024 spp one tile, rendered by
+    the GPU as the tile shard a rank of a large group would get."""
+    import torch
+
+    verts, indices = scenes.bunny_class_mesh()
+    w, cam, sky = scenes.cornell(extra_mesh=(verts, indices))
+    build(gpu_tracer, w, 8, sky)
+    sc = oracle.Scene(world.flatten_world(w), 8, sky)
+    wd, ht = 3840, 2160
+    tiles_x, tiles_y = (wd + 63) // 64, (ht + 63) // 64
+    stream = torch.cuda.current_stream().cuda_stream
+    c = cam(wd, ht, 8)
+    buf = torch.full((ht, wd, 3), -1.0, dtype=torch.float32, device="cuda:0")
+    gpu_tracer.check(gpu_tracer.lib.rthip_cast_device(gpu_tracer.h, abi.ptr(c), 3, buf.data_ptr(), wd, ht, None, stream), "rthip_cast_device")
+    torch.cuda.synchronize()
+    frame = buf.cpu().numpy()
+    assert float(frame.min()) >= 0.0
+    mid = (tiles_y // 2) * tiles_x + tiles_x // 2
+    lit = 0.0
+    for name, tile in (("centre: mesh and back wall", mid), ("mesh seen from outside, reflecting the opening", mid + tiles_x + 3), ("wall seam", (tiles_y - 8) * tiles_x + tiles_x // 2 + 4),
+                       ("light", (tiles_y // 2 - 9) * tiles_x + tiles_x // 2), ("outside the box", 5 * tiles_x + 3)):
+        lit += assert_tile_matches_oracle(oracle, sc, c, 3, frame, tile, name)
+    assert lit > 0.01  # the chosen tiles do see the scene
+    # 1024 spp: the tile alone, as a shard
+    c = cam(wd, ht, 32)
+    tile = (tiles_y - 8) * tiles_x + tiles_x // 2 + 4
+    sh = np.zeros(1, dtype=abi.SHARD)
+    sh[0] = (1, tile, tiles_x * tiles_y)
+    buf.fill_(-1.0)
+    gpu_tracer.check(gpu_tracer.lib.rthip_cast_device(gpu_tracer.h, abi.ptr(c), 1, buf.data_ptr(), wd, ht, abi.ptr(sh), stream), "rthip_cast_device")
+    torch.cuda.synchronize()
+    frame = buf.cpu().numpy()
+    assert_tile_matches_oracle(oracle, sc, c, 1, frame, tile, "wall seam at 1024 spp")
+    x0, y0 = (tile % tiles_x) * 64, (tile // tiles_x) * 64
+    frame[y0:y0 + 64, x0:x0 + 64] = 0.0
+    assert not frame.any(), "a tile shard leaves the other ranks' pixels at zero"
 
 
 def test_long_ray_stream(oracle, gpu_tracer):

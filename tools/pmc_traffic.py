@@ -59,8 +59,17 @@ def main(src: str, dst: str) -> None:
             if v:
                 v = [x for g, x in v if g == max(g for g, _ in v)]
                 out[workload][k]["valu_insts_per_launch"] = int(sum(v) / len(v))
+    # the revision the counters belong to: bench.py hands a counter out only while the kernel's sources still have these
+    # hashes (`git hash-object` of every file under raytracer_amd/csrc)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    import datetime
+
+    from bench import source_hashes
+
+    out["_recorded_on"] = {"sources": source_hashes(), "when": datetime.date.today().isoformat()}
     with open(dst, "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
+    del out["_recorded_on"]
     for workload in out:
         for k, r in sorted(out[workload].items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"]):
             print(f"{workload:10s} {k:28s} x{r['launches']:<3d} fetch {r['fetch_size_kib']:>12.1f} KiB  write {r['write_size_kib']:>12.1f} KiB"
