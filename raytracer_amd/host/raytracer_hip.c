@@ -7,6 +7,7 @@
 
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 internal RT_HIP_Tracer* rt_hip_handle_to_tracer(RT_Handle handle) {
     return (RT_HIP_Tracer*)handle.v64[0];
@@ -118,6 +119,18 @@ rt_hook RT_Handle rt_make_tracer(RT_TracerSettings settings) {
     AssertAlways(rc == RTHIP_OK);
     if (tracer->group) rt_hip_check(tracer, rthip_group_set_tracer(tracer->group, settings.max_bounces, settings.sky ? 1 : 0), "rthip_group_set_tracer");
     else rt_hip_check(tracer, rthip_set_tracer(tracer->ctx, settings.max_bounces, settings.sky ? 1 : 0), "rthip_set_tracer");
+    // RT_HIP_TRAVERSAL=fast: the opt-in ordered walk (rthip_set_traversal: 4-wide records, nearest box first).  The frame
+    // equals the default walk's except where the reference's own answer hangs on its visiting order (hits at exactly
+    // equal distance, rays along a seam between two triangles); anything else, or unset: the reference's fixed walk.
+    {
+        const char* trav = getenv("RT_HIP_TRAVERSAL");
+        if (trav && strcmp(trav, "fast") == 0) {
+            if (tracer->group) rt_hip_check(tracer, rthip_group_set_traversal(tracer->group, RTHIP_TRAV_FAST), "rthip_group_set_traversal");
+            else rt_hip_check(tracer, rthip_set_traversal(tracer->ctx, RTHIP_TRAV_FAST), "rthip_set_traversal");
+        } else if (trav && trav[0] && strcmp(trav, "exact") != 0) {
+            fprintf(stderr, "rthip: RT_HIP_TRAVERSAL=%s is neither \"exact\" nor \"fast\"; using the exact walk\n", trav);
+        }
+    }
     // lbvh_make normalises centroids by the boxes' bounds in a BUILD_DEBUG build and by the centroids' own in a
     // release build (lbvh.c:97-104): the trees differ, so the backend follows the flavour it is compiled into.
     #if BUILD_DEBUG

@@ -140,7 +140,7 @@ def test_one_process_drives_the_group():
     env = dict(os.environ, RTHIP_GROUP_TRANSPORT="rccl")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--multi", "group", "--workload", "cornell", "--shard",
                         "samples", "--steps", "2", "--warmup", "1", "--width", "192", "--height", "128"], cwd=ROOT, capture_output=True,
-                       text=True, timeout=600, env=env)
+                       text=True, timeout=240, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     assert "RCCL" in d["config"]["transport"] and d["value"] > 0
