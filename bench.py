@@ -4,8 +4,10 @@
     python bench.py [--gpus N --steps K --warmup W --workload bunny|instanced|soup|cornell]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One step = one frame of the workload rendered through rthip_cast_device with everything
-(BVHs, triangles, framebuffer) resident in HBM.  With N > 1 every rank renders the same frame
+One step = one frame of the workload on EACH of the `--streams` HIP streams (default 4: a batch of four frames in flight
+together), rendered through rthip_cast_accumulate_device with everything (BVHs, triangles, framebuffers) resident in HBM;
+`--streams 1` makes a step one frame.  The timed region of exactly `--steps` steps is repeated until about half a second
+of timed work has been done and the MEDIAN region is reported (`regions`).  With N > 1 every rank renders the same frame
 with its own sample set (seed + rank) and the framebuffers are summed onto rank 0 with RCCL
 (`torch.distributed.reduce`), i.e. N times the samples in the same wall time: weak scaling.  By
 default the image is accumulated progressively: every step of every rank renders its own sample set
@@ -429,6 +431,9 @@ def parse_args(argv=None):
                     help="N ranks only join the process group, add up their ranks and rank 0 prints one JSON line: a test of "
                          "the launch path that needs no GPU with --backend gloo")
     ap.add_argument("--build-sizes", default="81920,1000000,10000000")
+    ap.add_argument("--min-region-s", type=float, default=0.5,
+                    help="the timed region of --steps steps is repeated until this many seconds of timed work have been done and "
+                         "the median region is reported; 0 = one region (counter passes under rocprofv3)")
     ap.add_argument("--multi", default="ranks", choices=["ranks", "group"],
                     help="N > 1: 'ranks' = one process per GPU, torch.distributed over RCCL (what a launcher starts; the default); "
                          "'group' = ONE process drives all N GPUs through rthip_group_cast_device (one context and one host "
@@ -590,8 +595,10 @@ def measure(args, name, steps, warmup, n_streams_arg, rank, world, device_index,
                 torch.zeros(16, device="cuda").add_(1.0)
         torch.cuda.synchronize()
     streams = [main_stream] if n_streams == 1 else [torch.cuda.Stream() for _ in range(n_streams)]
-    accums = [torch.zeros((H, W, 3), dtype=torch.float32, device="cuda") for _ in streams] if combine == "end" else None
-    accum = accums[0] if accums else None
+    accum_all = torch.zeros((len(streams), H, W, 3), dtype=torch.float32, device="cuda") if combine == "end" else None
+    accums = [accum_all[k] for k in range(len(streams))] if combine == "end" else None
+    accum_sum = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda") if (combine == "end" and n_streams > 1) else None
+    accum = (accum_sum if n_streams > 1 else accums[0]) if accums else None
     step_no = [0]
     # --combine every: two framebuffers, the RCCL reduce of frame k overlaps the render of frame k + 1
     pipe = rdist.FramePipeline([torch.zeros((H, W, 3), dtype=torch.float32, device="cuda") for _ in range(2)],
@@ -606,7 +613,16 @@ def measure(args, name, steps, warmup, n_streams_arg, rank, world, device_index,
         ray_hits = [torch.zeros((wl["rays"], 4), dtype=torch.int32, device="cuda") for _ in streams]
     torch.cuda.synchronize()
 
+    # A step = one launch on EACH of the streams (a batch of `n_streams` frames in flight together; one frame with
+    # --streams 1): the pipeline's fill and drain -- about one frame's latency per timed region, whatever its length --
+    # then weigh the same few per cent at the driver's 20 steps as in a long run.
+    frames_per_step = n_streams
+
     def step(events=None):
+        for j in range(frames_per_step):
+            launch(events[j] if events else None)
+
+    def launch(events=None):
         k = step_no[0] % n_streams
         stream = streams[k]
         if ray_o is not None:
@@ -647,8 +663,8 @@ def measure(args, name, steps, warmup, n_streams_arg, rank, world, device_index,
             main_stream.wait_stream(s)
         if combine != "end" or ray_o is not None:
             return
-        for a in accums[1:]:
-            accum.add_(a)
+        if n_streams > 1:
+            torch.sum(accum_all, dim=0, out=accum_sum)  # one pass over the streams' accumulators
         if world > 1:
             if dist.get_backend() == "gloo":  # rehearsal: gloo has no GPU reduce
                 host = accum.cpu()
@@ -657,7 +673,7 @@ def measure(args, name, steps, warmup, n_streams_arg, rank, world, device_index,
             else:
                 dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
         if rank == 0:
-            accum.mul_(1.0 / float(n_steps * world))
+            accum.mul_(1.0 / float(n_steps * frames_per_step * world))
 
     # Traversal counters of this rank's frames: untimed launches with counting on, one per seed of the first timed steps
     # (at most 4; the steps of a progressive image differ only in their sample sets, so their ray counts differ by a
@@ -667,13 +683,13 @@ def measure(args, name, steps, warmup, n_streams_arg, rank, world, device_index,
     T.set_counting(tr, True)
     T.get_stats(tr)
     for _ in range(counted):
-        step()
+        launch()
     pipe.drain()
     torch.cuda.synchronize()
     st = T.get_stats(tr)
     T.set_counting(tr, False)
     step_no[0] = 0
-    st = {k: (v / counted if k in ("rays", "nodes_tested", "tris_tested", "inst_entered", "wave_steps") else v) for k, v in st.items()}
+    st = {k: (v / counted if k in ("rays", "nodes_tested", "tris_tested", "inst_entered", "wave_steps", "lane_steps") else v) for k, v in st.items()}
     rays = st["rays"]
     algo_bytes = 48 * st["rays"] + 32 * st["nodes_tested"] + 48 * st["tris_tested"] + 64 * st["inst_entered"]
 
@@ -694,16 +710,15 @@ def measure(args, name, steps, warmup, n_streams_arg, rank, world, device_index,
         """EXACTLY `steps` steps, bracketed by a barrier and a device synchronisation on both sides; the image's exchange
         (--combine end) lies inside.  Returns (seconds: MAX over ranks, mean launch duration in ms, host enqueue ms)."""
         if accums is not None:
-            for a in accums:
-                a.zero_()
+            accum_all.zero_()
         step_no[0] = 0
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps * frames_per_step)]
         t0 = time.perf_counter()
         for k in range(steps):
-            step(ev[k])
+            step(ev[k * frames_per_step:(k + 1) * frames_per_step])
         enqueue_ms = (time.perf_counter() - t0) * 1e3 / steps
         pipe.drain()
         finish_image(steps)
@@ -742,11 +757,12 @@ def measure(args, name, steps, warmup, n_streams_arg, rank, world, device_index,
             kernel_name = "trace_rays_persistent_kernel"
     line = None
     if rank == 0:
-        value = total_rays * steps / elapsed / 1e6
+        value = total_rays * steps * frames_per_step / elapsed / 1e6
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
         ms_per_step = elapsed / steps * 1e3
-        overlapped = algo_bytes * steps / elapsed / 1e9
-        bound = ceilings(algo_bytes, traffic, valu_insts, kernel_ms, ms_per_step, n_streams, counters_from)
+        ms_per_launch = ms_per_step / frames_per_step  # what one frame (or ray stream) costs with the others beside it
+        overlapped = algo_bytes * steps * frames_per_step / elapsed / 1e9
+        bound = ceilings(algo_bytes, traffic, valu_insts, kernel_ms, ms_per_launch, n_streams, counters_from)
         line = {
             "metric": "Mrays/sec (whole node); LBVH build ms per 1M triangles",
             "value": round(value, 2),
@@ -764,7 +780,10 @@ def measure(args, name, steps, warmup, n_streams_arg, rank, world, device_index,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
+            "ms_per_frame": round(ms_per_launch, 4),
             "config": {"workload": wl["label"], "rays_per_frame_per_gpu": int(round(rays)), "streams": n_streams,
+                       # a step = one launch on each stream: `frames_per_step` frames (ray streams) in flight together
+                       "frames_per_step": frames_per_step,
                        "rays_counted_over_seeds": counted,
                        "sharding": "none" if world == 1 else {
                            "frames": "every rank renders the frame with its own sample set; " + (
@@ -791,7 +810,7 @@ def measure(args, name, steps, warmup, n_streams_arg, rank, world, device_index,
                          # a fraction of the HBM peak only where that is a statement about HBM: never above 1
                          "frac_overlapped": round(overlapped / HBM_PEAK_GBS, 5) if overlapped <= HBM_PEAK_GBS else None,
                          "ceilings": bound, "bounding": bound["bounding"], "frac_of_bounding": bound["frac_of_bounding"],
-                         "valu": valu_issue(valu_insts, kernel_ms, ms_per_step, n_streams)},
+                         "valu": valu_issue(valu_insts, kernel_ms, ms_per_launch, n_streams)},
             "scene_build_ms": {"blas": round(blas_ms, 4), "blas_first_call": round(blas_first_ms, 4), "tlas": round(tlas_ms, 4), "tlas_rebuild_call": round(tlas_call_ms, 4),
                                "instances": int(flat.instances.size)},
         }
@@ -815,7 +834,7 @@ def measure(args, name, steps, warmup, n_streams_arg, rank, world, device_index,
                 threads = min(16, os.cpu_count() or 1)  # the box's CPU share for one GPU
                 line["cpu_port_all_cores"] = cpu_port_parallel(wl, cast, flat, threads)
     T.rt_tracer_cleanup(tr)
-    del accums, accum, pipe, ray_o, ray_d, ray_hits
+    del accums, accum, accum_all, accum_sum, pipe, ray_o, ray_d, ray_hits
     torch.cuda.empty_cache()
     return line
 
@@ -850,26 +869,27 @@ def host_cast_figure(tr, cast, W, H, rays, reps=8):
 
 
 # The other BASELINE configurations and views of the default one, each a short run of its own inside the default
-# `python bench.py` so that the driver's record holds them: (key, workload, streams, steps, warm-up)
+# `python bench.py` so that the driver's record holds them: (key, workload, streams, steps, warm-up, walk); a step is one
+# launch on each of the streams
 EXTRA_RUNS = [
     ("bunny_one_stream", "bunny", 1, 40, 5, "exact"),
-    ("instanced", "instanced", 4, 12, 2, "exact"),
+    ("instanced", "instanced", 4, 3, 1, "exact"),
     ("instanced_one_stream", "instanced", 1, 6, 1, "exact"),
-    ("soup", "soup", 4, 12, 2, "exact"),
+    ("soup", "soup", 4, 3, 1, "exact"),
     ("soup_rays", "soup-rays", 1, 3, 1, "exact"),
-    ("heightfield", "heightfield", 4, 12, 2, "exact"),
-    ("instanced_rays", "instanced-rays", 4, 8, 2, "exact"),
-    ("cornell", "cornell", 4, 40, 5, "exact"),
+    ("heightfield", "heightfield", 4, 3, 1, "exact"),
+    ("instanced_rays", "instanced-rays", 4, 2, 1, "exact"),
+    ("cornell", "cornell", 4, 10, 2, "exact"),
     ("cornell_mesh_4k", "cornell-mesh", 1, 4, 1, "exact"),
     # BASELINE config 5's frame itself (1024 spp: --c5-samples 32), one step: the N = 1 end of its strong-scaling curve
     ("cornell_mesh_4k_1024spp", "cornell-mesh", 1, 1, 0, "exact"),
     # the opt-in ordered walk (rthip_set_traversal(RTHIP_TRAV_FAST)) on the deep scenes
-    ("bunny_fast", "bunny", 4, 40, 5, "fast"),
-    ("instanced_fast", "instanced", 4, 12, 2, "fast"),
-    ("instanced_rays_fast", "instanced-rays", 4, 8, 2, "fast"),
-    ("soup_fast", "soup", 4, 12, 2, "fast"),
+    ("bunny_fast", "bunny", 4, 10, 2, "fast"),
+    ("instanced_fast", "instanced", 4, 3, 1, "fast"),
+    ("instanced_rays_fast", "instanced-rays", 4, 2, 1, "fast"),
+    ("soup_fast", "soup", 4, 3, 1, "fast"),
     ("soup_rays_fast", "soup-rays", 1, 3, 1, "fast"),
-    ("heightfield_fast", "heightfield", 4, 12, 2, "fast"),
+    ("heightfield_fast", "heightfield", 4, 3, 1, "fast"),
 ]
 
 
@@ -987,6 +1007,7 @@ def group_main(args):
 def compact(line):
     r = line["roofline"]
     out = {"workload": line["config"]["workload"], "value": line["value"], "unit": line["unit"], "ms_per_step": line["ms_per_step"],
+           "ms_per_frame": line["ms_per_frame"], "frames_per_step": line["config"]["frames_per_step"],
            "steps": line["steps"], "regions": line["regions"], "streams": line["config"]["streams"],
            "rays_per_frame": line["config"]["rays_per_frame_per_gpu"],
            "kernel": r["kernel"], "kernel_ms": r["kernel_ms"], "per_ray": r["per_ray"], "lane_utilisation": r["lane_utilisation"],
@@ -1029,7 +1050,8 @@ def main():
             dist.init_process_group(backend="gloo")
 
     want_cpu = not args.no_cpu_baseline and world == 1  # the CPU baseline is reported at N = 1 only
-    line = measure(args, args.workload, args.steps, args.warmup, args.streams, rank, world, device_index, want_cpu)
+    line = measure(args, args.workload, args.steps, args.warmup, args.streams, rank, world, device_index, want_cpu,
+                   min_region_s=args.min_region_s)
     default_run = (args.workload == "bunny" and world == 1 and not args.no_workloads and args.samples == 0 and args.width == 0
                    and args.traversal == "exact")
     if rank == 0 and default_run:
