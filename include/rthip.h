@@ -313,11 +313,20 @@ int rthip_lbvh_build(rthip_ctx* ctx, const float* aabb6, uint64_t n, uint64_t* o
 
 /* The same build with the boxes already in HBM and the tree left in HBM: what the
  * build benchmark times.  d_nodes must hold 2n-1 records.  Enqueues on `stream`
- * and returns without synchronising, with two exceptions: a build larger than any before it first grows the
- * context's workspace (see rthip_lbvh_reserve), and a build of more than 131 072 boxes waits for the stream once, half
- * way through its sort (it sorts by the upper half of the Morton codes, finishes locally, and reads back one word that
- * says whether that was enough; RTHIP_SORT_TOP_BYTES=8 in the environment, or a stream that is being captured, selects
- * the sort by all eight bytes, which only enqueues). */
+ * and returns without synchronising, with one exception: a build larger than any before it first grows the
+ * context's workspace (see rthip_lbvh_reserve).  Builds of more than 131 072 boxes sort by the upper half of the Morton
+ * codes and finish inside the stretches of keys that share it, all on the device; whether a stretch was long enough to
+ * need the slow finish travels to the host behind the build and makes the NEXT build of that many boxes sort by all
+ * eight bytes (RTHIP_SORT_TOP_BYTES=8 in the environment does so from the start).  A stream that is being captured
+ * records the same kernels.
+ * Hand-offs between workgroups: builds of more than 131 072 boxes finish the nodes that span chunks of leaves with a
+ * chain of device-wide hand-offs.  Their fast form (records and counters as device-scope atomics, ordered by waiting for
+ * the stores) is how gfx950 behaves, not something the HIP memory model promises, so a context uses it only after it has
+ * checked it on its own device: before its first such build it builds one tree of 400 000 boxes in both forms (a few
+ * milliseconds, once per context, the calling thread waits) and keeps the memory model's release / acquire form -- 8 %
+ * slower at 10^7 boxes -- on any difference, and for builds that cannot wait for the check (a first large build on a
+ * stream that is being captured).  RTHIP_REFIT_FENCE=0|1|2 in the environment chooses a form outright (0 release /
+ * acquire, 1 __threadfence, 2 the fast one). */
 int rthip_lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, rthip_node* d_nodes, void* stream);
 
 /* Grows the builder's workspace to what builds of up to n boxes (or triangles) need.  rthip_lbvh_build_device and

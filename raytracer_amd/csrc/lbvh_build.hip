@@ -792,7 +792,7 @@ __global__ __launch_bounds__(256) void tile_merge_kernel(const uint64_t* __restr
 // come before it: smaller low bits, or equal ones and an earlier position), in place: a stretch belongs to the
 // workgroup whose tile holds its first key, which reads all of it before anything is written; other workgroups look
 // only at its upper bits, which no write changes.  A longer stretch that is out of order (a dense object in a scene
-// thousands of times its size) is left alone and reported in *gave_up: the host then sorts by all eight bytes.
+// thousands of times its size) is left alone and reported in *gave_up: sort_long_kernel, launched next, finishes those.
 constexpr int kFixTile = 2048;  // positions per workgroup
 constexpr int kFixLong = 128;   // stretches up to this long are finished here; also the halo read on either side of the tile
 constexpr int kFixWin = kFixTile + 2 * kFixLong;
@@ -861,6 +861,136 @@ __global__ __launch_bounds__(256) void sort_fix_kernel(uint64_t* __restrict__ ke
             keys[to[j]] = ((uint64_t)top[k] << 32) | low[k];
             vals[to[j]] = val[j];
         }
+    }
+}
+
+// The long stretches sort_fix_kernel left alone, finished on the device as well, so that no build has to tell the host
+// how its sort went and wait for the answer.  Launched behind sort_fix_kernel in every build; when that kernel reported
+// nothing (nearly always) every workgroup leaves at its first instruction.  Otherwise each workgroup looks for the heads
+// of stretches in its share of the positions and sorts the long ones that are out of order by their lower four bytes,
+// stably: up to kLongLds keys by ranking in LDS, longer ones by four radix passes of its own through the sort's other
+// buffer (one workgroup per stretch: bounded, not fast -- a build of that many boxes goes by all eight passes from the
+// next time on, see lbvh_build_device).
+constexpr int kLongLds = 2048;
+
+__global__ __launch_bounds__(256) void sort_long_kernel(uint64_t* __restrict__ keys, uint32_t* __restrict__ vals, uint64_t* __restrict__ tmp_keys,
+                                                        uint32_t* __restrict__ tmp_vals, uint32_t n, const uint32_t* __restrict__ gave_up) {
+    if (*gave_up == 0u) return;
+    __shared__ uint32_t s_low[kLongLds], s_val[kLongLds];
+    __shared__ uint32_t hist[256], cnt[4][256];
+    __shared__ uint32_t heads[256];
+    __shared__ uint32_t n_heads, s_end, s_unordered;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    const uint32_t share = (n + gridDim.x - 1u) / gridDim.x;
+    const uint32_t first = blockIdx.x * share, last = first + share < n ? first + share : n;  // heads in [first, last) are this workgroup's
+    for (uint32_t p0 = first; p0 < last; p0 += 256u) {
+        if (tid == 0) n_heads = 0;
+        __syncthreads();
+        {
+            const uint32_t p = p0 + tid;
+            if (p < last) {
+                const uint32_t t = (uint32_t)(keys[p] >> 32);
+                const bool head = p == 0u || (uint32_t)(keys[p - 1u] >> 32) != t;
+                // sorted by the upper bytes: the stretch is longer than kFixLong exactly if the key kFixLong further on shares them
+                if (head && p + (uint32_t)kFixLong < n && (uint32_t)(keys[p + (uint32_t)kFixLong] >> 32) == t) heads[atomicAdd(&n_heads, 1u)] = p;
+            }
+        }
+        __syncthreads();
+        const uint32_t count = n_heads;
+        for (uint32_t e = 0; e < count; e++) {
+            const uint32_t h = heads[e];
+            const uint32_t t = (uint32_t)(keys[h] >> 32);
+            if (tid == 0) {  // the stretch's end: gallop, then bisect (the upper bytes are in order)
+                uint32_t lo = h + (uint32_t)kFixLong, step = (uint32_t)kFixLong;  // lo is inside the stretch
+                while (lo + step < n && (uint32_t)(keys[lo + step] >> 32) == t) {
+                    lo += step;
+                    if (step < (1u << 30)) step <<= 1;
+                }
+                uint32_t hi = lo + step < n ? lo + step : n;  // hi is outside (or n)
+                while (hi - lo > 1u) {
+                    const uint32_t mid = lo + (hi - lo) / 2u;
+                    if ((uint32_t)(keys[mid] >> 32) == t) lo = mid;
+                    else hi = mid;
+                }
+                s_end = hi;
+                s_unordered = 0;
+            }
+            __syncthreads();
+            const uint32_t len = s_end - h;
+            {
+                bool found = false;
+                for (uint32_t q = 1u + tid; q < len; q += 256u) found |= (uint32_t)keys[h + q - 1u] > (uint32_t)keys[h + q];
+                if (found) s_unordered = 1;
+            }
+            __syncthreads();
+            if (!s_unordered) continue;  // (uniform: read after the barrier, next written after the next one)
+            if (len <= (uint32_t)kLongLds) {
+                for (uint32_t q = tid; q < len; q += 256u) {
+                    s_low[q] = (uint32_t)keys[h + q];
+                    s_val[q] = vals[h + q];
+                }
+                __syncthreads();
+                for (uint32_t q = tid; q < len; q += 256u) {
+                    const uint32_t mine = s_low[q];
+                    uint32_t rank = 0;
+                    for (uint32_t r = 0; r < len; r++) rank += (s_low[r] < mine || (s_low[r] == mine && r < q)) ? 1u : 0u;
+                    keys[h + rank] = ((uint64_t)t << 32) | mine;
+                    vals[h + rank] = s_val[q];
+                }
+                __syncthreads();
+                continue;
+            }
+            // four stable counting passes over the lower bytes, there and back between the two buffers
+            for (int pass = 0; pass < 4; pass++) {
+                const uint64_t* src_k = (pass & 1) ? tmp_keys + h : keys + h;
+                const uint32_t* src_v = (pass & 1) ? tmp_vals + h : vals + h;
+                uint64_t* dst_k = (pass & 1) ? keys + h : tmp_keys + h;
+                uint32_t* dst_v = (pass & 1) ? vals + h : tmp_vals + h;
+                const int shift = 8 * pass;
+                hist[tid] = 0;
+                cnt[0][tid] = cnt[1][tid] = cnt[2][tid] = cnt[3][tid] = 0;
+                __syncthreads();
+                for (uint32_t q = tid; q < len; q += 256u) atomicAdd(&hist[(uint32_t)(src_k[q] >> shift) & 255u], 1u);
+                __syncthreads();
+                if (tid == 0) {  // hist becomes the first place of every digit
+                    uint32_t run = 0;
+                    for (int d = 0; d < 256; d++) {
+                        const uint32_t c = hist[d];
+                        hist[d] = run;
+                        run += c;
+                    }
+                }
+                __syncthreads();
+                for (uint32_t c0 = 0; c0 < len; c0 += 256u) {
+                    const uint32_t q = c0 + tid;
+                    const bool live = q < len;
+                    const uint64_t key = live ? src_k[q] : 0ull;
+                    const uint32_t val = live ? src_v[q] : 0u;
+                    const uint32_t d = (uint32_t)(key >> shift) & 255u;
+                    uint64_t same = __ballot(live);
+#pragma unroll
+                    for (int b = 0; b < 8; b++) {
+                        const uint64_t ones = __ballot(live && ((d >> b) & 1u));
+                        same &= ((d >> b) & 1u) ? ones : ~ones;
+                    }
+                    const uint32_t rank_in_wave = (uint32_t)__popcll(same & lt_mask);
+                    if (live && rank_in_wave == 0u) cnt[wave][d] = (uint32_t)__popcll(same);
+                    __syncthreads();
+                    if (live) {
+                        uint32_t to = hist[d] + rank_in_wave;
+                        for (uint32_t w = 0; w < wave; w++) to += cnt[w][d];
+                        dst_k[to] = key;
+                        dst_v[to] = val;
+                    }
+                    __syncthreads();
+                    hist[tid] += cnt[0][tid] + cnt[1][tid] + cnt[2][tid] + cnt[3][tid];
+                    cnt[0][tid] = cnt[1][tid] = cnt[2][tid] = cnt[3][tid] = 0;
+                    __syncthreads();
+                }
+            }
+        }
+        __syncthreads();  // heads[] is rewritten by the next round
     }
 }
 
@@ -1023,7 +1153,9 @@ __device__ __forceinline__ uint8_t gap_priority_of(const uint64_t* keys, uint64_
 // on the counter, and an acquire fence before the second child to arrive reads the sibling's record (the first reads
 // nothing).  Same trees bit for bit (tests run all three); its release writes the L2 back and its acquire invalidates
 // it at every level of a latency-bound chain (+8 % at 10^7 triangles).  MODE 1 (RTHIP_REFIT_FENCE=1, diagnostic):
-// plain accesses bracketed by __threadfence().
+// plain accesses bracketed by __threadfence().  Because MODE 2 leans on the chip and not on the model, a context takes
+// it only after it has checked it on the device it runs on (handoff_self_check: one tree built both ways before the
+// first build that needs the device-wide climb; any difference, or a build that cannot wait for the check, means MODE 0).
 constexpr int kChunk = 512;  // sorted leaves per workgroup, one per thread
 constexpr uint64_t kTopSortMin = 1ull << 17;  // builds of more boxes sort by the upper bytes first (lbvh_build_device)
 
@@ -2464,6 +2596,40 @@ size_t scan_tmp_elems(uint64_t n) {
     return total + 64;
 }
 
+// ---- the self-check of the fast hand-off (handoff_self_check) ------------------------------------------------------------
+// boxes of a scene that makes the upper climb deep and uneven: clusters of different densities plus a uniform rest
+__global__ __launch_bounds__(kBlock) void check_boxes_kernel(float* __restrict__ aabb6, uint32_t n) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    auto mix = [](uint32_t x) {
+        x ^= x >> 16; x *= 0x7feb352du;
+        x ^= x >> 15; x *= 0x846ca68bu;
+        x ^= x >> 16;
+        return x;
+    };
+    const uint32_t a = mix(3u * i + 1u), b = mix(3u * i + 2u), c = mix(3u * i + 3u);
+    float x = (float)(a >> 8) * (1.f / 16777216.f), y = (float)(b >> 8) * (1.f / 16777216.f), z = (float)(c >> 8) * (1.f / 16777216.f);
+    const uint32_t cluster = mix(i / 97u) & 15u;
+    if (cluster < 9u) {  // most boxes lie in small clusters: long runs of neighbouring codes, subtrees of very different heights
+        const uint32_t k = mix(i / 97u + 77u);
+        const float s = cluster < 3u ? 1e-4f : 1e-2f;
+        x = (float)(k & 1023u) * (1.f / 1024.f) + x * s;
+        y = (float)((k >> 10) & 1023u) * (1.f / 1024.f) + y * s;
+        z = (float)((k >> 20) & 1023u) * (1.f / 1024.f) + z * s;
+    }
+    float* o = aabb6 + 6 * (size_t)i;
+    o[0] = x - 1e-4f; o[1] = y - 1e-4f; o[2] = z - 1e-4f;
+    o[3] = x + 1e-4f; o[4] = y + 1e-4f; o[5] = z + 1e-4f;
+}
+
+__global__ __launch_bounds__(kBlock) void check_compare_kernel(const uint4* __restrict__ a, const uint4* __restrict__ b, uint64_t n16,
+                                                               uint32_t* __restrict__ differ) {
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n16) return;
+    const uint4 x = a[i], y = b[i];
+    if (x.x != y.x || x.y != y.y || x.z != y.z || x.w != y.w) atomicOr(differ, 1u);
+}
+
 }  // namespace
 
 // Keys per tile of the sort in tiles.  Measured, whole build of random boxes, tiles of 1024 / 2048 / 4096 keys: 3 000 boxes
@@ -2625,12 +2791,66 @@ int lbvh_reserve_workspace(rthip_ctx* ctx, uint64_t n, LbvhWorkspace* ws) {
     return RTHIP_OK;
 }
 
+// The default hand-off of the climb above the chunks (MODE 2 of climb_upper_kernel) is ordered by what gfx950 does, not by
+// what the HIP memory model promises.  Before a context uses it for the first time it builds one tree of 400 000 boxes
+// both ways, on its own stream and in a workspace of its own (about 90 MB, released again), and compares every record:
+// equal -> MODE 2 stays; different, or anything fails on the way -> the model's own release / acquire form from then on.
+// Once per context; the calling thread waits for it (a few milliseconds).
+static int handoff_self_check(rthip_ctx* ctx) {
+    ctx->refit_checked = true;  // whatever comes of it: not again (and the two builds below must not come back here)
+    constexpr uint32_t n = 400000;
+    const uint64_t node_bytes = (2ull * n - 1ull) * 32ull;
+    DevBuf boxes, nodes_a, nodes_b, flag;
+    LbvhWorkspace ws;
+    int rc = RTHIP_OK;
+    uint32_t differ = 1;
+    const auto run = [&]() -> int {
+        RT_TRY(rthip_reserve(ctx, boxes, (size_t)n * 24));
+        RT_TRY(rthip_reserve(ctx, nodes_a, node_bytes));
+        RT_TRY(rthip_reserve(ctx, nodes_b, node_bytes));
+        RT_TRY(rthip_reserve(ctx, flag, 256));
+        hipStream_t s = ctx->stream;
+        RT_HIP(ctx, hipMemsetAsync(flag.p, 0, 256, s));
+        check_boxes_kernel<<<div_up(n, kBlock), kBlock, 0, s>>>((float*)boxes.p, n);
+        RT_HIP(ctx, hipGetLastError());
+        ctx->refit_fence = 2;
+        RT_TRY(lbvh_build_device(ctx, (const float*)boxes.p, n, (float4*)nodes_a.p, s, nullptr, nullptr, nullptr, true, &ws));
+        ctx->refit_fence = 0;
+        RT_TRY(lbvh_build_device(ctx, (const float*)boxes.p, n, (float4*)nodes_b.p, s, nullptr, nullptr, nullptr, true, &ws));
+        check_compare_kernel<<<div_up(node_bytes / 16, kBlock), kBlock, 0, s>>>((const uint4*)nodes_a.p, (const uint4*)nodes_b.p, node_bytes / 16,
+                                                                                (uint32_t*)flag.p);
+        RT_HIP(ctx, hipGetLastError());
+        RT_HIP(ctx, hipMemcpyAsync(&differ, flag.p, 4, hipMemcpyDeviceToHost, s));
+        RT_HIP(ctx, hipStreamSynchronize(s));
+        return RTHIP_OK;
+    };
+    rc = run();
+    for (DevBuf* b : {&boxes, &nodes_a, &nodes_b, &flag, &ws.aabb, &ws.keys[0], &ws.keys[1], &ws.vals[0], &ws.vals[1], &ws.block_hist, &ws.scan_aux,
+                      &ws.prio, &ws.child, &ws.vis, &ws.flags, &ws.starters, &ws.lefts, &ws.bounds})
+        rthip_release(*b);
+    ctx->refit_fence = (rc == RTHIP_OK && differ == 0u) ? 2 : 0;
+    if (ctx->refit_fence == 0)
+        fprintf(stderr, "rthip: the fast hand-off of the LBVH builder did not pass its self-check on device %d (%s): release / acquire hand-offs from now on\n",
+                ctx->device, rc == RTHIP_OK ? "trees differ" : ctx->err.c_str());
+    else if (getenv("RTHIP_TUNE_LOG"))
+        fprintf(stderr, "rthip: hand-off self-check passed on device %d\n", ctx->device);
+    ctx->err.clear();
+    return RTHIP_OK;
+}
+
 int lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, float4* d_nodes, hipStream_t s,
                       uint64_t* d_codes_unsorted, uint64_t* d_keys_sorted, uint32_t* d_ids_sorted, bool paired,
                       LbvhWorkspace* ws) {
     if (n == 0) return rthip_fail(ctx, RTHIP_E_INVALID, "lbvh build needs at least one box");
     if (n > (1ull << 30)) return rthip_fail(ctx, RTHIP_E_LIMIT, "lbvh build is limited to 2^30 boxes (got %llu)",
                                             (unsigned long long)n);
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    if (s) (void)hipStreamIsCapturing(s, &capturing);
+    // The device-wide climb takes its fast hand-off only after this context has checked it on its device, before the
+    // first build that needs it; a build that cannot wait for the check (its stream is being captured) goes without.
+    if (ctx->refit_fence == 2 && !ctx->refit_checked && (n > kOneGroupUpper || ctx->upper_device_wide) && n > (uint64_t)kChunk &&
+        capturing == hipStreamCaptureStatusNone)
+        RT_TRY(handoff_self_check(ctx));
     LbvhWorkspace& w = ws ? *ws : ctx->ws;
     if (ws) ctx->bounds_of = nullptr;  // bounds left by a triangle pass are in the context's own workspace
     RT_TRY(lbvh_reserve_workspace(ctx, n, &w));
@@ -2691,10 +2911,17 @@ int lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, float4* 
     codes_of.aabb6 = d_aabb6;
     codes_of.bounds = bounds;
     codes_of.zero_word = A.start_count;
-    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
-    if (s) (void)hipStreamIsCapturing(s, &capturing);
-    const bool top_first = n > ctx->sort_merge_max && n > kTopSortMin && ctx->sort_top_bytes < 8 && ctx->sort_top_gave_up_n != n &&
-                           capturing == hipStreamCaptureStatusNone;
+    // what the previous build by the upper bytes reported, if it has arrived: a build of that many boxes whose long
+    // stretches had to be finished by sort_long_kernel goes by all eight passes from now on
+    // (not looked at while a stream is being captured: an event query is not allowed then)
+    if (ctx->sort_flag_pending && capturing == hipStreamCaptureStatusNone && hipEventQuery(ctx->sort_flag_ev) == hipSuccess) {
+        ctx->sort_flag_pending = false;
+        if (*ctx->sort_flag_host != 0u) {
+            ctx->sort_top_gave_up_n = ctx->sort_flag_n;
+            if (getenv("RTHIP_TUNE_LOG")) fprintf(stderr, "rthip sort: a long stretch of keys with equal upper bytes was out of order at %llu boxes: all eight passes from now on\n", (unsigned long long)ctx->sort_flag_n);
+        }
+    }
+    const bool top_first = n > ctx->sort_merge_max && n > kTopSortMin && ctx->sort_top_bytes < 8 && ctx->sort_top_gave_up_n != n;
     uint32_t* gave_up = (uint32_t*)w.bounds.p + kBoundSlots * kBoundStride;  // a word behind the bounds' copies
     if (!tiles_sort) {
         codes_of.zero_all = (uint32_t*)w.flags.p;  // n words, the list's length among them
@@ -2709,33 +2936,27 @@ int lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, float4* 
     if (d_codes_unsorted)
         RT_HIP(ctx, hipMemcpyAsync(d_codes_unsorted, keys[0], n * 8, hipMemcpyDeviceToDevice, s));
 
-    // Above kTopSortMin keys: passes over the upper four bytes, the rest finished inside the short stretches of keys that
-    // share them (sort_fix_kernel).  Whether that was enough is one word read back from the device, so the call waits for
-    // the stream at this point (not while the stream is being captured: then all eight passes run); if a long stretch
-    // was out of order the codes are made again and sorted by all eight bytes, and builds of this many boxes skip the
-    // attempt from then on.
+    // Above kTopSortMin keys: passes over the upper four bytes, the rest finished inside the stretches of keys that share
+    // them -- the short ones (nearly all) by sort_fix_kernel, long ones that are out of order by sort_long_kernel, which
+    // costs a launch and nothing else when there are none.  Nothing is read back in between: the build never waits for
+    // its stream, and a captured build takes the same kernels.  The flag travels to the host behind the build (not
+    // while capturing) and is looked at by the NEXT build.
     int cur = 0;
-    bool sorted = false;
-    if (top_first) {  // (the flag was cleared by morton_kernel)
+    if (top_first) {  // (the flag was cleared by the kernel that made the codes)
         RT_TRY(radix_sort_workspace_device(ctx, n, 8, s, &cur, &w, true, 8 - ctx->sort_top_bytes, sort_codes ? &codes_of : nullptr));
         sort_fix_kernel<<<div_up(n, kFixTile), 256, 0, s>>>(keys[cur], vals[cur], (uint32_t)n, gave_up);
         RT_HIP(ctx, hipGetLastError());
-        uint32_t h_gave_up = 0;
-        RT_HIP(ctx, hipMemcpyAsync(&h_gave_up, gave_up, 4, hipMemcpyDeviceToHost, s));
-        RT_HIP(ctx, hipStreamSynchronize(s));
-        sorted = h_gave_up == 0;
-        if (!sorted) {
-            ctx->sort_top_gave_up_n = n;
-            if (getenv("RTHIP_TUNE_LOG")) fprintf(stderr, "rthip sort: a long stretch of keys with equal upper bytes was out of order: all eight passes\n");
-            if (!sort_codes) {
-                morton_kernel<<<div_up(n, kBlock) < 4096u ? div_up(n, kBlock) : 4096u, kBlock, 0, s>>>(d_aabb6, n, bounds, keys[0], nullptr, (uint32_t*)w.flags.p);
-                RT_HIP(ctx, hipGetLastError());
-            }
-            codes_of.zero_word2 = nullptr;
-            cur = 0;
+        sort_long_kernel<<<256, 256, 0, s>>>(keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], (uint32_t)n, gave_up);
+        RT_HIP(ctx, hipGetLastError());
+        if (capturing == hipStreamCaptureStatusNone && ctx->sort_flag_host && !ctx->sort_flag_pending) {
+            RT_HIP(ctx, hipMemcpyAsync(ctx->sort_flag_host, gave_up, 4, hipMemcpyDeviceToHost, s));
+            RT_HIP(ctx, hipEventRecord(ctx->sort_flag_ev, s));
+            ctx->sort_flag_pending = true;
+            ctx->sort_flag_n = n;
         }
+    } else {
+        RT_TRY(radix_sort_workspace_device(ctx, n, 8, s, &cur, &w, true, 0, sort_codes ? &codes_of : nullptr));
     }
-    if (!sorted) RT_TRY(radix_sort_workspace_device(ctx, n, 8, s, &cur, &w, true, 0, sort_codes ? &codes_of : nullptr));
     if (d_keys_sorted) RT_HIP(ctx, hipMemcpyAsync(d_keys_sorted, keys[cur], n * 8, hipMemcpyDeviceToDevice, s));
     if (d_ids_sorted) RT_HIP(ctx, hipMemcpyAsync(d_ids_sorted, vals[cur], n * 4, hipMemcpyDeviceToDevice, s));
 
@@ -2772,7 +2993,8 @@ int lbvh_build_device(rthip_ctx* ctx, const float* d_aabb6, uint64_t n, float4* 
         RT_HIP(ctx, hipGetLastError());
         return RTHIP_OK;
     }
-    const int mode = (n <= kOneGroupUpper && !ctx->upper_device_wide) ? 3 : (int)ctx->refit_fence;
+    int mode = (n <= kOneGroupUpper && !ctx->upper_device_wide) ? 3 : (int)ctx->refit_fence;
+    if (mode == 2 && !ctx->refit_checked) mode = 0;  // unchecked (this build could not wait for the check): the memory model's own form
 #define RT_UPPER(MODE, GRID, BLOCK)                                               \
     if (paired) climb_upper_kernel<MODE, true><<<GRID, BLOCK, 0, s>>>(A);         \
     else climb_upper_kernel<MODE, false><<<GRID, BLOCK, 0, s>>>(A)

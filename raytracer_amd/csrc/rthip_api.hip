@@ -175,6 +175,7 @@ int rthip_create(rthip_ctx** out_ctx, int device_id) {
     ctx->device = device_id;
     const char* fence = getenv("RTHIP_REFIT_FENCE");
     ctx->refit_fence = (fence && fence[0] >= '0' && fence[0] <= '2') ? fence[0] - '0' : 2;
+    ctx->refit_checked = fence && fence[0] >= '0' && fence[0] <= '2';  // an explicit choice is taken as it is
     const char* by_passes = getenv("RTHIP_SORT_BY_PASSES");
     ctx->sort_by_passes = (by_passes && by_passes[0] == '1') ? 1 : 0;
     const char* top_bytes = getenv("RTHIP_SORT_TOP_BYTES");
@@ -223,6 +224,16 @@ int rthip_create(rthip_ctx** out_ctx, int device_id) {
     // the address of the static build workspace on this device (used by rthip_lbvh_build_device_noalloc); a failure
     // here is reported by that entry point, which tries again
     (void)lbvh_static_workspace_init(ctx);
+    // where large builds leave word of how their sort went (read by the next build; lbvh_build_device): without it
+    // builds still work, they only never learn to skip the attempt
+    if (hipHostMalloc((void**)&ctx->sort_flag_host, 64, hipHostMallocDefault) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->sort_flag_ev, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        if (ctx->sort_flag_host) (void)hipHostFree(ctx->sort_flag_host);
+        ctx->sort_flag_host = nullptr;
+    } else {
+        *ctx->sort_flag_host = 0;
+    }
     ctx->err.clear();
     *out_ctx = ctx;
     return RTHIP_OK;
@@ -261,6 +272,8 @@ void rthip_destroy(rthip_ctx* ctx) {
         if (e) (void)hipEventDestroy(e);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->sort_flag_ev) (void)hipEventDestroy(ctx->sort_flag_ev);
+    if (ctx->sort_flag_host) (void)hipHostFree(ctx->sort_flag_host);
     rthip_release(ctx->tune_counters);
     rthip_release(ctx->tune_frame);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);

@@ -147,14 +147,19 @@ struct rthip_ctx {
     int sky = 1;
     int counting = 0;
     int sort_top_bytes = 4;     // large LBVH builds sort by this many upper key bytes and finish locally; 8: all passes (RTHIP_SORT_TOP_BYTES)
-    uint64_t sort_top_gave_up_n = 0;  // a build of this many boxes needed all eight passes after all: not tried again
+    uint64_t sort_top_gave_up_n = 0;  // a build of this many boxes had long stretches left after the upper bytes: all eight passes from then on
+    uint32_t* sort_flag_host = nullptr;  // page-locked word: the flag of the last build by the upper bytes, copied behind the build
+    hipEvent_t sort_flag_ev = nullptr;   // ... and the event behind that copy
+    bool sort_flag_pending = false;
+    uint64_t sort_flag_n = 0;            // the number of boxes of the build the pending flag belongs to
     int sort_by_passes = 0;     // RTHIP_SORT_BY_PASSES=1: small sorts also go pass by pass through HBM (diagnostic)
     uint32_t sort_merge_tile = 0;           // keys per tile of the sort-in-LDS-then-merge path: 1024, 2048 or 4096; 0: by size (RTHIP_SORT_MERGE_TILE)
     uint64_t sort_merge_max = 1ull << 17;   // sorts of up to this many keys take that path, at most 128 tiles (RTHIP_SORT_MERGE_MAX)
     uint64_t sort_small_tile_max = 1ull << 18;  // sorts of up to this many keys use 1024-key tiles (RTHIP_SORT_SMALL_TILE_MAX)
     int upper_ranges = 2;       // builds of up to 2^17 leaves take their inner nodes from leaf ranges: 2 all of them, 1 only those above the chunks (generations of hand-offs inside), 0 hand-offs throughout (RTHIP_UPPER_RANGES)
     int upper_device_wide = 0;  // RTHIP_UPPER_DEVICE_WIDE=1: never run the upper climbs in one workgroup (diagnostic)
-    int refit_fence = 2;  // hand-offs of the upper hierarchy kernels: 0 release / acquire through the counter, 1 __threadfence(), 2 relaxed + s_waitcnt (default)
+    int refit_fence = 2;  // hand-offs of the upper hierarchy kernels: 0 release / acquire through the counter, 1 __threadfence(), 2 relaxed + s_waitcnt (default, once checked)
+    bool refit_checked = false;  // mode 2 has passed handoff_self_check on this context's device (or RTHIP_REFIT_FENCE chose the mode)
 
     struct Pinned { void* p; size_t bytes; };
     std::vector<Pinned> pinned;    // page-locked host memory handed out by rthip_host_alloc

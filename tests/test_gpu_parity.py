@@ -146,6 +146,31 @@ def test_hierarchy_hand_off_modes_build_the_same_tree(oracle):
             os.environ["RTHIP_REFIT_FENCE"] = old
 
 
+def test_fast_hand_off_is_taken_only_after_its_self_check(capfd):
+    """A context checks the fast form of the device-wide hand-off on its device before its first build that needs it
+    (one tree of 400 000 boxes built both ways), once; smaller builds never ask for it."""
+    saved = {k: os.environ.pop(k, None) for k in ("RTHIP_REFIT_FENCE",)}
+    os.environ["RTHIP_TUNE_LOG"] = "1"
+    t = T.rt_make_tracer(T.RT_TracerSettings(max_bounces=1, sky=True), device_id=0)
+    try:
+        rng = np.random.default_rng(5)
+        small = rng.random((50_000, 3)).astype(np.float32)
+        capfd.readouterr()
+        T.lbvh_build(t, np.concatenate([small, small + 1e-3], axis=1), want_codes=False)
+        assert "self-check" not in capfd.readouterr().err
+        big = rng.random((200_000, 3)).astype(np.float32)
+        a = T.lbvh_build(t, np.concatenate([big, big + 1e-3], axis=1), want_codes=False)[3]
+        assert "hand-off self-check passed" in capfd.readouterr().err
+        b = T.lbvh_build(t, np.concatenate([big, big + 1e-3], axis=1), want_codes=False)[3]
+        assert "self-check" not in capfd.readouterr().err and a.tobytes() == b.tobytes()
+    finally:
+        T.rt_tracer_cleanup(t)
+        os.environ.pop("RTHIP_TUNE_LOG", None)
+        for k, v in saved.items():
+            if v is not None:
+                os.environ[k] = v
+
+
 @pytest.mark.parametrize("n", [513, 1023, 1024, 1025, 2048, 2049, 4097, 16_384, 16_385, 65_537, 131_072, 131_073, 262_144, 262_145])
 def test_lbvh_sizes_at_the_seams_of_the_builder(oracle, n):
     """Sizes just below, at and above the points where the builder changes its path: one workgroup (512), tiles of the
@@ -182,39 +207,42 @@ def test_lbvh_sizes_at_the_seams_of_the_builder(oracle, n):
                 os.environ[k] = v
 
 
-@pytest.mark.parametrize("case", ["uniform", "clusters", "dense_cloud", "identical", "stretch_128", "stretch_129"])
+@pytest.mark.parametrize("case", ["uniform", "clusters", "dense_cloud", "identical", "stretch_128", "stretch_129", "stretch_2048",
+                                  "stretch_2049"])
 def test_lbvh_sort_by_upper_bytes(oracle, capfd, case):
     """Builds of more than 131 072 boxes sort by the upper four key bytes and finish the sort inside the stretches of keys
-    that share them (up to 128 keys); a longer stretch that is out of order makes the build sort by all eight bytes
-    after all (it says so with RTHIP_TUNE_LOG).  Every case against the oracle: uniform boxes (stretches are rare
-    pairs), clusters of 60 boxes within 1e-5 (every stretch needs work, many straddle the finishing kernel's tiles), a
-    cloud of 300 000 boxes inside 1e-4 of the scene (one long stretch, out of order: all eight passes), 300 000
-    identical boxes (one long stretch, in order: nothing to do), and stretches of exactly 128 and 129 keys in
-    descending order."""
+    that share them, on the device: up to 128 keys by the finishing kernel, longer stretches that are out of order by a
+    kernel of their own (up to 2048 keys by ranking in LDS, beyond that by four counting passes of one workgroup).  No
+    build waits for an answer; word of a long stretch reaches the host behind the build and the NEXT build of that many
+    boxes sorts by all eight bytes (it says so with RTHIP_TUNE_LOG).  Every case against the oracle: uniform boxes
+    (stretches are rare pairs), clusters of 60 boxes within 1e-5 (every stretch needs work, many straddle the finishing
+    kernel's tiles), a cloud of 300 000 boxes inside 1e-4 of the scene (one long stretch, out of order), 300 000
+    identical boxes (one long stretch, in order: nothing to do), and stretches of exactly 128, 129, 2048 and 2049 keys
+    in descending order."""
     n = 300_000
     rng = np.random.default_rng(11)
     cen = rng.random((n, 3)).astype(np.float32)
-    falls_back = False
+    long_stretch = False
     if case == "clusters":
         centres = rng.random((5000, 3)).astype(np.float32)
         cen = centres[rng.integers(0, 5000, n)] + (rng.random((n, 3)).astype(np.float32) - 0.5) * 1e-5
     elif case == "dense_cloud":
         cen = 0.5 + (rng.random((n, 3)).astype(np.float32) - 0.5) * 1e-4
-        falls_back = True
+        long_stretch = True
     elif case == "identical":
         cen[:] = 0.375
-    elif case in ("stretch_128", "stretch_129"):
+    elif case.startswith("stretch_"):
         # y = z = 0.25: a key's upper 31 bits hold the upper 10 bits of x, so the keys of one 2^-10 wide cell of x form a
         # stretch; the cells' keys are handed over with descending x, i.e. every stretch is in reverse order
-        length = 128 if case == "stretch_128" else 129
-        cells = 700
+        length = int(case.split("_")[1])
+        cells = min(700, 200_000 // length)
         j = np.arange(length, dtype=np.float64)[::-1]
-        xs = (np.arange(cells, dtype=np.float64)[:, None] + 17) / 1024.0 + (j[None, :] + 1) * 2.0 ** -20
+        xs = (np.arange(cells, dtype=np.float64)[:, None] + 17) / 1024.0 + (j[None, :] + 1) * 2.0 ** -22
         m = cells * length
         cen[:m, 0] = xs.reshape(-1).astype(np.float32)
         cen[:m, 1:] = 0.25
         cen[m:, 0] = 0.9 + 0.1 * cen[m:, 0]  # the rest lies beyond the cells
-        falls_back = case == "stretch_129"
+        long_stretch = length > 128
     cen[-2], cen[-1] = (0.0, 0.0, 0.0), (1.0, 1.0, 1.0)  # fix the bounds
     half = np.full((n, 3), 1e-6, dtype=np.float32)
     boxes = np.concatenate([cen - half, cen + half], axis=1).astype(np.float32)
@@ -224,10 +252,12 @@ def test_lbvh_sort_by_upper_bytes(oracle, capfd, case):
     t = T.rt_make_tracer(T.RT_TracerSettings(max_bounces=1, sky=True), device_id=0)
     try:
         capfd.readouterr()
-        assert_same_tree(T.lbvh_build(t, boxes, want_codes=False)[3], want, case)
-        said = "all eight passes" in capfd.readouterr().err
-        assert said == falls_back, f"{case}: fell back {said}, expected {falls_back}"
-        assert_same_tree(T.lbvh_build(t, boxes)[3], want, case + ", second build")  # after a fallback: no second attempt
+        assert_same_tree(T.lbvh_build(t, boxes, want_codes=False)[3], want, case)  # finished on the device, whatever it took
+        assert "all eight passes" not in capfd.readouterr().err
+        assert_same_tree(T.lbvh_build(t, boxes)[3], want, case + ", second build")
+        said = "all eight passes" in capfd.readouterr().err  # the first build's word has arrived by now
+        assert said == long_stretch, f"{case}: second build went by all eight passes: {said}, expected {long_stretch}"
+        assert_same_tree(T.lbvh_build(t, boxes, want_codes=False)[3], want, case + ", third build")
         assert "all eight passes" not in capfd.readouterr().err
     finally:
         T.rt_tracer_cleanup(t)
@@ -292,9 +322,10 @@ def test_lbvh_tile_sort_by_upper_bytes(oracle, case):
 
 
 def test_large_build_can_be_captured_in_a_hip_graph(gpu_tracer):
-    """A build of more than 131 072 boxes reads one word back from the device half way through its sort, which a stream
-    capture does not allow: on a stream that is being captured it sorts by all eight key bytes instead and only
-    enqueues.  The captured build, replayed on other boxes, gives the tree of the build outside the capture."""
+    """A build of more than 131 072 boxes only enqueues kernels (its sort by the upper key bytes is finished on the device,
+    long stretches included), so it can be captured as it is.  The captured build, replayed on other boxes -- with short
+    stretches, equal keys, and one stretch of 5 000 keys in reverse order -- gives the tree of the build outside the
+    capture."""
     import torch
 
     lib, h = gpu_tracer.lib, gpu_tracer.h
@@ -306,6 +337,9 @@ def test_large_build_can_be_captured_in_a_hip_graph(gpu_tracer):
         g.manual_seed(seed)
         cen = torch.rand((n, 3), device="cuda", generator=g)
         cen[: n // 2] = torch.floor(cen[: n // 2] * 300) / 300  # stretches of keys with equal upper bytes, equal keys among them
+        if seed == 2:  # a long stretch, out of order: 5 000 centres inside one 2^-10 cell of x, descending
+            cen[-5000:, 0] = 0.5 + 2.0 ** -11 - torch.arange(5000, device="cuda") * 2.0 ** -24
+            cen[-5000:, 1:] = 0.25
         return torch.cat([cen - 0.001, cen + 0.001], dim=1).contiguous()
 
     buf = boxes(1)
