@@ -748,7 +748,9 @@ def measure(args, name, steps, warmup, n_streams_arg, rank, world, device_index,
                    2: "wf_trace_kernel + wf_shade_kernel (wavefront)"}[last["last_cast_kernel"]]
     if ray_o is not None:
         kernel_name = "trace_rays_kernel"
-    table_key = name + ("+fast" if traversal == "fast" else "")
+    # (the recorded passes ran the workloads at their own samples per pixel and frame size: nothing is quoted for others)
+    table_key = name + ("+fast" if traversal == "fast" else "") + (f"@samples={args.samples}" if args.samples > 0 else "") + \
+        (f"@{args.width}x{args.height}" if args.width > 0 and args.height > 0 else "")
     traffic, valu_insts, counters_from = recorded_counters(table_key, kernel_name)
     if ray_o is not None and traffic is None:  # deep scenes: the library takes the ray stream's persistent kernel
         t2, v2, from2 = recorded_counters(table_key, "trace_rays_persistent_kernel")
