@@ -10,14 +10,13 @@
 //
 // The writer's greedy loop cuts a component into maximal runs of >= 3 equal bytes and the stretches between them, and
 // both kinds are cut into packets from their own start.  That is a function of each byte's neighbourhood and of two
-// running positions (start of the current run, start of the current stretch), so a wave codes a component 64 bytes
-// at a time: one ballot of "equal to the next byte" per block, shifted and combined with the masks of the
-// neighbouring blocks, tells every byte whether it lies in a run; further ballots give the two start positions and
-// the output offset of every byte (a byte emits 0, 1 or 2 bytes), and the last byte of each packet writes the
-// packet's length.
+// running positions (start of the current run, start of the current stretch), so a wave codes a component 256 bytes
+// at a time, four consecutive bytes per lane: "equal to the next byte" of a lane's bytes and of its neighbours' tells
+// every byte whether it lies in a run; ballots and shuffles give the two start positions and the output offset of every
+// byte (a byte emits 0, 1 or 2 bytes), and the last byte of each packet writes the packet's length.
 //
 // Three launches: hdr_rows_kernel (one workgroup per scanline: RGBE conversion into LDS planes, then one wave per
-// component codes its plane into a staging slot and records the length), hdr_offsets_kernel (scan of the lengths,
+// component codes its plane, 256 bytes a step, into a staging slot and records the length), hdr_offsets_kernel (scan of the lengths,
 // header, total size), hdr_gather_kernel (staging slots -> their place in the file).
 
 #include "rthip_internal.h"
@@ -66,9 +65,19 @@ __global__ __launch_bounds__(kBlock) void hdr_flat_kernel(const float* __restric
     out[4 * i + 3] = (uint8_t)(v >> 24);
 }
 
-// One workgroup per scanline y.  planes (LDS): 4 x width bytes.  Wave c codes component c into
-// stage + (4 y + c) * stage_pitch and stores the coded length in lengths[4 y + c].
-__global__ __launch_bounds__(kBlock) void hdr_rows_kernel(const float* __restrict__ rgb, int width,
+// One workgroup per scanline y.  planes (LDS): 4 planes of `pitch` bytes (room for a component or its coding, a multiple of
+// four so that a lane reads its four bytes as one word).  Wave c codes component c into stage + (4 y + c) * stage_pitch and stores
+// the coded length in lengths[4 y + c].
+//
+// A wave codes 256 bytes per step, lane l the four consecutive bytes 4 l .. 4 l + 3 of the block.  What a byte needs to
+// know of its neighbourhood -- equal to the next byte (e), first of three equal bytes (tri), inside a run of >= 3 (run) --
+// is four bits per lane, made from the lane's own word and the next lane's (one shuffle down; the last lane takes the
+// first bytes of the next block) and handed to the next lane (two shuffles up; the first lane takes what the previous
+// block's last lane left).  The start of the run / literal stretch a byte belongs to is the last head at or before it: the
+// heads inside the lane are scanned in the lane, the one that reaches in from outside comes from the nearest earlier
+// lane that has a head (one ballot and one shuffle per kind), or from the previous blocks.  A lane emits 0 to 8 bytes;
+// their offsets are prefix sums over four ballots (one per bit of the lane's count).
+__global__ __launch_bounds__(kBlock) void hdr_rows_kernel(const float* __restrict__ rgb, int width, int pitch,
                                                           uint8_t* __restrict__ stage, uint64_t stage_pitch,
                                                           uint32_t* __restrict__ lengths) {
     extern __shared__ uint8_t planes[];
@@ -77,79 +86,131 @@ __global__ __launch_bounds__(kBlock) void hdr_rows_kernel(const float* __restric
     for (int x = threadIdx.x; x < width; x += kBlock) {
         const uint32_t v = rgbe_of(row[3 * x], row[3 * x + 1], row[3 * x + 2]);
         planes[x] = (uint8_t)v;
-        planes[width + x] = (uint8_t)(v >> 8);
-        planes[2 * width + x] = (uint8_t)(v >> 16);
-        planes[3 * width + x] = (uint8_t)(v >> 24);
+        planes[pitch + x] = (uint8_t)(v >> 8);
+        planes[2 * pitch + x] = (uint8_t)(v >> 16);
+        planes[3 * pitch + x] = (uint8_t)(v >> 24);
     }
     __syncthreads();
+#ifdef RT_HDR_PHASE1_ONLY  // dev build: how long the conversion alone takes
+    if (threadIdx.x < 4) lengths[4 * y + threadIdx.x] = planes[threadIdx.x * pitch];
+    return;
+#endif
 
     const int lane = threadIdx.x & 63;
     const uint32_t c = threadIdx.x >> 6;
-    const uint8_t* b = planes + (size_t)c * width;
-    uint8_t* o = stage + (size_t)(4 * y + c) * stage_pitch;
-    const uint64_t le_mask = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);  // lanes <= this one
+    const uint32_t* b = (const uint32_t*)(planes + (size_t)c * pitch);  // word k holds bytes 4 k .. 4 k + 3
+    // The coded bytes go back into the component's own plane (scattered byte stores cost far less in LDS than in global
+    // memory) and from there to the staging slot as whole words.  Coding byte i writes no further than byte
+    // i + i / 128 + 2 of the plane, and a step holds its own 256 bytes and the next step's in registers before it
+    // stores, so nothing is overwritten before it has been read; the pitch leaves room for the growth.
+    uint8_t* o = planes + (size_t)c * pitch;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     uint32_t total = 0;      // bytes coded so far
-    int run_start = 0;       // where the run of equal bytes that reaches into this block began
-    int stretch_start = 0;   // where the current stretch of literal bytes began
-    // Lane masks of the previous block (wave-uniform): eq bit l = byte l equals byte l + 1, tri bit l = bytes l, l + 1,
-    // l + 2 exist and are equal, run bit l = byte l lies in a run of >= 3.
-    uint64_t eq_prev = 0, tri_prev = 0, run_prev = 0;
-    uint32_t cur = lane < width ? b[lane] : 0u, next = 0;
-    for (int base = 0; base < width; base += 64) {
-        const int i = base + lane;
-        next = (i + 64 < width) ? b[i + 64] : 0u;
-        const bool valid = i < width;
-        // the first three bytes of the next block decide the last lanes' flags
-        const uint32_t n0 = __shfl(next, 0), n1 = __shfl(next, 1), n2 = __shfl(next, 2);
-        const uint32_t down = __shfl_down(cur, 1);
-        const uint32_t p1 = lane == 63 ? n0 : down;
-        const bool same_as_next = i + 1 < width && cur == p1;
-        const uint64_t eq = __ballot(same_as_next);
-        const uint64_t eq_n0 = (base + 65 < width && n0 == n1) ? 1ull : 0ull;  // eq of the next block's lanes 0, 1
-        const uint64_t eq_n1 = (base + 66 < width && n1 == n2) ? 1ull : 0ull;
-        const uint64_t tri = eq & ((eq >> 1) | (eq_n0 << 63));
-        const uint64_t tri_n0 = eq_n0 & eq_n1;
-        const uint64_t run = tri | (tri << 1) | (tri_prev >> 63) | (tri << 2) | (tri_prev >> 62);
-        const uint64_t run_n0 = tri_n0 | (tri >> 63) | ((tri >> 62) & 1ull);
-        const uint64_t before_in_run = (run << 1) | (run_prev >> 63);  // bit l: byte l - 1 lies in a run
-        const uint64_t after_in_run = (run >> 1) | (run_n0 << 63);     // bit l: byte l + 1 lies in a run
-        const uint64_t same_as_before = (eq << 1) | (eq_prev >> 63);
-        const uint64_t valid_mask = __ballot(valid);
-        const uint64_t rh = run & ~same_as_before;  // first byte of a run
-        const uint64_t sh = valid_mask & ~run & (before_in_run | (base == 0 ? 1ull : 0ull));  // first literal byte of a stretch
-        const bool in_run = (run >> lane) & 1ull;
-        // start of the run / stretch this byte belongs to: the last start at or before it
-        const uint64_t rh_le = rh & le_mask, sh_le = sh & le_mask;
-        const int my_run_start = rh_le ? base + 63 - __clzll((long long)rh_le) : run_start;
-        const int my_stretch_start = sh_le ? base + 63 - __clzll((long long)sh_le) : stretch_start;
-        if (rh) run_start = base + 63 - __clzll((long long)rh);
-        if (sh) stretch_start = base + 63 - __clzll((long long)sh);
-        // bytes this byte emits: a packet's first byte emits the length byte as well
-        const int k = in_run ? i - my_run_start : i - my_stretch_start;
-        const int in_packet = in_run ? k % 127 : k % 128;
-        const uint32_t emits = !valid ? 0u : (in_run ? (in_packet == 0 ? 2u : 0u) : (in_packet == 0 ? 2u : 1u));
-        const uint64_t e1 = __ballot(emits >= 1u), e2 = __ballot(emits == 2u);
-        const uint32_t off = total + (uint32_t)__popcll(e1 & lt_mask) + (uint32_t)__popcll(e2 & lt_mask);
-        total += (uint32_t)__popcll(e1) + (uint32_t)__popcll(e2);
-        if (in_run) {
-            const bool last = in_packet == 126 || !same_as_next;
-            if (last) {  // bytes after the packet's first emit nothing, so they all see the offset behind it
-                const uint32_t at = in_packet == 0 ? off : off - 2u;
-                o[at] = (uint8_t)(128 + in_packet + 1);
-                o[at + 1] = (uint8_t)cur;
-            }
-        } else if (valid) {
-            o[in_packet == 0 ? off + 1u : off] = (uint8_t)cur;
-            const bool last = in_packet == 127 || i + 1 >= width || ((after_in_run >> lane) & 1ull);
-            if (last) o[in_packet == 0 ? off : off - (uint32_t)in_packet - 1u] = (uint8_t)(in_packet + 1);
+    int run_start = 0;       // where the last run of equal bytes that began in an earlier block began
+    int stretch_start = 0;   // where the last stretch of literal bytes that began in an earlier block began
+    uint32_t carry = 0;      // the previous block's last lane: e | tri << 4 | run << 8 of its four bytes
+    uint32_t w = 4 * lane < width ? b[lane] : 0u, w_next = 0;
+    for (int base = 0; base < width; base += 256) {
+        const int i0 = base + 4 * lane;
+        w_next = (i0 + 256 < width) ? b[(i0 + 256) >> 2] : 0u;
+        // bytes 0..3 are the lane's own, 4..6 the next lane's first three (the next block's for the last lane)
+        const uint32_t from_next = __shfl_down(w, 1);
+        const uint32_t first_of_next_block = __shfl(w_next, 0);
+        const uint32_t nx = lane == 63 ? first_of_next_block : from_next;
+        uint32_t by[7];
+#pragma unroll
+        for (int j = 0; j < 4; j++) by[j] = (w >> (8 * j)) & 0xffu;
+#pragma unroll
+        for (int j = 0; j < 3; j++) by[4 + j] = (nx >> (8 * j)) & 0xffu;
+        uint32_t e = 0;  // bit j: bytes i0 + j and i0 + j + 1 both exist and are equal (j = 0 .. 5)
+#pragma unroll
+        for (int j = 0; j < 6; j++) e |= (i0 + j + 1 < width && by[j] == by[j + 1]) ? (1u << j) : 0u;
+        const uint32_t tri = e & (e >> 1);  // bit j: bytes j, j + 1, j + 2 are equal (j = 0 .. 4)
+        // what the previous lane knows of its own bytes: e and tri now, run once this lane's run bits are made
+        const uint32_t mine1 = (e & 15u) | ((tri & 15u) << 4);
+        uint32_t prev1 = __shfl_up(mine1, 1);
+        if (lane == 0) prev1 = carry & 0xffu;
+        const uint32_t e_before = (prev1 >> 3) & 1u;                   // byte i0 - 1 equals byte i0
+        const uint32_t tri_m1 = (prev1 >> 7) & 1u, tri_m2 = (prev1 >> 6) & 1u;  // tri of bytes i0 - 1 and i0 - 2
+        // run bit j: byte j lies in a run of >= 3 (it is the first, second or third of three equal bytes), j = 0 .. 4
+        const uint32_t tri_ext = (tri << 2) | (tri_m1 << 1) | tri_m2;  // bit j + 2: tri of byte j
+        const uint32_t run = (tri_ext >> 2 | tri_ext >> 1 | tri_ext) & 31u;
+        uint32_t prev_run = __shfl_up(run, 1);
+        if (lane == 0) prev_run = carry >> 8;
+        const uint32_t run_before = (prev_run >> 3) & 1u;  // byte i0 - 1 lies in a run
+        uint32_t valid = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) valid |= (i0 + j < width) ? (1u << j) : 0u;
+        const uint32_t same_as_before = ((e << 1) | e_before) & 15u;
+        const uint32_t in_run_before = ((run << 1) | run_before) & 15u;
+        const uint32_t rh = run & ~same_as_before & 15u;  // first byte of a run
+        const uint32_t sh = valid & ~run & (in_run_before | (i0 == 0 ? 1u : 0u)) & 15u;  // first literal byte of a stretch
+        // the heads that reach in from outside the lane: the last one in an earlier lane of this block, else the carried one
+        const uint64_t rh_lanes = __ballot(rh != 0u), sh_lanes = __ballot(sh != 0u);
+        const int my_last_rh = i0 + 31 - __clz(rh ? (int)rh : 1);  // the lane's last head (only read from lanes that have one)
+        const int my_last_sh = i0 + 31 - __clz(sh ? (int)sh : 1);
+        const uint64_t rh_before = rh_lanes & lt_mask, sh_before = sh_lanes & lt_mask;
+        const int rh_src = rh_before ? 63 - __clzll((long long)rh_before) : 0;
+        const int sh_src = sh_before ? 63 - __clzll((long long)sh_before) : 0;
+        const int rh_in = __shfl(my_last_rh, rh_src), sh_in = __shfl(my_last_sh, sh_src);
+        int rs = rh_before ? rh_in : run_start, ss = sh_before ? sh_in : stretch_start;
+        if (rh_lanes) run_start = __shfl(my_last_rh, 63 - __clzll((long long)rh_lanes));
+        if (sh_lanes) stretch_start = __shfl(my_last_sh, 63 - __clzll((long long)sh_lanes));
+        // per byte: place in its packet, bytes emitted
+        int in_packet[4];
+        uint32_t emits[4], lane_sum = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if ((rh >> j) & 1u) rs = i0 + j;
+            if ((sh >> j) & 1u) ss = i0 + j;
+            const bool in_run = (run >> j) & 1u;
+            const uint32_t k = (uint32_t)(i0 + j - (in_run ? rs : ss));  // < 32768: rows of that width are not run-length coded
+            // k mod 127 without a division, both forms computed and one selected (no branch): floor(k / 127) =
+            // k * 33027 >> 22 for k < 33554 (33027 = ceil(2^22 / 127)), with 24-bit multiplies
+            const uint32_t mod127 = k - __umul24(__umul24(k, 33027u) >> 22, 127u);
+            const uint32_t p = in_run ? mod127 : (k & 127u);
+            in_packet[j] = (int)p;
+            const uint32_t ok = (valid >> j) & 1u;
+            emits[j] = ok * ((p == 0u ? 2u : 0u) | ((p != 0u && !in_run) ? 1u : 0u));
+            lane_sum += emits[j];
         }
-        eq_prev = eq;
-        tri_prev = tri;
-        run_prev = run;
-        cur = next;
+        uint32_t off = total;
+#pragma unroll
+        for (int bit = 0; bit < 4; bit++) {
+            const uint64_t m = __ballot((lane_sum >> bit) & 1u);
+            off += (uint32_t)__popcll(m & lt_mask) << bit;
+            total += (uint32_t)__popcll(m) << bit;
+        }
+        // Every byte stores at most twice -- its own value, and, where it ends a packet, the packet's length byte -- at
+        // places and under conditions computed without branches.  In a run only the packet's last byte stores (count at
+        // `at`, value behind it): the bytes after a packet's first emit nothing, so they all see the offset behind it.
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const bool ok = (valid >> j) & 1u;
+            const int i = i0 + j;
+            const bool in_run = (run >> j) & 1u;
+            const bool same_as_next = (e >> j) & 1u;
+            const uint32_t p = (uint32_t)in_packet[j];
+            const bool first = p == 0u;
+            const bool last_run = p == 126u || !same_as_next;
+            const bool last_lit = p == 127u || i + 1 >= width || ((run >> (j + 1)) & 1u);
+            const uint32_t at = first ? off : off - 2u;                 // a run packet's first byte
+            const uint32_t lit_at = first ? off + 1u : off;             // a literal byte's place
+            const uint32_t lit_head = first ? off : off - p - 1u;       // its packet's length byte
+            const bool value_en = ok && (in_run ? last_run : true);
+            const bool count_en = ok && (in_run ? last_run : last_lit);
+            const uint32_t value_at = in_run ? at + 1u : lit_at, count_at = in_run ? at : lit_head;
+            const uint32_t count = in_run ? 129u + p : p + 1u;
+            if (value_en) o[value_at] = (uint8_t)by[j];
+            if (count_en) o[count_at] = (uint8_t)count;
+            off += emits[j];
+        }
+        carry = __shfl((int)(mine1 | ((run & 15u) << 8)), 63);
+        w = w_next;
     }
     if (lane == 0) lengths[4 * y + c] = total;
+    uint32_t* slot = (uint32_t*)(stage + (size_t)(4 * y + c) * stage_pitch);
+    for (uint32_t k = lane; 4u * k < total; k += 64u) slot[k] = b[k];  // (the slot and the plane both end on a whole word)
 }
 
 // Exclusive scan of the 4 * height coded lengths (one workgroup, 1024 entries per round) into file offsets: component
@@ -186,6 +247,9 @@ __global__ __launch_bounds__(1024) void hdr_offsets_kernel(const uint32_t* __res
 }
 
 // One workgroup per component stream: staging slot -> file position; component 0 also writes the scanline marker.
+// The file position is any byte address, the staging slot is 16-byte aligned: the bytes up to the first aligned word of
+// the destination and behind the last one go one by one, the words between as words, each put together from the two
+// aligned source words it straddles.
 __global__ __launch_bounds__(kBlock) void hdr_gather_kernel(const uint8_t* __restrict__ stage, uint64_t stage_pitch,
                                                             const uint32_t* __restrict__ lengths,
                                                             const uint64_t* __restrict__ offsets, int width,
@@ -198,7 +262,20 @@ __global__ __launch_bounds__(kBlock) void hdr_gather_kernel(const uint8_t* __res
         const uint8_t marker[4] = {2, 2, (uint8_t)((width & 0xff00) >> 8), (uint8_t)(width & 0xff)};
         dst[(int)threadIdx.x - 4] = marker[threadIdx.x];
     }
-    for (uint32_t i = threadIdx.x; i < len; i += kBlock) dst[i] = src[i];
+    const uint32_t head = (4u - (uint32_t)((uintptr_t)dst & 3u)) & 3u;  // bytes in front of the first aligned word
+    const uint32_t lead = head < len ? head : len;
+    const uint32_t words = (len - lead) / 4u;
+    if (threadIdx.x < lead) dst[threadIdx.x] = src[threadIdx.x];
+    const uint32_t* src_w = (const uint32_t*)src;
+    uint32_t* dst_w = (uint32_t*)(dst + lead);
+    const uint32_t shift = 8u * (lead & 3u);  // source byte lead + 4 k lies `lead` bytes into source word k + lead / 4
+    for (uint32_t k = threadIdx.x; k < words; k += kBlock) {
+        const uint32_t lo = src_w[k + lead / 4u];
+        const uint32_t hi = shift ? src_w[k + lead / 4u + 1u] : 0u;  // (within the slot: its pitch leaves room behind every coded length)
+        dst_w[k] = shift ? (lo >> shift) | (hi << (32u - shift)) : lo;
+    }
+    const uint32_t done = lead + 4u * words;
+    if (threadIdx.x < len - done) dst[done + threadIdx.x] = src[done + threadIdx.x];
 }
 
 }  // namespace
@@ -234,12 +311,13 @@ int hdr_encode_device(rthip_ctx* ctx, const float* d_rgb, int width, int height,
         RT_HIP(ctx, hipGetLastError());
         return RTHIP_OK;
     }
-    const uint64_t stage_pitch = ((uint64_t)width + ((uint64_t)width + 127) / 128 + 15) & ~15ull;
+    const uint64_t stage_pitch = ((uint64_t)width + ((uint64_t)width + 127) / 128 + 31) & ~15ull;  // the longest coding, a word of slack behind it (hdr_gather_kernel reads whole words), 16-byte aligned
     RT_TRY(rthip_reserve(ctx, ctx->hdr_stage, (size_t)n_streams * stage_pitch));
-    const size_t lds = 4 * (size_t)width;
+    const int pitch = (width + (width + 127) / 128 + 2 + 3) & ~3;  // a component, or its coding (hdr_rows_kernel codes in place)
+    const size_t lds = 4 * (size_t)pitch;
     if (lds > 64 * 1024)
         RT_HIP(ctx, hipFuncSetAttribute((const void*)hdr_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hdr_rows_kernel<<<(uint32_t)height, kBlock, lds, stream>>>(d_rgb, width, (uint8_t*)ctx->hdr_stage.p, stage_pitch,
+    hdr_rows_kernel<<<(uint32_t)height, kBlock, lds, stream>>>(d_rgb, width, pitch, (uint8_t*)ctx->hdr_stage.p, stage_pitch,
                                                               (uint32_t*)ctx->hdr_lengths.p);
     hdr_offsets_kernel<<<1, 1024, 0, stream>>>((const uint32_t*)ctx->hdr_lengths.p, n_streams, head, 0,
                                                (uint64_t*)ctx->hdr_offsets.p, d_out, d_size);

@@ -1797,12 +1797,13 @@ def test_hdr_encode_matches_reference_bytes(gpu_tracer):
         assert got == g[name + "_hdr"].tobytes(), name
 
 
-@pytest.mark.parametrize("w,h", [(8, 1), (63, 3), (64, 3), (65, 3), (127, 2), (128, 2), (129, 2), (191, 5), (192, 5),
-                                 (1000, 11), (4097, 3), (16384, 2), (32767, 2), (32768, 2), (5, 7)])
+@pytest.mark.parametrize("w,h", [(8, 1), (9, 2), (10, 2), (11, 2), (63, 3), (64, 3), (65, 3), (127, 2), (128, 2), (129, 2), (191, 5),
+                                 (192, 5), (253, 3), (254, 3), (255, 3), (256, 3), (257, 3), (258, 3), (259, 3), (511, 2), (512, 2),
+                                 (513, 2), (767, 2), (770, 2), (1000, 11), (4097, 3), (16384, 2), (32767, 2), (32768, 2), (5, 7)])
 def test_hdr_encode_shapes(oracle, gpu_tracer, w, h):
     rng = np.random.default_rng(w * 131 + h)
     img = (rng.random((h, w, 3), dtype=np.float32) * np.float32(3.0)).astype(np.float32)
-    # runs that start and end at every offset relative to the 64-byte blocks a wave codes
+    # runs that start and end at every offset relative to the 256-byte blocks a wave codes and the 4 bytes of a lane
     x = 0
     while x < w:
         run = int(rng.integers(1, 200))
@@ -1810,6 +1811,25 @@ def test_hdr_encode_shapes(oracle, gpu_tracer, w, h):
             img[h // 2, x:x + run] = img[h // 2, x]
         x += run
     img[0, :, 2] = 0.25
+    assert T.hdr_encode(gpu_tracer, img, w, h) == oracle.hdr_encode(img)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_hdr_encode_short_runs_at_every_alignment(oracle, gpu_tracer, seed):
+    """Images of a few grey levels in runs of 1 to 6 pixels (and, in other rows, of up to 400): runs of two (literal),
+    three and four equal bytes begin and end at every position of a lane's four bytes and across the 256-byte blocks,
+    and the 127 / 128-byte packet limits fall everywhere."""
+    rng = np.random.default_rng(100 + seed)
+    w, h = (int(rng.integers(8, 1500)), 24)
+    img = np.zeros((h, w, 3), dtype=np.float32)
+    levels = np.array([0.1, 0.2, 0.4, 0.8, 1.6, 0.0], dtype=np.float32)
+    for y in range(h):
+        longest = 6 if y % 3 else 400
+        x = 0
+        while x < w:
+            run = int(rng.integers(1, longest + 1))
+            img[y, x:x + run] = levels[rng.integers(0, len(levels), 3)] if y % 2 else levels[rng.integers(0, len(levels))]
+            x += run
     assert T.hdr_encode(gpu_tracer, img, w, h) == oracle.hdr_encode(img)
 
 
