@@ -143,7 +143,60 @@ __global__ __launch_bounds__(kBlock) void hdr_rows_kernel(const float* __restric
         for (int j = 0; j < 4; j++) valid |= (i0 + j < width) ? (1u << j) : 0u;
         const uint32_t same_as_before = ((e << 1) | e_before) & 15u;
         const uint32_t in_run_before = ((run << 1) | run_before) & 15u;
-        const uint32_t rh = run & ~same_as_before & 15u;  // first byte of a run
+        const uint32_t rh_bits = run & ~same_as_before & 15u;
+        // Two kinds of block make up most of an image and need far less than the general case below (same bytes out, by
+        // the same rules): a block without a run in or next to it -- every byte a literal of the stretch that is under
+        // way -- and a block that lies wholly inside one run that began earlier.  Both tests are wave-uniform.
+        if (__ballot(run != 0u || run_before != 0u) == 0ull) {
+            const uint32_t p0 = (uint32_t)(i0 - stretch_start) & 127u;  // place of the lane's first byte in its packet
+            const uint32_t head_j = (128u - p0) & 127u;                  // which of the lane's bytes opens a packet (>= 4: none)
+            const bool has_head = head_j < 4u && ((valid >> head_j) & 1u);
+            const uint64_t heads = __ballot(has_head);
+            uint32_t off = total + 4u * (uint32_t)lane + (uint32_t)__popcll(heads & lt_mask);  // (lanes in front of a valid byte are full)
+            const uint32_t in_block = (uint32_t)(width - base < 256 ? width - base : 256);
+            total += in_block + (uint32_t)__popcll(heads);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const bool ok = (valid >> j) & 1u;
+                const uint32_t p = (p0 + (uint32_t)j) & 127u;
+                const bool first = p == 0u;
+                const bool last = p == 127u || i0 + j + 1 >= width;
+                if (ok) o[first ? off + 1u : off] = (uint8_t)by[j];
+                if (ok && last) o[first ? off : off - p - 1u] = (uint8_t)(p + 1u);
+                off += ok ? (first ? 2u : 1u) : 0u;
+            }
+            carry = (uint32_t)__shfl((int)mine1, 63);  // (its run bits are zero)
+            w = w_next;
+            continue;
+        }
+        if (__ballot((valid & ~run) != 0u || rh_bits != 0u) == 0ull) {
+            // every byte of the block continues the run that began at run_start: only packet ends store anything
+            const uint32_t k0 = (uint32_t)(i0 - run_start);
+            const uint32_t p0 = k0 - __umul24(__umul24(k0, 33027u) >> 22, 127u);  // k0 mod 127 (see below)
+            const uint32_t head_j = (127u - p0) % 127u;  // which byte of the lane opens a packet (>= 4: none); p0 < 127
+            const bool has_head = head_j < 4u && ((valid >> head_j) & 1u);
+            const uint64_t heads = __ballot(has_head);
+            uint32_t off = total + 2u * (uint32_t)__popcll(heads & lt_mask);
+            total += 2u * (uint32_t)__popcll(heads);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const bool ok = (valid >> j) & 1u;
+                uint32_t p = p0 + (uint32_t)j;
+                p = p >= 127u ? p - 127u : p;
+                const bool first = p == 0u;
+                const bool last = p == 126u || !((e >> j) & 1u);
+                const uint32_t at = first ? off : off - 2u;
+                if (ok && last) {
+                    o[at] = (uint8_t)(129u + p);
+                    o[at + 1u] = (uint8_t)by[j];
+                }
+                off += (ok && first) ? 2u : 0u;
+            }
+            carry = (uint32_t)__shfl((int)(mine1 | ((run & 15u) << 8)), 63);
+            w = w_next;
+            continue;
+        }
+        const uint32_t rh = rh_bits;  // first byte of a run
         const uint32_t sh = valid & ~run & (in_run_before | (i0 == 0 ? 1u : 0u)) & 15u;  // first literal byte of a stretch
         // the heads that reach in from outside the lane: the last one in an earlier lane of this block, else the carried one
         const uint64_t rh_lanes = __ballot(rh != 0u), sh_lanes = __ballot(sh != 0u);
