@@ -3,8 +3,10 @@
           from every cast kernel (the oracle draws the same counter-based random numbers)
   boxes:  random box sets (scenes.random_boxes) -- Morton codes, sorted order, every tree node, in both forms of the build
   bigboxes: the same with up to 150 000 boxes (the sizes of the sort in tiles and of the range form of the climb, and above)
+  hugeboxes: the same with up to 600 000 boxes (the sort by the upper key bytes with its two finishing kernels, the climb
+          with device-wide hand-offs)
   obj:    random OBJ texts (scenes.random_obj_text) -- vertices and indices
-Usage: fuzz_parity.py [worlds|boxes|bigboxes|obj] [first_seed [count]]"""
+Usage: fuzz_parity.py [worlds|boxes|bigboxes|hugeboxes|obj] [first_seed [count]]"""
 import sys, os, tempfile
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root)
@@ -25,8 +27,8 @@ tmp = tempfile.mkdtemp()
 def one(seed):
     if kind == "worlds":
         check_random_world(oracle, tr, seed)
-    elif kind in ("boxes", "bigboxes"):
-        boxes = scenes.random_boxes(seed, 150_000 if kind == "bigboxes" else 20_000)
+    elif kind in ("boxes", "bigboxes", "hugeboxes"):
+        boxes = scenes.random_boxes(seed, {"boxes": 20_000, "bigboxes": 150_000, "hugeboxes": 600_000}[kind])
         codes, cs, ids, nodes, _ = T.lbvh_build(tr, boxes)
         ocodes, ocs, oids, onodes = oracle.lbvh_build(boxes)
         assert (codes == ocodes).all() and (cs == ocs).all() and (ids == oids).all(), f"codes / order of {boxes.shape[0]} boxes"
