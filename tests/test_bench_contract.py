@@ -108,12 +108,16 @@ def test_default_run_carries_every_configuration():
 
 
 def test_twenty_and_two_hundred_steps_agree():
-    """The driver runs a short region: the median over repeated regions must make its figure the long run's."""
-    a = run_bench("--steps", "20", "--warmup", "5", "--build-sizes", "", "--no-cpu-baseline", "--no-workloads")
-    b = run_bench("--steps", "200", "--warmup", "20", "--build-sizes", "", "--no-cpu-baseline", "--no-workloads")
-    assert a["regions"]["count"] > b["regions"]["count"] >= 1
-    # (measured 2.6 % apart; the bound leaves room for a noisy box)
-    assert abs(a["value"] - b["value"]) <= 0.04 * b["value"], (a["value"], b["value"], a["regions"], b["regions"])
+    """The driver runs a short region: the median over repeated regions must make its figure the long run's (measured
+    2.6 % apart; one region of 20 single-frame steps used to be 16 % under the long run).  A timing test on a shared
+    box: the bound is twice what is measured, and a miss is tried once more before it counts."""
+    for attempt in range(2):
+        a = run_bench("--steps", "20", "--warmup", "5", "--build-sizes", "", "--no-cpu-baseline", "--no-workloads")
+        b = run_bench("--steps", "200", "--warmup", "20", "--build-sizes", "", "--no-cpu-baseline", "--no-workloads")
+        assert a["regions"]["count"] > b["regions"]["count"] >= 1
+        if abs(a["value"] - b["value"]) <= 0.06 * b["value"]:
+            return
+    raise AssertionError((a["value"], b["value"], a["regions"], b["regions"]))
 
 
 def test_two_ranks_start_themselves():
