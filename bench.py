@@ -445,6 +445,8 @@ def parse_args(argv=None):
     ap.add_argument("--c5-samples", type=int, default=32,
                     help="samples per pixel axis of the `cornell_mesh_4k_*` strong-scaling entries (BASELINE config 5: 32 = 1024 spp)")
     ap.add_argument("--no-config5", action="store_true", help="skip the config-5 strong-scaling entries of a multi-GPU run")
+    ap.add_argument("--config5-limit-s", type=float, default=300.0,
+                    help="N > 1: if the config-5 entries have not finished after this many seconds, rank 0 prints the line without them")
     return ap.parse_args(argv)
 
 
@@ -1066,15 +1068,35 @@ def main():
                 a = copy.copy(args)
                 a.samples = args.c5_samples
                 key = f"cornell_mesh_4k_{args.c5_samples * args.c5_samples}spp"
-            sub = measure(a, name, steps, warmup, n_streams, rank, world, device_index, want_cpu and traversal == "exact" and not c5,
-                          cpu_budget_s=4.0, cpu_max_paths=1 << 17, extras=False, traversal=traversal, min_region_s=0.0 if c5 else 0.3)
-            others[key] = compact(sub)
+            try:  # a side figure that fails must not take the headline with it
+                sub = measure(a, name, steps, warmup, n_streams, rank, world, device_index, want_cpu and traversal == "exact" and not c5,
+                              cpu_budget_s=4.0, cpu_max_paths=1 << 17, extras=False, traversal=traversal, min_region_s=0.0 if c5 else 0.3)
+                others[key] = compact(sub)
+            except Exception as e:  # noqa: BLE001
+                others[key] = {"error": f"{type(e).__name__}: {e}"}
         line["workloads"] = others
     if world > 1 and not args.no_config5 and args.workload == "bunny" and args.shard == "frames":
         # BASELINE config 5 proper beside the weak-scaling headline: ONE Cornell + mesh frame at 3840x2160 and 1024 spp
         # split between the ranks by tiles (an RCCL gather of disjoint tiles) and by sample index (an RCCL sum), one
         # exchange per frame: strong scaling.  Every rank takes part; rank 0 keeps the figures.
-        others = config5_entries(args, rank, world, device_index)
+        # Their collectives are the first of their kind in the run (a gather of tiles, a per-frame reduce): should one of
+        # them never return, a timer lets every rank leave with the headline instead of hanging the launcher.
+        import threading
+
+        def give_up():
+            if rank == 0:
+                line["workloads"] = {"error": f"the config-5 entries did not finish within {args.config5_limit_s:.0f} s"}
+                print(json.dumps(line), flush=True)
+            os._exit(0)
+
+        timer = threading.Timer(args.config5_limit_s, give_up)
+        timer.daemon = True
+        timer.start()
+        try:
+            others = config5_entries(args, rank, world, device_index)
+        except Exception as e:  # noqa: BLE001
+            others = {"error": f"{type(e).__name__}: {e}"}
+        timer.cancel()
         if rank == 0:
             line["workloads"] = others
     if rank == 0:
