@@ -23,6 +23,7 @@ untimed launch).  `cpu_baseline` times the CPU reference on the host cores of th
 from __future__ import annotations
 
 import argparse
+import collections
 import ctypes as C
 import json
 import os
@@ -620,9 +621,22 @@ def measure(args, name, steps, warmup, n_streams_arg, rank, world, device_index,
     # then weigh the same few per cent at the driver's 20 steps as in a long run.
     frames_per_step = n_streams
 
+    # The library refuses a 65th unfinished launch of its persistent kernels: the host keeps at most `depth` steps
+    # enqueued ahead of the device (it waits for the step that far back, while the device still has the later ones).
+    depth = max(2, 40 // frames_per_step)
+    enqueued = collections.deque()
+
     def step(events=None):
         for j in range(frames_per_step):
             launch(events[j] if events else None)
+        marks = []
+        for s in streams:
+            marks.append(torch.cuda.Event())
+            marks[-1].record(s)
+        enqueued.append(marks)
+        if len(enqueued) > depth:
+            for m in enqueued.popleft():
+                m.synchronize()
 
     def launch(events=None):
         k = step_no[0] % n_streams

@@ -405,6 +405,7 @@ struct TravFast {
     uint32_t cur_inst;  // TLAS id of the instance being walked (0: in the TLAS)
     uint32_t tri_base;
     uint32_t overflow;  // the stack was too short for this ray: T.h is not valid, ask the stackless walk
+    uint32_t pend_id;   // TLAS leaf whose instance is still to be entered (0: none); see trav_fast_enter
     const float4* nodes;  // the records being walked: 8 x float4 each
     Hit h;
 };
@@ -423,6 +424,7 @@ __device__ __forceinline__ void trav_fast_begin(TravFast& T, const DevScene& S, 
     T.cur_inst = 0;
     T.tri_base = 0;
     T.overflow = 0;
+    T.pend_id = 0;
     T.nodes = S.tlas_wide;
     T.h.inst = 0;
     T.h.tri = 0;
@@ -431,8 +433,51 @@ __device__ __forceinline__ void trav_fast_begin(TravFast& T, const DevScene& S, 
     T.h.t = kMaxF;
 }
 
-// One step.  Returns true when the query has ended (T.h is final).
+// A TLAS leaf whose turn has come (rt_cpu_intersect_tlas_node, raytracer_cpu.c:494-531): a sphere is tested, a mesh
+// instance is entered -- the ray goes to model space and the instance's records are walked from the stack height at
+// which it was entered.
 template <bool COUNT>
+__device__ __forceinline__ void trav_fast_enter_leaf(TravFast& T, const DevScene& S, Counters& cnt, uint32_t id) {
+    const DevInstance* it = &S.inst[id - 1];
+    if (COUNT) cnt.insts++;
+    if (it->type == RTHIP_INST_SPHERE) {
+        const float4 cr = *(const float4*)it->sphere_center;
+        if (sphere_test(T.o, T.d, mk(cr.x, cr.y, cr.z), it->sphere_radius, kEps, T.tmax)) {
+            T.h.inst = id;
+            T.h.tri = 0;
+            T.h.u = 0.f;
+            T.h.v = 0.f;
+        }
+        return;
+    }
+    const float4 tr = *(const float4*)it->translation;
+    const float4 q = *(const float4*)it->rotation;
+    const float4 sc = *(const float4*)it->scale;
+    const V3 qv = mk(-q.x, -q.y, -q.z);
+    const V3 s3 = mk(sc.x, sc.y, sc.z);
+    T.o = divv(rot_quat(sub(T.wo, mk(tr.x, tr.y, tr.z)), qv, q.w), s3);
+    T.d = divv(rot_quat(T.wd, qv, q.w), s3);
+    T.inv = mk(1.f / T.d.x, 1.f / T.d.y, 1.f / T.d.z);
+    T.cur_inst = id;
+    T.tri_base = it->tri_base;
+    T.nodes = S.blas_wide + 8 * (size_t)it->wide_base;
+    T.base = T.sp;
+    T.cur = it->n_nodes == 1 ? (kLeafBit | 1u) : 0u;  // a one-triangle mesh has no record
+}
+
+// Enters the instance a lane was parked at by trav_fast_step<COUNT, true>.
+template <bool COUNT>
+__device__ __forceinline__ void trav_fast_enter(TravFast& T, const DevScene& S, Counters& cnt) {
+    const uint32_t id = T.pend_id;
+    T.pend_id = 0;
+    trav_fast_enter_leaf<COUNT>(T, S, cnt, id);
+}
+
+// One step.  Returns true when the query has ended (T.h is final).  With DEFER a lane that reaches an instance parks
+// there (T.pend_id) and the caller enters it later with trav_fast_enter, for several lanes of the wave at once: the entry
+// is the longest branch of a step (two quaternion rotations, nine divisions) and in a scene of many instances nearly
+// every step of a wave has some lane that needs it.
+template <bool COUNT, bool DEFER = false>
 __device__ __forceinline__ bool trav_fast_step(TravFast& T, const DevScene& S, Counters& cnt, FastStack& st) {
     uint32_t cur = T.cur;
     if (cur == kPop) {
@@ -476,7 +521,6 @@ __device__ __forceinline__ bool trav_fast_step(TravFast& T, const DevScene& S, C
             }
             return false;
         }
-        const DevInstance* it = &S.inst[id - 1];
         if (S.n_inst == 1u) {
             // The TLAS is this one leaf and has no record, so no step has tested its box: the reference does
             // (lbvh.c:151-156), and a ray that misses it is spared the change to model space.
@@ -484,30 +528,11 @@ __device__ __forceinline__ bool trav_fast_step(TravFast& T, const DevScene& S, C
             if (COUNT) cnt.nodes++;
             if (!slab(make_float4(ra.x, ra.z, rb.x, 0.f), make_float4(ra.y, ra.w, rb.y, 0.f), T.o, T.inv, kEps, T.tmax)) return false;
         }
-        if (COUNT) cnt.insts++;
-        if (it->type == RTHIP_INST_SPHERE) {
-            const float4 cr = *(const float4*)it->sphere_center;
-            if (sphere_test(T.o, T.d, mk(cr.x, cr.y, cr.z), it->sphere_radius, kEps, T.tmax)) {
-                T.h.inst = id;
-                T.h.tri = 0;
-                T.h.u = 0.f;
-                T.h.v = 0.f;
-            }
+        if (DEFER) {  // the caller enters the instance later (trav_fast_enter)
+            T.pend_id = id;
             return false;
         }
-        const float4 tr = *(const float4*)it->translation;
-        const float4 q = *(const float4*)it->rotation;
-        const float4 sc = *(const float4*)it->scale;
-        const V3 qv = mk(-q.x, -q.y, -q.z);
-        const V3 s3 = mk(sc.x, sc.y, sc.z);
-        T.o = divv(rot_quat(sub(T.wo, mk(tr.x, tr.y, tr.z)), qv, q.w), s3);
-        T.d = divv(rot_quat(T.wd, qv, q.w), s3);
-        T.inv = mk(1.f / T.d.x, 1.f / T.d.y, 1.f / T.d.z);
-        T.cur_inst = id;
-        T.tri_base = it->tri_base;
-        T.nodes = S.blas_wide + 8 * (size_t)it->wide_base;
-        T.base = T.sp;
-        T.cur = it->n_nodes == 1 ? (kLeafBit | 1u) : 0u;  // a one-triangle mesh has no record
+        trav_fast_enter_leaf<COUNT>(T, S, cnt, id);
         return false;
     }
     const float4* rec = T.nodes + 8 * (size_t)cur;

@@ -53,6 +53,8 @@ struct Walk<false> {
     __device__ __forceinline__ void begin(const DevScene& S, V3 o, V3 d) { trav_begin(T, S, o, d); }
     template <bool COUNT, bool DEFER>
     __device__ __forceinline__ bool step(const DevScene& S, Counters& cnt) { return trav_step<COUNT, DEFER>(T, S, cnt); }
+    template <bool COUNT>
+    __device__ __forceinline__ void enter(const DevScene& S, Counters& cnt) { trav_enter<COUNT>(T, S, cnt); }
 };
 template <>
 struct Walk<true> {
@@ -62,10 +64,12 @@ struct Walk<true> {
     __device__ __forceinline__ void begin(const DevScene& S, V3 o, V3 d) { trav_fast_begin(T, S, o, d); }
     template <bool COUNT, bool DEFER>
     __device__ __forceinline__ bool step(const DevScene& S, Counters& cnt) {
-        if (!trav_fast_step<COUNT>(T, S, cnt, st)) return false;
+        if (!trav_fast_step<COUNT, DEFER>(T, S, cnt, st)) return false;
         if (T.overflow) T.h = closest_hit_query<COUNT>(S, T.wo, T.wd, cnt);  // see kFastLds
         return true;
     }
+    template <bool COUNT>
+    __device__ __forceinline__ void enter(const DevScene& S, Counters& cnt) { trav_fast_enter<COUNT>(T, S, cnt); }
 };
 
 // The workgroup's block of the ordered walk's stacks: it lies behind the bounce stack in the dynamic LDS block.
@@ -234,14 +238,14 @@ __global__ __launch_bounds__(kBlock, FAST ? 4 : RT_PERSIST_WAVES) void cast_kern
             // rays enter instances often (many small instances); elsewhere the plain step is faster.
             if (COUNT && (int)lane == __ffsll((long long)walking) - 1) cnt.wave_steps++;
             if (COUNT && state == ST_TRAVERSE) cnt.lane_steps++;
-            if constexpr (DEFER && !FAST) {
+            if constexpr (DEFER) {
                 const uint64_t parked = __ballot(state == ST_TRAVERSE && Wk.T.pend_id != 0);
                 const bool enter_now =
                     parked != 0 && ((uint32_t)__popcll(parked) >= inst_batch || (walking & ~parked) == 0);
                 if (state == ST_TRAVERSE) {
                     if (Wk.T.pend_id != 0) {
-                        if (enter_now) trav_enter<COUNT>(Wk.T, S, cnt);
-                    } else if (trav_step<COUNT, true>(Wk.T, S, cnt)) {
+                        if (enter_now) Wk.template enter<COUNT>(S, cnt);
+                    } else if (Wk.template step<COUNT, true>(S, cnt)) {
                         state = ST_SHADE;
                     }
                 }
@@ -554,13 +558,13 @@ __global__ __launch_bounds__(kBlock) void trace_rays_kernel(DevScene S, const fl
 // and prefix count; it goes back for rays whenever `refill` lanes are idle.
 constexpr uint32_t kRayGrab = 1024;
 
-template <bool COUNT, bool FAST = false>
+template <bool COUNT, bool FAST = false, bool DEFER = false>
 __global__ __launch_bounds__(kBlock) void trace_rays_persistent_kernel(DevScene S, const float* __restrict__ ro,
                                                                        const float* __restrict__ rd, uint64_t n,
                                                                        uint32_t* __restrict__ hits4,
                                                                        float* __restrict__ uv, float* __restrict__ normal,
                                                                        uint32_t* work_counter, uint32_t refill,
-                                                                       uint64_t* counters) {
+                                                                       uint64_t* counters, uint32_t inst_batch = 0) {
     extern __shared__ uint32_t fast_lds[];  // FAST: kFastLds entries per lane
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
@@ -609,7 +613,19 @@ __global__ __launch_bounds__(kBlock) void trace_rays_persistent_kernel(DevScene 
                 if ((int)lane == __ffsll((long long)walking) - 1) cnt.wave_steps++;
                 if (active) cnt.lane_steps++;
             }
-            if (active && Wk.template step<COUNT, false>(S, cnt)) {
+            if constexpr (DEFER) {  // lanes park at instances and enter them together (see cast_kernel)
+                const uint64_t walking = __ballot(active);
+                const uint64_t parked = __ballot(active && Wk.T.pend_id != 0);
+                const bool enter_now = parked != 0 && ((uint32_t)__popcll(parked) >= inst_batch || (walking & ~parked) == 0);
+                if (active) {
+                    if (Wk.T.pend_id != 0) {
+                        if (enter_now) Wk.template enter<COUNT>(S, cnt);
+                    } else if (Wk.template step<COUNT, true>(S, cnt)) {
+                        write_ray_result(S, ray, Wk.T.h, Wk.T.wo, Wk.T.wd, hits4, uv, normal);
+                        active = false;
+                    }
+                }
+            } else if (active && Wk.template step<COUNT, false>(S, cnt)) {
                 write_ray_result(S, ray, Wk.T.h, Wk.T.wo, Wk.T.wd, hits4, uv, normal);
                 active = false;
             }
@@ -715,23 +731,30 @@ int trace_rays_launch(rthip_ctx* ctx, const DevScene& scene, const float* d_o, c
     const bool resident = ctx->cast_mode == 0 || (ctx->cast_mode != 1 && ctx->cast_mode != 4 && scene_bytes <= (256ull << 20));
     if (n >= (1ull << 18) && n < (1ull << 32) * kRayGrab && resident) {
         uint32_t blocks = div_up(n, kBlock);
-        const uint32_t held = fast ? (d_counters ? resident_blocks(ctx, trace_rays_persistent_kernel<true, true>, kFastLdsBytes)
-                                                 : resident_blocks(ctx, trace_rays_persistent_kernel<false, true>, kFastLdsBytes))
-                                   : (d_counters ? resident_blocks(ctx, trace_rays_persistent_kernel<true, false>, 0)
-                                                 : resident_blocks(ctx, trace_rays_persistent_kernel<false, false>, 0));
+        const uint32_t batch = fast && ctx->n_inst >= 8u ? ctx->fast_inst_batch : 0u;
+        uint32_t held;
+        if (fast && batch) held = d_counters ? resident_blocks(ctx, trace_rays_persistent_kernel<true, true, true>, kFastLdsBytes)
+                                             : resident_blocks(ctx, trace_rays_persistent_kernel<false, true, true>, kFastLdsBytes);
+        else if (fast) held = d_counters ? resident_blocks(ctx, trace_rays_persistent_kernel<true, true>, kFastLdsBytes)
+                                         : resident_blocks(ctx, trace_rays_persistent_kernel<false, true>, kFastLdsBytes);
+        else held = d_counters ? resident_blocks(ctx, trace_rays_persistent_kernel<true, false>, 0)
+                               : resident_blocks(ctx, trace_rays_persistent_kernel<false, false>, 0);
         if (blocks > held) blocks = held;
         uint32_t* work = nullptr;  // a slot of zeroed counters: see work_slot_release
         int slot = -1;
         RT_TRY(work_slot_take(ctx, stream, &work, &slot));
-#define RT_LAUNCH_RAYS_P(COUNT, FAST, CNT)                                                                              \
-    trace_rays_persistent_kernel<COUNT, FAST><<<blocks, kBlock, (FAST) ? kFastLdsBytes : 0, stream>>>(                  \
-        scene, d_o, d_d, n, d_hits4, d_uv, d_normal, work, ctx->refill_lanes, CNT)
-        if (fast) {
-            if (d_counters) RT_LAUNCH_RAYS_P(true, true, d_counters);
-            else RT_LAUNCH_RAYS_P(false, true, nullptr);
+#define RT_LAUNCH_RAYS_P(COUNT, FAST, DEFER, CNT)                                                                       \
+    trace_rays_persistent_kernel<COUNT, FAST, DEFER><<<blocks, kBlock, (FAST) ? kFastLdsBytes : 0, stream>>>(           \
+        scene, d_o, d_d, n, d_hits4, d_uv, d_normal, work, ctx->refill_lanes, CNT, batch)
+        if (fast && batch) {
+            if (d_counters) RT_LAUNCH_RAYS_P(true, true, true, d_counters);
+            else RT_LAUNCH_RAYS_P(false, true, true, nullptr);
+        } else if (fast) {
+            if (d_counters) RT_LAUNCH_RAYS_P(true, true, false, d_counters);
+            else RT_LAUNCH_RAYS_P(false, true, false, nullptr);
         } else {
-            if (d_counters) RT_LAUNCH_RAYS_P(true, false, d_counters);
-            else RT_LAUNCH_RAYS_P(false, false, nullptr);
+            if (d_counters) RT_LAUNCH_RAYS_P(true, false, false, d_counters);
+            else RT_LAUNCH_RAYS_P(false, false, false, nullptr);
         }
 #undef RT_LAUNCH_RAYS_P
         RT_HIP(ctx, hipGetLastError());
@@ -879,7 +902,8 @@ int launch_persistent(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_se
     const size_t lds = (size_t)(scene.max_bounces ? scene.max_bounces : 1) * kBlock * sizeof(uint32_t);
     const bool fast_walk = ctx->traversal == RTHIP_TRAV_FAST, batched = inst_batch != 0;
     uint32_t held;
-    if (fast_walk) held = d_counters ? resident_blocks(ctx, cast_kernel<true, false, true>, lds + kFastLdsBytes) : resident_blocks(ctx, cast_kernel<false, false, true>, lds + kFastLdsBytes);
+    if (fast_walk && batched) held = d_counters ? resident_blocks(ctx, cast_kernel<true, true, true>, lds + kFastLdsBytes) : resident_blocks(ctx, cast_kernel<false, true, true>, lds + kFastLdsBytes);
+    else if (fast_walk) held = d_counters ? resident_blocks(ctx, cast_kernel<true, false, true>, lds + kFastLdsBytes) : resident_blocks(ctx, cast_kernel<false, false, true>, lds + kFastLdsBytes);
     else if (batched) held = d_counters ? resident_blocks(ctx, cast_kernel<true, true>, lds) : resident_blocks(ctx, cast_kernel<false, true>, lds);
     else held = d_counters ? resident_blocks(ctx, cast_kernel<true, false>, lds) : resident_blocks(ctx, cast_kernel<false, false>, lds);
     if (blocks > held) blocks = held;
@@ -893,13 +917,20 @@ int launch_persistent(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_se
 #define RT_LAUNCH_CAST(COUNT, DEFER, CNT)                                                                              \
     cast_kernel<COUNT, DEFER><<<blocks, kBlock, lds, stream>>>(scene, cast, seed, d_rgb, width, height, shard, work, \
                                                                refill, inst_batch, ctx->cast_accumulate, CNT)
+#define RT_LAUNCH_CAST_FAST(COUNT, DEFER, CNT)                                                                         \
+    do {                                                                                                               \
+        RT_TRY(allow_lds(ctx, cast_kernel<COUNT, DEFER, true>, lds + kFastLdsBytes));                                  \
+        cast_kernel<COUNT, DEFER, true><<<blocks, kBlock, lds + kFastLdsBytes, stream>>>(                              \
+            scene, cast, seed, d_rgb, width, height, shard, work, refill, inst_batch, ctx->cast_accumulate, CNT);      \
+    } while (0)
     if (ctx->traversal == RTHIP_TRAV_FAST) {
-        if (d_counters) RT_TRY(allow_lds(ctx, cast_kernel<true, false, true>, lds + kFastLdsBytes));
-        else RT_TRY(allow_lds(ctx, cast_kernel<false, false, true>, lds + kFastLdsBytes));
-        if (d_counters)
-            cast_kernel<true, false, true><<<blocks, kBlock, lds + kFastLdsBytes, stream>>>(scene, cast, seed, d_rgb, width, height, shard, work, refill, 0u, ctx->cast_accumulate, d_counters);
-        else
-            cast_kernel<false, false, true><<<blocks, kBlock, lds + kFastLdsBytes, stream>>>(scene, cast, seed, d_rgb, width, height, shard, work, refill, 0u, ctx->cast_accumulate, nullptr);
+        if (d_counters) {
+            if (defer) RT_LAUNCH_CAST_FAST(true, true, d_counters);
+            else RT_LAUNCH_CAST_FAST(true, false, d_counters);
+        } else {
+            if (defer) RT_LAUNCH_CAST_FAST(false, true, nullptr);
+            else RT_LAUNCH_CAST_FAST(false, false, nullptr);
+        }
     } else if (d_counters) {
         if (defer) RT_LAUNCH_CAST(true, true, d_counters);
         else RT_LAUNCH_CAST(true, false, d_counters);
@@ -908,6 +939,7 @@ int launch_persistent(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_se
         else RT_LAUNCH_CAST(false, false, nullptr);
     }
 #undef RT_LAUNCH_CAST
+#undef RT_LAUNCH_CAST_FAST
     RT_HIP(ctx, hipGetLastError());
     return work_slot_launched(ctx, slot, stream);
 }
@@ -1094,6 +1126,10 @@ int cast_launch(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_settings
         }
         if (choice.kernel == 1 && by_samples_possible) choice.kernel = 4;
     }
+    // The ordered walk parks lanes at instances and enters them in batches wherever a scene has instances to speak of: a
+    // step of that walk is long already (four box tests, a sort, the stack), and with a few per cent of the lane steps
+    // ending in an instance nearly every step of a wave pays for the entry as well (RTHIP_FAST_INST_BATCH; 0 = never).
+    if (fast) choice.inst_batch = ctx->n_inst >= 8u ? ctx->fast_inst_batch : 0u;
     ctx->last_cast_kernel = (uint32_t)choice.kernel;
     ctx->last_cast_refill = choice.kernel == 0 ? choice.refill : 0u;
     uint32_t ib = 0;

@@ -1286,6 +1286,39 @@ def tree_depth(nodes):
     return depth
 
 
+def test_fast_traversal_enters_instances_in_batches_with_the_same_answers(monkeypatch):
+    """The ordered walk parks lanes at instances and enters them several at a time (RTHIP_FAST_INST_BATCH, default 8) in
+    its resident kernels.  Parking delays a lane's entry and changes nothing else about its walk: frames and ray
+    streams are equal bit for bit whatever the batch, also with a batch no wave ever fills (64)."""
+    verts, indices = scenes.bunny_class_mesh(3)
+    w, cam, sky = scenes.instanced_grid(24, seed=3, verts=verts, indices=indices)
+    c = cam(320, 200, 2)
+    rng = np.random.default_rng(5)
+    n = 1 << 18  # long enough for the resident ray-stream kernel
+    o = rng.uniform(-30.0, 30.0, (n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    got = {}
+    for batch in ("0", "8", "3", "64"):
+        monkeypatch.setenv("RTHIP_FAST_INST_BATCH", batch)
+        tr = T.rt_make_tracer(T.RT_TracerSettings(max_bounces=4, sky=sky), device_id=0)
+        try:
+            T.rt_tracer_build_blas(tr, w)
+            T.rt_tracer_build_tlas(tr, w)
+            T.set_traversal(tr, "fast")
+            T.set_cast_kernel(tr, "persistent")
+            img = np.zeros((200, 320, 3), dtype=np.float32)
+            T.rt_tracer_cast(tr, c, img, 320, 200, seed=9)
+            got[batch] = (img, T.trace_rays(tr, o, d))
+        finally:
+            T.rt_tracer_cleanup(tr)
+    assert int((got["0"][1][0] != 0).sum()) > n // 20, "the rays miss the grid: the test tests nothing"
+    for batch in ("8", "3", "64"):
+        assert (bits(got[batch][0]) == bits(got["0"][0])).all(), batch
+        for a, b in zip(got[batch][1], got["0"][1]):
+            assert (bits(a) == bits(b)).all() if a.dtype == np.float32 else (a == b).all(), batch
+
+
 @pytest.mark.parametrize("level", ["mesh", "tlas"])
 def test_fast_traversal_on_a_tree_deeper_than_its_stack(gpu_tracer, level):
     """A tree about sixty levels deep whose boxes a ray pierces all at once wants more stack than the ordered walk keeps
