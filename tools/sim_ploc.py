@@ -90,6 +90,32 @@ def tri_hit(o, d, tri, tmax):
     if t < 1e-7 or t > tmax: return None
     return t
 
+def slots_fixed(k, L, R, B):
+    slots = []
+    for c in (L[k], R[k]):
+        if L[c] < 0: slots.append(c)
+        else: slots.extend([L[c], R[c]])
+    return slots
+
+_AREA = {}
+def slots_greedy(k, L, R, B, width=4):
+    """the node's two children, then the inner slot with the largest box is replaced by its two children until there are
+    `width` slots (or none is inner): the usual surface-area-guided collapse of a binary tree into a wide one"""
+    slots = [L[k], R[k]]
+    while len(slots) < width:
+        best = -1; ba = -1.0
+        for j, c in enumerate(slots):
+            if L[c] >= 0:
+                a = area(B[c])
+                if a > ba: ba = a; best = j
+        if best < 0: break
+        c = slots[best]
+        slots[best:best + 1] = [L[c], R[c]]
+    return slots
+
+SLOTS = slots_fixed
+WIDE_STEPS = [0]
+
 def traverse_wide(root, L, R, B, tris, o, d):
     """4-wide (two levels collapsed), nearest first, stack; returns box tests, tri tests"""
     inv = 1.0 / d
@@ -105,10 +131,8 @@ def traverse_wide(root, L, R, B, tris, o, d):
             t = tri_hit(o, d, tris[k], tmax)
             if t is not None: tmax = t
             continue
-        slots = []
-        for c in (L[k], R[k]):
-            if L[c] < 0: slots.append(c)
-            else: slots.extend([L[c], R[c]])
+        slots = SLOTS(k, L, R, B)
+        WIDE_STEPS[0] += 1
         hits = []
         for sidx in slots:
             nb += 1
