@@ -212,6 +212,8 @@ int rthip_create(rthip_ctx** out_ctx, int device_id) {
     const char* refill = getenv("RTHIP_REFILL");
     const char* sib = getenv("RTHIP_SAMPLES_INST_BATCH");
     if (sib && atoi(sib) >= 0 && atoi(sib) <= 64) ctx->samples_inst_batch_env = atoi(sib);
+    const char* rib = getenv("RTHIP_RAYS_INST_BATCH");
+    if (rib && atoi(rib) >= 0 && atoi(rib) <= 64) ctx->rays_inst_batch = (uint32_t)atoi(rib);
     const char* fib = getenv("RTHIP_FAST_INST_BATCH");
     if (fib && atoi(fib) >= 0 && atoi(fib) <= 64) ctx->fast_inst_batch = (uint32_t)atoi(fib);
     if (refill && atoi(refill) >= 1 && atoi(refill) <= 64) ctx->refill_lanes = (uint32_t)atoi(refill);

@@ -220,6 +220,7 @@ struct rthip_ctx {
     // pixel- / sample-per-lane kernels: instance entries of a wave in batches (entry_batch, trace.hip)
     bool small_meshes = false;        // set by rthip_tlas_build: the mesh instances average at most 32 nodes
     int samples_inst_batch_env = -1;  // RTHIP_SAMPLES_INST_BATCH
+    uint32_t rays_inst_batch = 8;     // exact walk, resident ray-stream kernel, scenes of >= 64 instances: the same (RTHIP_RAYS_INST_BATCH)
     uint32_t fast_inst_batch = 8;     // ordered walk: lanes parked at instances enter k at a time, 0 = at once (RTHIP_FAST_INST_BATCH)
     bool batch_known = false;         // the measured decision for batch_key (scene generation, frame size, samples, sharding)
     uint64_t batch_key[4] = {0, 0, 0, 0};

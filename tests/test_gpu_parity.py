@@ -1286,10 +1286,11 @@ def tree_depth(nodes):
     return depth
 
 
-def test_fast_traversal_enters_instances_in_batches_with_the_same_answers(monkeypatch):
-    """The ordered walk parks lanes at instances and enters them several at a time (RTHIP_FAST_INST_BATCH, default 8) in
-    its resident kernels.  Parking delays a lane's entry and changes nothing else about its walk: frames and ray
-    streams are equal bit for bit whatever the batch, also with a batch no wave ever fills (64)."""
+def test_resident_kernels_enter_instances_in_batches_with_the_same_answers(oracle, monkeypatch):
+    """The resident kernels park lanes at instances and enter them several at a time (the ordered walk:
+    RTHIP_FAST_INST_BATCH, default 8; the exact walk's ray streams: RTHIP_RAYS_INST_BATCH, default 8 from 64 instances).
+    Parking delays a lane's entry and changes nothing else about its walk: frames and ray streams are equal bit for bit
+    whatever the batch, also with a batch no wave ever fills (64); the exact walk's stream equals the oracle's answers."""
     verts, indices = scenes.bunny_class_mesh(3)
     w, cam, sky = scenes.instanced_grid(24, seed=3, verts=verts, indices=indices)
     c = cam(320, 200, 2)
@@ -1298,13 +1299,15 @@ def test_fast_traversal_enters_instances_in_batches_with_the_same_answers(monkey
     o = rng.uniform(-30.0, 30.0, (n, 3)).astype(np.float32)
     d = rng.normal(size=(n, 3)).astype(np.float32)
     d /= np.linalg.norm(d, axis=1, keepdims=True)
-    got = {}
+    got, exact = {}, {}
     for batch in ("0", "8", "3", "64"):
         monkeypatch.setenv("RTHIP_FAST_INST_BATCH", batch)
+        monkeypatch.setenv("RTHIP_RAYS_INST_BATCH", batch)
         tr = T.rt_make_tracer(T.RT_TracerSettings(max_bounces=4, sky=sky), device_id=0)
         try:
             T.rt_tracer_build_blas(tr, w)
             T.rt_tracer_build_tlas(tr, w)
+            exact[batch] = T.trace_rays(tr, o, d)
             T.set_traversal(tr, "fast")
             T.set_cast_kernel(tr, "persistent")
             img = np.zeros((200, 320, 3), dtype=np.float32)
@@ -1317,6 +1320,14 @@ def test_fast_traversal_enters_instances_in_batches_with_the_same_answers(monkey
         assert (bits(got[batch][0]) == bits(got["0"][0])).all(), batch
         for a, b in zip(got[batch][1], got["0"][1]):
             assert (bits(a) == bits(b)).all() if a.dtype == np.float32 else (a == b).all(), batch
+        for a, b in zip(exact[batch], exact["0"]):
+            assert (bits(a) == bits(b)).all() if a.dtype == np.float32 else (a == b).all(), ("exact walk", batch)
+    sc = oracle.Scene(world.flatten_world(w), 4, sky)
+    k = 4096
+    oi, otri, ot, ouv, onrm, _ = sc.trace(o[:k], d[:k], threads=8)
+    gi, gtri, gt, guv, gnrm = exact["8"]
+    assert (gi[:k] == oi).all() and (gtri[:k] == otri).all() and (bits(gt[:k]) == bits(ot)).all()
+    assert (bits(guv[:k]) == bits(ouv)).all() and (bits(gnrm[:k]) == bits(onrm)).all()
 
 
 @pytest.mark.parametrize("level", ["mesh", "tlas"])
