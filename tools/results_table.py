@@ -22,7 +22,7 @@ def ms(x):
 def row(label, v, cpu=None):
     c = v["ceilings"]
     cpu = cpu if cpu is not None else v.get("cpu_baseline", {}).get("value", "")
-    return (f"| {label} | {v['value']:,.0f} | {v['ms_per_frame']:.3g} | {v['per_ray']['nodes']:.1f} | {v['lane_utilisation']:.2f} | "
+    return (f"| {label} | {v['value']:,.0f} | {ms(v['ms_per_frame'])} | {v['per_ray']['nodes']:.1f} | {v['lane_utilisation']:.2f} | "
             f"{bound(v)} | {c.get('traffic_over_algorithmic', '')} | {cpu} |")
 
 
