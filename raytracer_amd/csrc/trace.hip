@@ -1095,8 +1095,11 @@ int cast_launch(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_settings
         // (one stream): short paths that are alike want the least bookkeeping per ray.
         const uint64_t paths = (uint64_t)width * (uint64_t)height * cast.samples * cast.samples;
         if (deep && paths >= (1ull << 20)) {
+            // (refill threshold, Mrays/s at 8 / 16 / 24 / 32 / 48 idle lanes: 10 000 instances 1354 / 1456 / 1490 / 1445 / 1496,
+            // height field 1165 / 1383 / 1479 / 1514 / 1560, soup 1581 / 1628 / 1613 / 1581 / 1489: a step of this walk is long,
+            // so the ray generation and shading between two runs of steps weigh less per ray when more lanes share them)
             choice.kernel = 0;
-            choice.refill = 16;
+            choice.refill = 24;
             choice.inst_batch = 0;
         } else {
             choice.kernel = by_samples_possible ? 4 : 1;
