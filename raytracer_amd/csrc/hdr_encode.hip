@@ -109,10 +109,55 @@ __global__ __launch_bounds__(kBlock) void hdr_rows_kernel(const float* __restric
     int run_start = 0;       // where the last run of equal bytes that began in an earlier block began
     int stretch_start = 0;   // where the last stretch of literal bytes that began in an earlier block began
     uint32_t carry = 0;      // the previous block's last lane: e | tri << 4 | run << 8 of its four bytes
+    uint32_t prev_byte = 0;  // the previous block's last byte
     uint32_t w = 4 * lane < width ? b[lane] : 0u, w_next = 0;
     for (int base = 0; base < width; base += 256) {
         const int i0 = base + 4 * lane;
         w_next = (i0 + 256 < width) ? b[(i0 + 256) >> 2] : 0u;
+        // A whole block of bytes that all equal the byte in front of them -- the inside of a long run: exponent planes,
+        // black or saturated regions, flat backgrounds -- is recognised from the words alone and costs a few packet ends:
+        // bytes base - 1, base, base + 1 are equal, so the run began at or before base - 1 and run_start knows it.
+        if (base != 0 && base + 256 <= width) {
+            uint32_t before = __shfl_up(w >> 24, 1);
+            if (lane == 0) before = prev_byte;
+            if (__ballot((w ^ ((w << 8) | before)) != 0u) == 0ull) {
+                const uint32_t wn = (uint32_t)__builtin_amdgcn_readfirstlane((int)w_next);
+                const uint32_t value = prev_byte;
+                const bool e3 = base + 256 < width && (wn & 0xffu) == value;                               // the run goes on into the next block
+                const bool e4 = base + 257 < width && (wn & 0xffu) == ((wn >> 8) & 0xffu);
+                const uint32_t k0 = (uint32_t)(base - __builtin_amdgcn_readfirstlane(run_start));          // the block's first byte in its run
+                const uint32_t q = k0 - ((k0 * 33027u) >> 22) * 127u;                                      // k0 mod 127, k0 < 32768: its place in its packet
+                // the packet under way (or, with q == 0, the one that begins here) has its two bytes at `slot`
+                uint32_t slot = q == 0u ? total : total - 2u;
+                uint32_t next_total = q == 0u ? total + 2u : total;
+                uint32_t end = 126u - q;  // offset in the block of that packet's 127th byte
+                for (;;) {
+                    if (end <= 255u) {  // a full packet ends inside the block
+                        if (lane == 0) {
+                            o[slot] = (uint8_t)255u;
+                            o[slot + 1u] = (uint8_t)value;
+                        }
+                        if (end == 255u) break;
+                        slot = next_total;  // the next packet begins behind it
+                        next_total += 2u;
+                        end += 127u;
+                    } else {  // the packet reaches the block's end: it ends there if the run does
+                        if (!e3 && lane == 0) {
+                            uint32_t pl = q + 1u;  // (q + 255) mod 127 = (q + 1) mod 127: the last byte's place in its packet
+                            pl = pl >= 127u ? pl - 127u : pl;
+                            o[slot] = (uint8_t)(129u + pl);
+                            o[slot + 1u] = (uint8_t)value;
+                        }
+                        break;
+                    }
+                }
+                total = next_total;
+                // what the next block's first lane needs to know of this block's last four bytes: e, tri, run
+                carry = (7u | (e3 ? 8u : 0u)) | ((3u | (e3 ? 4u : 0u) | ((e3 && e4) ? 8u : 0u)) << 4) | (15u << 8);
+                w = w_next;
+                continue;
+            }
+        }
         // bytes 0..3 are the lane's own, 4..6 the next lane's first three (the next block's for the last lane)
         const uint32_t from_next = __shfl_down(w, 1);
         const uint32_t first_of_next_block = __shfl(w_next, 0);
@@ -166,6 +211,7 @@ __global__ __launch_bounds__(kBlock) void hdr_rows_kernel(const float* __restric
                 off += ok ? (first ? 2u : 1u) : 0u;
             }
             carry = (uint32_t)__shfl((int)mine1, 63);  // (its run bits are zero)
+            prev_byte = (uint32_t)__builtin_amdgcn_readlane((int)w, 63) >> 24;
             w = w_next;
             continue;
         }
@@ -193,6 +239,7 @@ __global__ __launch_bounds__(kBlock) void hdr_rows_kernel(const float* __restric
                 off += (ok && first) ? 2u : 0u;
             }
             carry = (uint32_t)__shfl((int)(mine1 | ((run & 15u) << 8)), 63);
+            prev_byte = (uint32_t)__builtin_amdgcn_readlane((int)w, 63) >> 24;
             w = w_next;
             continue;
         }
@@ -259,6 +306,7 @@ __global__ __launch_bounds__(kBlock) void hdr_rows_kernel(const float* __restric
             off += emits[j];
         }
         carry = __shfl((int)(mine1 | ((run & 15u) << 8)), 63);
+        prev_byte = (uint32_t)__builtin_amdgcn_readlane((int)w, 63) >> 24;
         w = w_next;
     }
     if (lane == 0) lengths[4 * y + c] = total;

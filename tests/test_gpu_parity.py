@@ -1877,6 +1877,35 @@ def test_hdr_encode_short_runs_at_every_alignment(oracle, gpu_tracer, seed):
     assert T.hdr_encode(gpu_tracer, img, w, h) == oracle.hdr_encode(img)
 
 
+def test_hdr_encode_long_runs_at_every_phase(oracle, gpu_tracer):
+    """Runs long enough to hold whole 256-byte blocks (which the coder recognises from their words alone), beginning at
+    every kind of offset and of lengths around the multiples of 127 and 256: packet ends on a block's first and last
+    bytes, runs that end with a block, with a packet, with both, with the row."""
+    rng = np.random.default_rng(9)
+    starts = list(range(0, 300, 7)) + [253, 254, 255, 256, 257, 258]
+    lengths = [257, 258, 381, 382, 383, 508, 509, 510, 511, 512, 513, 635, 636, 637, 762, 763, 1016, 1017, 1270, 1271]
+    w = 300 + 1271 + 40
+    rows = []
+    for s0 in starts:
+        for n in lengths:
+            row = (rng.random((w, 3), dtype=np.float32) * np.float32(4.0)).astype(np.float32)
+            row[s0:s0 + n] = np.float32(0.37)
+            rows.append(row)
+    for n in (w, w - 1, w - 3):  # a run to the row's end, from its start or behind a few bytes
+        row = (rng.random((w, 3), dtype=np.float32) * np.float32(4.0)).astype(np.float32)
+        row[w - n:] = np.float32(1.5)
+        rows.append(row)
+    img = np.stack(rows).astype(np.float32)
+    got = T.hdr_encode(gpu_tracer, img, w, img.shape[0])
+    want = oracle.hdr_encode(img)
+    assert len(got) == len(want) and got == want
+    # the same with rows a whole number of blocks wide (every block of the row can be such a block)
+    img2 = np.ascontiguousarray(img[:200, :1536])
+    img2[::3] = np.float32(0.0)
+    img2[1::3, 5:] = np.float32(7.25)
+    assert T.hdr_encode(gpu_tracer, img2, 1536, 200) == oracle.hdr_encode(img2)
+
+
 def test_hdr_encode_full_frame(oracle, gpu_tracer):
     """A 3840 x 2160 frame with flat regions, gradients and noise."""
     w, h = 3840, 2160
