@@ -725,10 +725,13 @@ int trace_rays_launch(rthip_ctx* ctx, const DevScene& scene, const float* d_o, c
     if (n == 0) return RTHIP_OK;
     const bool fast = ctx->traversal == RTHIP_TRAV_FAST;
     // Long streams over a scene that the caches can hold: resident waves with lane refill.  Once the
-    // scene is larger than the Infinity Cache the walk is bound by HBM line fetches, not by idle lanes,
-    // and the plain kernel (fewer registers, more waves) is the faster one.
+    // scene is larger than the Infinity Cache the exact walk is bound by HBM line fetches (a 128-byte line per
+    // 32-byte record: 0.8 of the peak), not by idle lanes, and the plain kernel (fewer registers, more waves) is the
+    // faster one: 160 against 122 Mrays/s on the 10 M-triangle soup.  The ordered walk uses the whole line it fetches
+    // and is short of requests in flight instead (27 % of the lanes at work in the plain kernel): resident with refill
+    // 490 against 298 Mrays/s on the same rays.
     const uint64_t scene_bytes = ctx->total_blas_nodes * 32ull + ctx->total_tris * 48ull;
-    const bool resident = ctx->cast_mode == 0 || (ctx->cast_mode != 1 && ctx->cast_mode != 4 && scene_bytes <= (256ull << 20));
+    const bool resident = ctx->cast_mode == 0 || (ctx->cast_mode != 1 && ctx->cast_mode != 4 && (fast || scene_bytes <= (256ull << 20)));
     if (n >= (1ull << 18) && n < (1ull << 32) * kRayGrab && resident) {
         uint32_t blocks = div_up(n, kBlock);
         // Lanes park at instances and enter them in batches (see cast_kernel).  Measured on rays through 10 000 instances:

@@ -1106,7 +1106,7 @@ def test_heightfield_scene(oracle, gpu_tracer):
 
 def test_ten_million_triangle_soup_incoherent_rays(oracle, gpu_tracer):
     """The benchmark's 10 M-triangle scene and its ray stream (2^24 incoherent rays, seed 2) at full size: the plain
-    ray kernel (the one such a scene takes by default) and the resident-wave kernel must agree on every ray bit for bit,
+    ray kernel (the one such a scene takes by default under the exact walk) and the resident-wave kernel must agree on every ray bit for bit,
     and the first 2^16 rays -- hits, distances and traversal counters -- must be the oracle's on the same scene."""
     import torch
 
@@ -1152,6 +1152,10 @@ def test_ten_million_triangle_soup_incoherent_rays(oracle, gpu_tracer):
         other = int(((fast[:, 0] != plain[:, 0]) | (fast[:, 1] != plain[:, 1])).sum())
         assert other <= 8, f"{other} rays report another primitive"
         assert fst["nodes_tested"] < 0.85 * 651.87 * n
+        # the ordered walk takes the resident-wave kernel at any scene size; the plain kernel gives the same answers
+        T.set_cast_kernel(gpu_tracer, "static")
+        fast_plain, _ = run(n)
+        assert torch.equal(fast_plain, fast), "plain and resident-wave ray kernels differ under the ordered walk"
     finally:
         T.set_traversal(gpu_tracer, "exact")
         T.set_cast_kernel(gpu_tracer, "auto")
