@@ -100,8 +100,11 @@ __device__ __forceinline__ void work_slot_release(uint32_t* work) {
 #ifndef RT_PERSIST_WAVES
 #define RT_PERSIST_WAVES 5
 #endif
+#ifndef RT_FAST_WAVES
+#define RT_FAST_WAVES 4  // waves per SIMD of the renderers under the ordered walk (their stacks in LDS allow four workgroups per CU)
+#endif
 template <bool COUNT, bool DEFER, bool FAST = false>
-__global__ __launch_bounds__(kBlock, FAST ? 4 : RT_PERSIST_WAVES) void cast_kernel(DevScene S, rthip_cast_settings c, uint64_t seed,
+__global__ __launch_bounds__(kBlock, FAST ? RT_FAST_WAVES : RT_PERSIST_WAVES) void cast_kernel(DevScene S, rthip_cast_settings c, uint64_t seed,
                                                       float* __restrict__ out, int width, int height,
                                                       rthip_shard shard, uint32_t* work_counters, uint32_t refill, uint32_t inst_batch,
                                                       uint32_t accumulate, uint64_t* counters) {
@@ -295,7 +298,7 @@ __device__ __forceinline__ bool pixel_of_thread(int width, int height, int& x, i
 #define RT_STATIC_WAVES 5
 #endif
 template <bool COUNT, bool BATCH = false, bool FAST = false>
-__global__ __launch_bounds__(kBlock, FAST ? 4 : RT_STATIC_WAVES) void cast_static_kernel(DevScene S, rthip_cast_settings c, uint64_t seed,
+__global__ __launch_bounds__(kBlock, FAST ? RT_FAST_WAVES : RT_STATIC_WAVES) void cast_static_kernel(DevScene S, rthip_cast_settings c, uint64_t seed,
                                                              float* __restrict__ out, int width, int height,
                                                              rthip_shard shard, uint32_t accumulate, uint64_t* counters,
                                                              uint32_t inst_batch = 0) {
@@ -368,8 +371,11 @@ __global__ __launch_bounds__(kBlock, FAST ? 4 : RT_STATIC_WAVES) void cast_stati
 // kernel would hold the frame in a few long-running waves (Cornell 512^2 at 4 spp: 4096 waves, all resident from the
 // start, the slowest 1.5 times the median).  The samples of a pixel are added in the order of the sample loop
 // (raytracer_cpu.c:196-236) by the pixel's first lane, so the sum has the same bits.
+#ifndef RT_SAMPLES_WAVES
+#define RT_SAMPLES_WAVES 7  // (Cornell 512^2 at 4 spp, Mrays/s at 5 / 6 / 7 waves per SIMD: 7139 / 7710 / 7856; the pixel-per-lane kernel loses from 6 up)
+#endif
 template <bool COUNT, bool BATCH, bool FAST = false>
-__global__ __launch_bounds__(kBlock, FAST ? 4 : RT_STATIC_WAVES) void cast_samples_kernel(DevScene S, rthip_cast_settings c, uint64_t seed,
+__global__ __launch_bounds__(kBlock, FAST ? RT_FAST_WAVES : RT_SAMPLES_WAVES) void cast_samples_kernel(DevScene S, rthip_cast_settings c, uint64_t seed,
                                                               float* __restrict__ out, int width, int height,
                                                               rthip_shard shard, uint32_t log2_group, uint32_t accumulate,
                                                               uint64_t* counters, uint32_t inst_batch) {
