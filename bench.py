@@ -509,11 +509,20 @@ def ceilings(algo_bytes, traffic, valu_insts, kernel_ms, ms_per_step, n_streams,
     measured = None
     if traffic:
         measured = traffic / (cost_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        if measured > 1.0:  # FETCH_SIZE / WRITE_SIZE count at the L2's far side: bytes served by the Infinity Cache are among them
+            out["hbm_measured_note"] = f"{measured:.2f} by bytes counted behind the L2, Infinity Cache hits included: capped at 1"
+            measured = 1.0
         out["hbm_measured_frac"] = round(measured, 4)
         out["traffic_over_algorithmic"] = round(traffic / max(algo_bytes, 1), 3)
     issue = None
     if valu_insts:
+        # 4 cycles per wave64 instruction is the most an instruction takes: one whose active lanes all lie in one half of
+        # the wave is done in 2, so with few lanes at work the estimate overshoots -- it is capped at 1 and says so
         issue = valu_insts * 4.0 / (SIMDS * ENGINE_CLOCK_GHZ * 1e9) * 1e3 / cost_ms
+        if issue > 1.0:
+            out["valu_issue_note"] = (f"{issue:.2f} by instructions x 4 cycles: an upper estimate (an instruction with one "
+                                      "half of the wave idle takes 2 cycles), capped at 1")
+            issue = 1.0
         out["valu_issue_frac"] = round(issue, 4)
     if measured is not None and traffic >= 0.7 * algo_bytes:
         out["bounding"] = "hbm"

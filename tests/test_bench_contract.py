@@ -57,6 +57,7 @@ def check_derived(r):
     if c["hbm_algorithmic_frac"] is None:
         assert "cache-resident" in c["hbm_algorithmic_note"]
     assert c.get("hbm_measured_frac", 0.0) <= 1.0
+    assert c.get("valu_issue_frac", 0.0) <= 1.0 and (c.get("frac_of_bounding") or 0.0) <= 1.0
     if "frac_overlapped" in r:
         assert r["frac_overlapped"] is None or r["frac_overlapped"] <= 1.0
 
