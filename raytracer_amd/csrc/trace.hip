@@ -1031,7 +1031,8 @@ int tune_cast(rthip_ctx* ctx, const DevScene& scene, const rthip_cast_settings& 
     const bool deep = ctx->n_inst >= 64u || ctx->total_tris >= (1ull << 20);
     if (util < (deep ? 0.45 : 0.28)) {
         best->kernel = 0;
-        best->refill = nodes_per_ray < 64.0 ? 32u : 16u;
+        // (Cornell + mesh at 3840x2160, 20 box tests per ray: 4553 / 4986 / 5134 / 5108 / 4465 Mrays/s at 24 / 32 / 40 / 48 / 56)
+        best->refill = nodes_per_ray < 64.0 ? 40u : 16u;
         // (10 000 instances, entries 0.8 % of the box tests: 1146 / 1183 / 1164 / 1130 Mrays/s at batch 0 / 4 / 8 / 16)
         best->inst_batch = (nodes > 0 && entries / nodes > 0.02) ? 8u : ((nodes > 0 && entries / nodes > 0.005) ? 4u : 0u);
     } else {
