@@ -1,4 +1,4 @@
-"""Writes the results table of DESIGN.md (between the RESULTS markers) from a default `python bench.py` line."""
+"""Writes the results table of the design document (between its RESULTS markers) from a default `python bench.py` line."""
 import json
 import os
 import sys
