@@ -7,12 +7,16 @@ OUT=$ROOT/gpurun_out/pmc_l2occ
 mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
 export RTHIP_CAST_BANDS=1
+# a workload named <name>+fast runs with --traversal fast
 for W in ${@:-bunny instanced soup-rays}; do
+  NAME=${W%+fast}
+  TRAV=exact
+  [ "$NAME" != "$W" ] && TRAV=fast
   k=0
   for C in "TCC_HIT_sum TCC_MISS_sum" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_THREAD_CYCLES_VALU"; do
     k=$((k+1))
     timeout -s KILL 240 rocprofv3 --pmc $C --output-format csv -d $OUT/${W}_$k -- \
-      python3 $ROOT/bench.py --workload $W --streams 1 --steps 2 --warmup 0 --min-region-s 0 --no-cpu-baseline --no-workloads --build-sizes "" \
+      python3 $ROOT/bench.py --workload $NAME --traversal $TRAV --streams 1 --steps 2 --warmup 0 --min-region-s 0 --no-cpu-baseline --no-workloads --build-sizes "" \
       > $OUT/${W}_$k.log 2>&1 || { echo "pass $W $k failed"; tail -5 $OUT/${W}_$k.log; exit 1; }
   done
 done
