@@ -18,6 +18,7 @@ for name in sys.argv[1:] or ["soup-rays", "instanced-rays"]:
     wl = bench.make_workload(name)
     tr = T.rt_make_tracer(T.RT_TracerSettings(max_bounces=wl["bounces"], sky=wl["sky"]))
     T.rt_tracer_build_blas(tr, wl["world"]); T.rt_tracer_build_tlas(tr, wl["world"])
+    T.set_traversal(tr, os.environ.get("TRAVERSAL", "exact"))  # TRAVERSAL=fast: the ordered walk
     n = wl["rays"]
     g = torch.Generator(device="cuda"); g.manual_seed(2)
     lo, hi = wl.get("ray_box", ((0.0, 0.0, 0.0), (1.0, 1.0, 1.0)))
