@@ -1125,8 +1125,15 @@ def main():
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
+        # the line is out: a rank that never reaches this barrier (it failed or gave up above) must not hold the others
+        import threading
+
+        last = threading.Timer(60.0, lambda: os._exit(0))
+        last.daemon = True
+        last.start()
         dist.barrier()
         dist.destroy_process_group()
+        last.cancel()
 
 
 if __name__ == "__main__":
