@@ -12,12 +12,15 @@ export RTHIP_CAST_BANDS=1
 for W in ${@:-bunny instanced soup cornell soup-rays instanced-rays cornell-mesh heightfield bunny+fast instanced+fast soup+fast soup-rays+fast instanced-rays+fast heightfield+fast}; do
   SIZES=""
   [ "$W" = "bunny" ] && SIZES="10000000"
-  NAME=${W%+fast}
+  BASE=${W%@samples=*}
+  SAMPLES=0   # <name>@samples=K: K x K samples per pixel instead of the workload's own (the table keeps the suffix)
+  [ "$BASE" != "$W" ] && SAMPLES=${W#*@samples=}
+  NAME=${BASE%+fast}
   TRAV=exact
-  [ "$NAME" != "$W" ] && TRAV=fast
+  [ "$NAME" != "$BASE" ] && TRAV=fast
   for C in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU; do
     timeout -s KILL 240 rocprofv3 --pmc $C --output-format csv -d $OUT/${W}_${C} -- \
-      python3 $ROOT/bench.py --workload $NAME --traversal $TRAV --streams 1 --steps 2 --warmup 0 --min-region-s 0 --no-cpu-baseline --no-workloads --build-sizes "$SIZES" \
+      python3 $ROOT/bench.py --workload $NAME --traversal $TRAV --samples $SAMPLES --streams 1 --steps 2 --warmup 0 --min-region-s 0 --no-cpu-baseline --no-workloads --build-sizes "$SIZES" \
       > $OUT/${W}_${C}.log 2>&1 || { echo "pass $W $C failed"; tail -5 $OUT/${W}_${C}.log; exit 1; }
     echo "pass $W $C done"
   done
